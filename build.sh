@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds sgdnet_amd/lib/libsgdnet_hip.so (gfx950 only) and the CPU oracle.
+set -euo pipefail
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+SRC=sgdnet_amd/csrc
+OUT=sgdnet_amd/lib
+mkdir -p "$OUT" build
+# -ffp-contract=off: the exact-order kernels follow the reference's arithmetic
+# order without fused multiply-adds.
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -I$SRC -Wall -Wno-unused-function"
+pids=()
+for f in saga_exact.hip saga_batched.hip solver.cpp driver.cpp r_rng.cpp; do
+  o=build/${f%.*}.o
+  if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ "$SRC/common.hpp" -nt "$o" ] || [ "$SRC/device_math.hpp" -nt "$o" ] || [ include/sgdnet_hip.h -nt "$o" ]; then
+    $HIPCC $FLAGS -x hip -c "$SRC/$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgdnet_hip.so" build/saga_exact.o build/saga_batched.o build/solver.o build/driver.o build/r_rng.o
+make -s -C oracle liboracle.so
+echo "built $OUT/libsgdnet_hip.so"

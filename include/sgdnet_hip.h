@@ -1,0 +1,226 @@
+/*
+ * sgdnet_hip.h -- C ABI of the MI355X (gfx950) SAGA elastic-net backend.
+ *
+ * Drop-in boundary for the hot path of jolars/sgdnet (paths below are relative
+ * to the reference tree):
+ *
+ *   src/RcppExports.cpp:11-21,24-34  _sgdnet_SgdnetDense / _sgdnet_SgdnetSparse
+ *   src/sgdnet.cpp:358-375           SgdnetDense / SgdnetSparse (x, y, control)
+ *   R/sgdnet.R:346-366               the `control` list and the two call sites
+ *
+ * sgdnet_fit_dense / sgdnet_fit_sparse take exactly what those entry points
+ * take (R's column-major matrix or dgCMatrix slots, the response matrix, the 14
+ * control fields) and return exactly what src/sgdnet.cpp:275-284 returns.  The
+ * R-side binding (a .Call shim over these two functions) is shown in
+ * INTEGRATION.md and shim/sgdnet_shim.c.
+ *
+ * The sgdnet_solver_* functions expose the device-resident per-lambda SAGA
+ * loop (reference src/saga-sparse.h:194-383, src/saga-dense.h:99-224) for the
+ * benchmark harness, the parity tests and the multi-GPU driver.
+ *
+ * Plain pointers and sizes only; no C++ or torch types.  All functions return 0
+ * on success or a negative SGDNET_E* code; sgdnet_last_error() describes the
+ * most recent failure on the calling thread.  There is no CPU fallback: every
+ * compute entry point fails with SGDNET_ENODEVICE when no HIP device exists.
+ */
+#ifndef SGDNET_HIP_H_
+#define SGDNET_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGDNET_ABI_VERSION 1
+
+/* error codes */
+#define SGDNET_OK          0
+#define SGDNET_EINVAL     -1   /* bad argument */
+#define SGDNET_ENODEVICE  -2   /* no HIP device / HIP runtime failure at init */
+#define SGDNET_EHIP       -3   /* HIP call failed */
+#define SGDNET_ENOMEM     -4
+#define SGDNET_EUNSUPPORTED -5 /* valid request outside what a mode implements */
+#define SGDNET_ESTREAM    -6   /* explicit sample stream exhausted */
+
+/* control$family (R/sgdnet.R:185-188; src/sgdnet.cpp:305-331) */
+#define SGDNET_GAUSSIAN    0
+#define SGDNET_BINOMIAL    1
+#define SGDNET_MULTINOMIAL 2
+#define SGDNET_MGAUSSIAN   3
+
+/* penalty functor chosen by RunSaga (src/sgdnet.cpp:80-98; src/penalties.h) */
+#define SGDNET_RIDGE       0
+#define SGDNET_ELASTICNET  1
+#define SGDNET_GROUPLASSO  2
+
+/* execution mode of the SAGA loop */
+#define SGDNET_MODE_EXACT   0  /* the reference iteration, one draw at a time, in stream order */
+#define SGDNET_MODE_BATCHED 1  /* `batch` consecutive draws against one snapshot (sparse only) */
+
+/* x as R passes it to SgdnetSparse: the slots of a dgCMatrix (R/sgdnet.R:226). */
+typedef struct sgdnet_csc {
+  int64_t        n_rows;   /* Dim[0] = samples  */
+  int64_t        n_cols;   /* Dim[1] = features */
+  const int32_t* colptr;   /* @p, n_cols + 1    */
+  const int32_t* rowidx;   /* @i, 0-based, ascending within a column */
+  const double*  values;   /* @x                */
+} sgdnet_csc;
+
+/* One uniform(0,1) draw; the R shim passes unif_rand() so that R's own RNG is
+ * advanced exactly as Rcpp::RNGScope + R::runif would (src/RcppExports.cpp:14,
+ * src/saga-sparse.h:261). */
+typedef double (*sgdnet_unif_fn)(void* ctx);
+
+typedef struct sgdnet_control {
+  /* ---- the control list of R/sgdnet.R:346-359, field for field ---- */
+  int           debug;
+  double        elasticnet_mix;
+  int           family;               /* SGDNET_GAUSSIAN ... */
+  int           intercept;
+  int           is_sparse;            /* unused natively, as in the reference */
+  const double* lambda;               /* NULL / n_lambda_user == 0 => automatic path */
+  int           n_lambda_user;        /* length(control$lambda) */
+  double        lambda_min_ratio;
+  unsigned      max_iter;
+  int           n_lambda;
+  int           n_classes;
+  int           standardize;
+  int           standardize_response;
+  double        tol;
+  int           type_multinomial;     /* 0 = "ungrouped" (the only value R sends), 1 = "grouped" */
+
+  /* ---- sample order (exactly one draw per inner iteration) ---- */
+  const uint32_t* sample_stream;      /* explicit indices in [0, n), or NULL */
+  int64_t         sample_stream_len;
+  sgdnet_unif_fn  unif;               /* used when sample_stream == NULL and unif != NULL */
+  void*           unif_ctx;
+  uint32_t        seed;               /* else: built-in R-compatible Mersenne-Twister, set.seed(seed) */
+
+  /* ---- backend extensions; zero-initialised == reference behaviour ---- */
+  int           mode;                 /* SGDNET_MODE_* */
+  int64_t       batch;                /* batched mode: staleness window; 0 = automatic */
+  int           device;               /* HIP device ordinal */
+} sgdnet_control;
+
+/* Caller-allocated mirror of the list returned by src/sgdnet.cpp:275-284. */
+typedef struct sgdnet_result {
+  double*  a0;            /* n_classes * n_lambda            (list of numeric(K))        */
+  double*  beta;          /* n_classes * n_features * n_lambda (K fastest, as unlist())  */
+  double*  lambda;        /* n_lambda                                                    */
+  double*  dev_ratio;     /* n_lambda                                                    */
+  double*  return_codes;  /* n_lambda, 0 converged / 1 max_iter reached                  */
+  double*  losses;        /* n_lambda * max_iter or NULL; filled when control.debug      */
+  int32_t* losses_len;    /* n_lambda or NULL                                            */
+  double   nulldev;
+  double   npasses;
+  int64_t  draws_used;    /* inner iterations executed == uniform draws consumed         */
+} sgdnet_result;
+
+int sgdnet_abi_version(void);
+const char* sgdnet_last_error(void);
+int sgdnet_device_count(void);
+
+/* replaces _sgdnet_SgdnetSparse (src/RcppExports.cpp:24-34 -> src/sgdnet.cpp:369-375) */
+int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols,
+                      const sgdnet_control* control, sgdnet_result* out);
+
+/* replaces _sgdnet_SgdnetDense (src/RcppExports.cpp:11-21 -> src/sgdnet.cpp:359-365);
+ * x is n_samples x n_features column-major (an R numeric matrix). */
+int sgdnet_fit_dense(const double* x, int64_t n_samples, int64_t n_features,
+                     const double* y, int y_cols,
+                     const sgdnet_control* control, sgdnet_result* out);
+
+/* ------------------------------------------------------------------------ */
+/* Built-in R-compatible Mersenne-Twister (the generator behind R::runif at  */
+/* src/saga-sparse.h:261 under R's default RNGkind): 625 words = mti + mt[]. */
+/* ------------------------------------------------------------------------ */
+typedef struct sgdnet_rng { uint32_t mti; uint32_t mt[624]; } sgdnet_rng;
+void     sgdnet_rng_seed(sgdnet_rng* r, uint32_t seed);           /* set.seed(seed)        */
+double   sgdnet_rng_unif(sgdnet_rng* r);                          /* unif_rand()           */
+void     sgdnet_rng_fill(sgdnet_rng* r, uint32_t n_samples,       /* floor(runif(0, n))    */
+                         uint32_t* out, int64_t count);
+
+/* ------------------------------------------------------------------------ */
+/* Device-resident SAGA solver: state (w, intercept, g_memory, g_sum,        */
+/* g_sum_intercept) persists across calls, i.e. across the lambda path       */
+/* (src/sgdnet.cpp:187-198, 217-244).                                        */
+/* ------------------------------------------------------------------------ */
+typedef struct sgdnet_solver sgdnet_solver;
+
+typedef struct sgdnet_problem {
+  int      family;
+  int      n_classes;        /* K */
+  int64_t  n_samples;        /* samples resident on this device */
+  int64_t  n_total;          /* samples of the whole job (1/n of the gradient average); 0 => n_samples */
+  int64_t  n_features;
+  int      fit_intercept;
+  int      standardize;      /* sparse: implicit centring with x_center_scaled */
+  /* sample-major data, i.e. the matrix after AdaptiveTranspose (src/sgdnet.cpp:177):
+   * sparse: column i = sample i (rowptr n+1, feature ids ascending, values);
+   * dense:  x_dense is n_features x n_samples column-major. */
+  const int64_t* rowptr;
+  const int32_t* colidx;
+  const double*  values;
+  const double*  x_dense;
+  const double*  x_center_scaled;  /* n_features or NULL */
+  const double*  y;                /* y_rows x n_samples column-major (src/sgdnet.cpp:178) */
+  int            y_rows;
+  int            device;
+} sgdnet_problem;
+
+int  sgdnet_solver_create(const sgdnet_problem* prob, sgdnet_solver** out);
+void sgdnet_solver_destroy(sgdnet_solver* s);
+
+/* Saga(...) arguments that change per lambda: penalty functor, step size gamma,
+ * L2 strength alpha, L1 strength beta (src/saga-sparse.h:196,206-208). */
+int sgdnet_solver_set_penalty(sgdnet_solver* s, int penalty, double gamma, double alpha, double beta);
+
+/* Copy a state array between host and device.  which: 0 w (K x p), 1 intercept (K),
+ * 2 g_memory (K x n), 3 g_sum (K x p), 4 g_sum_intercept (K). */
+int sgdnet_solver_get_state(sgdnet_solver* s, int which, double* host);
+int sgdnet_solver_set_state(sgdnet_solver* s, int which, const double* host);
+
+/* Make `count` sample indices resident on the device (replaces any previous stream). */
+int sgdnet_solver_upload_stream(sgdnet_solver* s, const uint32_t* host, int64_t count);
+
+/* Run the SAGA loop of one lambda on the resident stream starting at `stream_offset`:
+ * epochs of `draws_per_epoch` inner iterations until ConvergenceCheck
+ * (src/utils.h:240-262) passes or max_epochs is reached.  Blocks until done.
+ * losses (max_epochs doubles) may be NULL. */
+int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch,
+                      int64_t stream_offset, int64_t draws_per_epoch,
+                      unsigned max_epochs, double tol,
+                      unsigned* epochs_run, int* converged, double* losses);
+
+/* Enqueue `n_epochs` batched epochs without convergence checks or host
+ * synchronisation (benchmark stepping).  sgdnet_solver_sync waits for them. */
+int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream_offset,
+                                 int64_t draws_per_epoch, int n_epochs);
+int sgdnet_solver_sync(sgdnet_solver* s);
+
+/* One batched epoch launched eagerly with HIP events around every gather
+ * kernel launch; returns summed kernel time and launch count. */
+int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_offset,
+                                int64_t draws_per_epoch, double* gather_ms, int* gather_launches,
+                                double* sweep_ms, int* sweep_launches);
+
+/* 2 * sum_i Loss_i (src/utils.h:304-329) over the resident samples. */
+int sgdnet_solver_deviance(sgdnet_solver* s, double* out);
+
+/* Multi-GPU merge: buffers hold 2*K*p + 2*K doubles in DEVICE memory:
+ * [g_sum - g_sum_ref | w - w_ref | g_sum_intercept - ref | intercept - ref].
+ * snapshot() records the reference point before a local epoch; export_delta() writes
+ * the deltas; apply_merged() sets state = ref + {1, w_weight, 1, w_weight} * merged. */
+int sgdnet_solver_snapshot(sgdnet_solver* s);
+int sgdnet_solver_export_delta(sgdnet_solver* s, void* device_buf);
+int sgdnet_solver_apply_merged(sgdnet_solver* s, const void* device_buf, double w_weight);
+int64_t sgdnet_solver_delta_len(const sgdnet_solver* s);
+
+/* ConvergenceCheck on the current w against the previous call's w (device-side). */
+int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGDNET_HIP_H_ */

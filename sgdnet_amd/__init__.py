@@ -1,0 +1,11 @@
+"""sgdnet_amd: MI355X (gfx950) SAGA elastic-net backend behind the sgdnet() API.
+
+The compute lives in sgdnet_amd/lib/libsgdnet_hip.so (hand-written HIP, C ABI in
+include/sgdnet_hip.h).  This package is the host-side mirror of the reference's
+R front-end for the fit path plus benchmark/multi-GPU plumbing.
+"""
+from ._lib import LIB_PATH, SgdnetError, load  # noqa: F401
+from .api import SgdnetFit, sgdnet  # noqa: F401
+from .solver import RRng, SagaSolver  # noqa: F401
+
+__all__ = ["sgdnet", "SgdnetFit", "SagaSolver", "RRng", "SgdnetError", "load", "LIB_PATH"]

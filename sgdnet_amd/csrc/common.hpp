@@ -1,0 +1,108 @@
+// Shared host/device declarations of the gfx950 SAGA backend.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sgdnet_hip.h"
+
+namespace sgdnet {
+
+void set_error(const char* fmt, ...);
+
+#define SGD_HIP_TRY(expr)                                                              \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      ::sgdnet::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                          __FILE__, __LINE__);                                         \
+      return SGDNET_EHIP;                                                              \
+    }                                                                                  \
+  } while (0)
+
+// src/constants.h:22 of the reference: 100 * DBL_EPSILON
+constexpr double kSmall = 100.0 * 2.220446049250313e-16;
+
+// Device view of one problem + its solver state.  Passed to kernels by value.
+struct SagaDev {
+  int family;
+  int K;         // n_classes
+  int Ky;        // rows of y
+  int fit_intercept;
+  int standardize;
+  int64_t n;     // resident samples
+  int64_t p;     // features
+  double n_total;  // samples of the whole job (the 1/n of the gradient average)
+  // data, sample-major (SURVEY.md 8a "x")
+  const int64_t* ptr;
+  const int32_t* idx;
+  const double* val;
+  const double* xd;   // dense p x n
+  const double* c;    // x_center_scaled (p) or nullptr
+  const double* y;    // Ky x n
+  // solver state (K fastest, like the reference's ArrayXXd K x p / K x n)
+  double* w;
+  double* G;      // g_sum
+  double* M;      // g_memory
+  double* b;      // intercept
+  double* gb;     // g_sum_intercept
+  double* w_prev; // ConvergenceCheck::w_prev
+  unsigned* lag;
+  // batched-mode scratch
+  double* D;      // K x p scatter accumulator
+  double* d0;     // K     intercept accumulator
+  int* claim;     // n     first-occurrence claims (K > 1)
+  const uint32_t* stream;
+};
+
+// Per-lambda parameters; lives in device memory so captured graphs stay valid
+// across the lambda path.
+struct LamParams {
+  int penalty;
+  double gamma;
+  double alpha;   // L2 strength
+  double beta;    // L1 strength
+  // batched mode: r^m and LS_m for the full batch and for the tail batch
+  double r_full, ls_full;
+  double r_tail, ls_tail;
+  int64_t m_full, m_tail;
+  // epoch bookkeeping for graph replays
+  int64_t stream_base;   // offset of the current epoch in the resident stream
+  int64_t draws_per_epoch;
+  int batch_seq;         // running batch id (claims)
+  // ConvergenceCheck scratch: bit patterns of max|dw| and max|w|
+  unsigned long long max_change_bits;
+  unsigned long long max_size_bits;
+  double loss_acc;
+};
+
+struct ExactCtl {
+  int64_t stream_off;
+  int64_t nit;          // inner iterations per epoch (the reference's n_samples)
+  unsigned max_epochs;
+  double tol;
+  const double* LS;     // lag_scaling table, nit + 1 entries (sparse)
+  int use_lds;          // w, g_sum (and lag) staged in LDS
+  int* out;             // [0] epochs run, [1] converged
+};
+
+// launchers implemented in the .hip files
+int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                        hipStream_t st);
+int launch_dense_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                       hipStream_t st);
+size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state);
+size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state);
+
+int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
+                        int batch_id_offset, hipStream_t st);
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, hipStream_t st);
+int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
+int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
+int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
+int launch_delta_export(const SagaDev& d, const double* ref, double* out, hipStream_t st);
+int launch_delta_apply(const SagaDev& d, const double* ref, const double* merged, double w_weight,
+                       hipStream_t st);
+int batched_max_classes();
+
+}  // namespace sgdnet

@@ -1,0 +1,554 @@
+// Lambda-path driver behind sgdnet_fit_sparse / sgdnet_fit_dense.
+//
+// Mirrors SetupSgdnet (reference src/sgdnet.cpp:119-285): preprocess, lambda
+// path, step sizes, then for every lambda {SAGA loop, deviance, rescale} with
+// the solver state kept resident in HBM across the path (warm starts,
+// src/sgdnet.cpp:187-198).  The per-fit setup passes are O(nnz) host loops in
+// this round (SURVEY.md 8 row f1 moves them onto the device); the SAGA loop and
+// the per-lambda deviance pass run on the GPU and there is no CPU fallback.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace sgdnet;
+
+namespace {
+
+struct Features {
+  bool sparse = false;
+  int64_t n = 0, p = 0;
+  // feature-major (as passed by R), preprocessed values
+  const int32_t* colptr = nullptr;
+  const int32_t* rowidx = nullptr;
+  std::vector<double> val;      // sparse values (scaled if standardize)
+  std::vector<double> xd;       // dense n x p column-major (standardised if requested)
+  // sample-major
+  std::vector<int64_t> sptr;
+  std::vector<int32_t> sidx;
+  std::vector<double> sval;
+  std::vector<double> xt;       // dense p x n
+  std::vector<double> x_center, x_scale, x_center_scaled;
+};
+
+// math.h:66-79 Mean / :114-130 StandardDeviation (population sd, 0 -> 1)
+void col_mean_sd(const double* x, int64_t n, int64_t m, double* mean, double* sd) {
+  for (int64_t j = 0; j < m; ++j) {
+    const double* col = x + j * n;
+    double s = 0.0;
+    for (int64_t i = 0; i < n; ++i) s += col[i];
+    mean[j] = s / (double)n;
+    double v = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+      const double dlt = col[i] - mean[j];
+      v += dlt * dlt;
+    }
+    v /= (double)n;
+    sd[j] = (v == 0.0) ? 1.0 : sqrt(v);
+  }
+}
+
+void standardize_cols(double* x, int64_t n, int64_t m, const double* mean, const double* sd) {
+  for (int64_t j = 0; j < m; ++j)
+    for (int64_t i = 0; i < n; ++i) x[i + j * n] = (x[i + j * n] - mean[j]) / sd[j];
+}
+
+// x^T v for every feature column; v is n x cols column-major
+void xt_times(const Features& X, const double* v, int cols, double* out) {
+  for (int c = 0; c < cols; ++c) {
+    const double* vc = v + (int64_t)c * X.n;
+    for (int64_t j = 0; j < X.p; ++j) {
+      double s = 0.0;
+      if (X.sparse) {
+        for (int64_t q = X.colptr[j]; q < X.colptr[j + 1]; ++q) s += X.val[(size_t)q] * vc[X.rowidx[q]];
+      } else {
+        const double* col = X.xd.data() + j * X.n;
+        for (int64_t i = 0; i < X.n; ++i) s += col[i] * vc[i];
+      }
+      out[j + (int64_t)c * X.p] = s;
+    }
+  }
+}
+
+double log_sum_exp_host(const double* x, int K) {
+  double mx = x[0];
+  for (int k = 1; k < K; ++k) mx = std::max(mx, x[k]);
+  double s = 0.0;
+  for (int k = 0; k < K; ++k) s += exp(x[k] - mx);
+  return log(s) + mx;
+}
+
+double binomial_link(double ybar) {     // families.h:141-150
+  const double pmin = 1e-9, pmax = 1.0 - pmin;
+  const double z = ybar > pmax ? pmax : (ybar < pmin ? pmin : ybar);
+  return log(z / (1.0 - z));
+}
+
+// Family::FitNullModel (families.h:112-117,190-201,287-298,380-385); yt is Ky x n
+void fit_null_model(int family, int K, const double* yt, int Ky, int64_t n, bool fit_intercept,
+                    double* b0) {
+  if (family == SGDNET_GAUSSIAN || family == SGDNET_MGAUSSIAN) {
+    for (int k = 0; k < Ky; ++k) {
+      double s = 0.0;
+      for (int64_t i = 0; i < n; ++i) s += yt[k + i * Ky];
+      b0[k] = s / (double)n;
+    }
+  } else if (family == SGDNET_BINOMIAL) {
+    if (fit_intercept) {
+      double s = 0.0;
+      for (int64_t i = 0; i < n; ++i) s += yt[i];
+      b0[0] = binomial_link(s / (double)n);
+    } else {
+      b0[0] = 0.0;
+    }
+  } else {
+    if (fit_intercept) {
+      for (int k = 0; k < K; ++k) b0[k] = 0.0;
+      for (int64_t i = 0; i < n; ++i) b0[(int64_t)(yt[i] + 0.5)] += 1.0 / (double)n;
+    } else {
+      for (int k = 0; k < K; ++k) b0[k] = 1.0 / (double)K;
+    }
+    double ls = 0.0;
+    for (int k = 0; k < K; ++k) ls += log(b0[k]);
+    for (int k = 0; k < K; ++k) b0[k] = log(b0[k]) - ls / (double)K;
+  }
+}
+
+// Family::NullDeviance (families.h:98-110,170-188,262-285,367-378); yt is Ky x n
+double null_deviance(int family, int K, const double* yt, int Ky, int64_t n, bool fit_intercept) {
+  std::vector<double> lp((size_t)std::max(K, Ky));
+  double loss = 0.0;
+  if (family == SGDNET_GAUSSIAN || family == SGDNET_MGAUSSIAN) {
+    fit_null_model(family, K, yt, Ky, n, true, lp.data());
+    for (int64_t i = 0; i < n; ++i) {
+      double s = 0.0;
+      for (int k = 0; k < Ky; ++k) {
+        const double dlt = lp[(size_t)k] - yt[k + i * Ky];
+        s += dlt * dlt;
+      }
+      loss += 0.5 * s;
+    }
+  } else if (family == SGDNET_BINOMIAL) {
+    fit_null_model(family, K, yt, Ky, n, fit_intercept, lp.data());
+    for (int64_t i = 0; i < n; ++i) loss += log(1.0 + exp(lp[0])) - yt[i] * lp[0];
+  } else {
+    fit_null_model(family, K, yt, Ky, n, fit_intercept, lp.data());
+    const double lse = log_sum_exp_host(lp.data(), K);
+    for (int64_t i = 0; i < n; ++i) loss += lse - lp[(size_t)(unsigned)(yt[i] + 0.5)];
+  }
+  return 2.0 * loss;
+}
+
+// Family::LambdaMax (families.h:119-126,203-220,300-325,387-406); y is n x Ky, preprocessed
+double lambda_max(int family, int K, const Features& X, const double* y, int Ky, const double* y_scale) {
+  const int64_t n = X.n, p = X.p;
+  double best = 0.0;
+  if (family == SGDNET_GAUSSIAN) {
+    std::vector<double> xty((size_t)p);
+    xt_times(X, y, 1, xty.data());
+    for (int64_t j = 0; j < p; ++j) best = std::max(best, fabs(xty[(size_t)j]));
+    return y_scale[0] * best / (double)n;
+  }
+  if (family == SGDNET_BINOMIAL) {
+    double ybar, ystd;
+    col_mean_sd(y, n, 1, &ybar, &ystd);
+    std::vector<double> ymap((size_t)n), xty((size_t)p);
+    for (int64_t i = 0; i < n; ++i) ymap[(size_t)i] = (y[i] - ybar) / ystd;
+    xt_times(X, ymap.data(), 1, xty.data());
+    for (int64_t j = 0; j < p; ++j) best = std::max(best, fabs(xty[(size_t)j]));
+    return ystd * best / (double)n;
+  }
+  if (family == SGDNET_MULTINOMIAL) {
+    std::vector<double> ymap((size_t)(n * K), 0.0), xty((size_t)(p * K)), ybar((size_t)K), ystd((size_t)K);
+    for (int64_t i = 0; i < n; ++i) ymap[(size_t)(i + (int64_t)(unsigned)(y[i] + 0.5) * n)] = 1.0;
+    col_mean_sd(ymap.data(), n, K, ybar.data(), ystd.data());
+    standardize_cols(ymap.data(), n, K, ybar.data(), ystd.data());
+    xt_times(X, ymap.data(), K, xty.data());
+    for (int k = 0; k < K; ++k)
+      for (int64_t j = 0; j < p; ++j)
+        best = std::max(best, fabs(xty[(size_t)(j + (int64_t)k * p)] * ystd[(size_t)k]));
+    return best / (double)n;
+  }
+  std::vector<double> ymap(y, y + n * Ky), xty((size_t)(p * Ky)), ybar((size_t)Ky), ystd((size_t)Ky);
+  col_mean_sd(y, n, Ky, ybar.data(), ystd.data());
+  standardize_cols(ymap.data(), n, Ky, ybar.data(), ystd.data());
+  xt_times(X, ymap.data(), Ky, xty.data());
+  for (int64_t j = 0; j < p; ++j) {
+    double s = 0.0;
+    for (int k = 0; k < Ky; ++k) {
+      const double v = xty[(size_t)(j + (int64_t)k * p)] * (y_scale[k] * ystd[(size_t)k]);
+      s += v * v;
+    }
+    best = std::max(best, sqrt(s));
+  }
+  return best / (double)n;
+}
+
+// Where the sample order comes from (include/sgdnet_hip.h "sample order").
+struct DrawSource {
+  const sgdnet_control* ctl;
+  sgdnet_rng rng;
+  int64_t pos = 0;
+  explicit DrawSource(const sgdnet_control* c) : ctl(c) { sgdnet_rng_seed(&rng, c->seed); }
+  int fill(uint32_t n, uint32_t* out, int64_t count) {
+    if (ctl->sample_stream) {
+      if (pos + count > ctl->sample_stream_len) {
+        set_error("explicit sample stream exhausted: %lld draws requested, %lld supplied",
+                  (long long)(pos + count), (long long)ctl->sample_stream_len);
+        return SGDNET_ESTREAM;
+      }
+      memcpy(out, ctl->sample_stream + pos, sizeof(uint32_t) * (size_t)count);
+    } else if (ctl->unif) {
+      const double nd = (double)n;
+      for (int64_t i = 0; i < count; ++i) {
+        double u;
+        do {
+          u = ctl->unif(ctl->unif_ctx);
+        } while (u <= 0.0 || u >= 1.0);
+        out[i] = (uint32_t)floor(nd * u);
+      }
+    } else {
+      sgdnet_rng_fill(&rng, n, out, count);
+    }
+    pos += count;
+    return SGDNET_OK;
+  }
+};
+
+int64_t auto_batch(const Features& X) {
+  // Staleness window that keeps the stale-sum update inside the linear-scaling
+  // regime of mini-batch SAGA: about L_max / L_F draws, which for uniformly
+  // sparse data is a small multiple of n_features (DESIGN.md "Choosing the batch").
+  const int64_t b = 2 * X.p;
+  return std::max<int64_t>(64, std::min<int64_t>(b, 65536));
+}
+
+int validate(const sgdnet_control* c, const sgdnet_result* out, int y_cols) {
+  if (!c || !out || !out->a0 || !out->beta || !out->lambda || !out->dev_ratio || !out->return_codes) {
+    set_error("null control/result pointer");
+    return SGDNET_EINVAL;
+  }
+  if (c->family < SGDNET_GAUSSIAN || c->family > SGDNET_MGAUSSIAN) {
+    set_error("unknown family %d", c->family);
+    return SGDNET_EINVAL;
+  }
+  if (c->n_lambda <= 0 || c->n_classes <= 0 || c->max_iter == 0 || c->tol < 0.0 ||
+      c->elasticnet_mix < 0.0 || c->elasticnet_mix > 1.0) {
+    set_error("invalid control field (n_lambda, n_classes, max_iter, tol or elasticnet_mix)");
+    return SGDNET_EINVAL;
+  }
+  if (c->n_lambda_user > 0 && (c->n_lambda_user != c->n_lambda || !c->lambda)) {
+    set_error("control.lambda must hold n_lambda values");
+    return SGDNET_EINVAL;
+  }
+  if (c->family == SGDNET_MGAUSSIAN ? (y_cols != c->n_classes) : (y_cols != 1)) {
+    set_error("response has %d columns, family expects %d", y_cols,
+              c->family == SGDNET_MGAUSSIAN ? c->n_classes : 1);
+    return SGDNET_EINVAL;
+  }
+  if (c->debug && (!out->losses || !out->losses_len)) {
+    set_error("control.debug needs result.losses and result.losses_len");
+    return SGDNET_EINVAL;
+  }
+  return SGDNET_OK;
+}
+
+int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ctl, sgdnet_result* out) {
+  const int family = ctl->family, K = ctl->n_classes;
+  const int64_t n = X.n, p = X.p;
+  const int n_lambda = ctl->n_lambda;
+  const bool fit_intercept = ctl->intercept != 0;
+  const double mix = ctl->elasticnet_mix;
+
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available: the SAGA backend has no CPU fallback");
+    return SGDNET_ENODEVICE;
+  }
+
+  std::vector<double> y(y_in, y_in + n * Ky);
+  std::vector<double> yt((size_t)(n * Ky));
+  std::vector<double> y_center((size_t)K, 0.0), y_scale((size_t)K, 1.0);
+
+  auto transpose_y = [&]() {
+    for (int64_t i = 0; i < n; ++i)
+      for (int k = 0; k < Ky; ++k) yt[(size_t)(k + i * Ky)] = y[(size_t)(i + (int64_t)k * n)];
+  };
+
+  transpose_y();
+  out->nulldev = null_deviance(family, K, yt.data(), Ky, n, fit_intercept);      // sgdnet.cpp:154
+
+  if (family == SGDNET_GAUSSIAN) {                                               // families.h:68-79
+    col_mean_sd(y.data(), n, 1, y_center.data(), y_scale.data());
+    for (int64_t i = 0; i < n; ++i) y[(size_t)i] = (y[(size_t)i] - y_center[0]) / y_scale[0];
+  } else if (family == SGDNET_MGAUSSIAN && ctl->standardize_response) {          // families.h:337-348
+    std::vector<double> m((size_t)Ky), s((size_t)Ky);
+    col_mean_sd(y.data(), n, Ky, m.data(), s.data());
+    standardize_cols(y.data(), n, Ky, m.data(), s.data());
+  }
+
+  // RegularizationPath: utils.h:142-181
+  std::vector<double> lambda((size_t)n_lambda), alpha((size_t)n_lambda), beta((size_t)n_lambda);
+  if (ctl->n_lambda_user == 0) {
+    const double lmax = lambda_max(family, K, X, y.data(), Ky, y_scale.data()) / std::max(mix, 0.001);
+    if (lmax != 0.0) {
+      const double log_from = log(lmax);
+      const double step = (log(lmax * ctl->lambda_min_ratio) - log_from) / (double)(n_lambda - 1);
+      for (int i = 0; i < n_lambda; ++i) lambda[(size_t)i] = exp(log_from + i * step);
+    } else {
+      std::fill(lambda.begin(), lambda.end(), 0.0);
+    }
+  } else {
+    std::copy(ctl->lambda, ctl->lambda + n_lambda, lambda.begin());
+  }
+  const double max_scale = *std::max_element(y_scale.begin(), y_scale.end());
+  for (int i = 0; i < n_lambda; ++i) {
+    alpha[(size_t)i] = (1.0 - mix) * lambda[(size_t)i] / max_scale;
+    beta[(size_t)i] = mix * lambda[(size_t)i] / max_scale;
+  }
+
+  transpose_y();                                                                 // sgdnet.cpp:178
+
+  // ColNormsMax: utils.h:60-85
+  double norm_max = 0.0;
+  if (X.sparse) {
+    double csq = 0.0;
+    if (ctl->standardize)
+      for (int64_t j = 0; j < p; ++j) csq += X.x_center_scaled[(size_t)j] * X.x_center_scaled[(size_t)j];
+    for (int64_t i = 0; i < n; ++i) {
+      double nrm = 0.0, cnz = 0.0;
+      for (int64_t q = X.sptr[(size_t)i]; q < X.sptr[(size_t)i + 1]; ++q) {
+        if (ctl->standardize) {
+          const double cj = X.x_center_scaled[(size_t)X.sidx[(size_t)q]];
+          const double dlt = X.sval[(size_t)q] - cj;
+          nrm += dlt * dlt;
+          cnz += cj * cj;
+        } else {
+          nrm += X.sval[(size_t)q] * X.sval[(size_t)q];
+        }
+      }
+      if (ctl->standardize) nrm += csq - cnz;
+      norm_max = std::max(norm_max, nrm);
+    }
+  } else {
+    for (int64_t i = 0; i < n; ++i) {
+      double nrm = 0.0;
+      for (int64_t j = 0; j < p; ++j) nrm += X.xt[(size_t)(j + i * p)] * X.xt[(size_t)(j + i * p)];
+      norm_max = std::max(norm_max, nrm);
+    }
+  }
+  const double L_scaling = (family == SGDNET_GAUSSIAN || family == SGDNET_MGAUSSIAN) ? 1.0 : 0.25;
+
+  std::vector<double> b0((size_t)K, 0.0);
+  fit_null_model(family, K, yt.data(), Ky, n, fit_intercept, b0.data());          // sgdnet.cpp:210
+  const double null_dev_scaled = null_deviance(family, K, yt.data(), Ky, n, fit_intercept);  // :211
+
+  // penalty functor: sgdnet.cpp:80-98
+  int penalty = SGDNET_ELASTICNET;
+  if (mix == 0.0) penalty = SGDNET_RIDGE;
+  else if (family == SGDNET_MGAUSSIAN || (family == SGDNET_MULTINOMIAL && ctl->type_multinomial == 1))
+    penalty = SGDNET_GROUPLASSO;
+
+  int mode = ctl->mode;
+  int64_t batch = ctl->batch;
+  if (mode == SGDNET_MODE_BATCHED) {
+    if (!X.sparse) {
+      set_error("batched mode is implemented for sparse x only; dense x runs in exact mode");
+      return SGDNET_EUNSUPPORTED;
+    }
+    if (batch <= 0) batch = auto_batch(X);
+  } else if (mode != SGDNET_MODE_EXACT) {
+    set_error("unknown mode %d", mode);
+    return SGDNET_EINVAL;
+  }
+
+  sgdnet_problem pb{};
+  pb.family = family;
+  pb.n_classes = K;
+  pb.n_samples = n;
+  pb.n_total = n;
+  pb.n_features = p;
+  pb.fit_intercept = fit_intercept ? 1 : 0;
+  pb.standardize = (X.sparse && ctl->standardize) ? 1 : 0;
+  if (X.sparse) {
+    pb.rowptr = X.sptr.data();
+    pb.colidx = X.sidx.data();
+    pb.values = X.sval.data();
+    pb.x_center_scaled = pb.standardize ? X.x_center_scaled.data() : nullptr;
+  } else {
+    pb.x_dense = X.xt.data();
+  }
+  pb.y = yt.data();
+  pb.y_rows = Ky;
+  pb.device = ctl->device;
+
+  sgdnet_solver* S = nullptr;
+  int rc = sgdnet_solver_create(&pb, &S);
+  if (rc) return rc;
+  struct Guard {
+    sgdnet_solver* s;
+    ~Guard() { sgdnet_solver_destroy(s); }
+  } guard{S};
+
+  rc = sgdnet_solver_set_state(S, 1, b0.data());
+  if (rc) return rc;
+
+  DrawSource draws(ctl);
+  std::vector<uint32_t> chunk((size_t)n);
+  std::vector<double> w((size_t)(K * p)), b((size_t)K), xbb((size_t)K);
+  std::vector<double> losses(ctl->debug ? (size_t)ctl->max_iter : 0);
+  double n_iter = 0.0;
+
+  for (int li = 0; li < n_lambda; ++li) {                                        // sgdnet.cpp:217-273
+    // StepSize: utils.h:31-51
+    const double L = (norm_max + (fit_intercept ? 1.0 : 0.0)) * L_scaling + alpha[(size_t)li];
+    const double mu_n = 2.0 * (double)n * alpha[(size_t)li];
+    const double gamma = 1.0 / (2.0 * L + std::min(L, mu_n));
+    rc = sgdnet_solver_set_penalty(S, penalty, gamma, alpha[(size_t)li], beta[(size_t)li]);
+    if (rc) return rc;
+
+    unsigned epochs = 0;
+    int converged = 0;
+    // one epoch per launch: exactly the draws the reference would consume are taken
+    // from the source (R's RNG state after the call matches, SURVEY.md 8b "RNG")
+    while (epochs < ctl->max_iter && !converged) {
+      rc = draws.fill((uint32_t)n, chunk.data(), n);
+      if (rc) return rc;
+      rc = sgdnet_solver_upload_stream(S, chunk.data(), n);
+      if (rc) return rc;
+      unsigned ran = 0;
+      rc = sgdnet_solver_run(S, mode, batch, 0, n, 1, ctl->tol, &ran, &converged,
+                             ctl->debug ? losses.data() + epochs : nullptr);
+      if (rc) return rc;
+      epochs += ran;
+    }
+    n_iter += (double)epochs;
+    out->return_codes[li] = (epochs == ctl->max_iter) ? 1.0 : 0.0;               // saga-sparse.h:376-382
+    if (ctl->debug) {
+      memcpy(out->losses + (size_t)li * ctl->max_iter, losses.data(), sizeof(double) * epochs);
+      out->losses_len[li] = (int32_t)epochs;
+    }
+
+    double dev = 0.0;
+    rc = sgdnet_solver_deviance(S, &dev);                                        // sgdnet.cpp:246-256
+    if (rc) return rc;
+    out->dev_ratio[li] = 1.0 - dev / null_dev_scaled;                            // :258
+    out->lambda[li] = lambda[(size_t)li];
+
+    // Rescale: utils.h:352-378
+    rc = sgdnet_solver_get_state(S, 0, w.data());
+    if (rc) return rc;
+    rc = sgdnet_solver_get_state(S, 1, b.data());
+    if (rc) return rc;
+    double* bo = out->beta + (size_t)li * (size_t)(K * p);
+    double* ao = out->a0 + (size_t)li * (size_t)K;
+    std::fill(xbb.begin(), xbb.end(), 0.0);
+    for (int64_t j = 0; j < p; ++j)
+      for (int k = 0; k < K; ++k) {
+        const double v = w[(size_t)(k + j * K)] * (y_scale[(size_t)k] / X.x_scale[(size_t)j]);
+        bo[k + j * K] = v;
+        xbb[(size_t)k] += X.x_center[(size_t)j] * v;
+      }
+    for (int k = 0; k < K; ++k)
+      ao[k] = fit_intercept ? b[(size_t)k] * y_scale[(size_t)k] + y_center[(size_t)k] - xbb[(size_t)k]
+                            : b[(size_t)k];
+  }
+  out->npasses = n_iter;
+  out->draws_used = draws.pos;
+  return SGDNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols, const sgdnet_control* ctl,
+                      sgdnet_result* out) {
+  int rc = validate(ctl, out, y_cols);
+  if (rc) return rc;
+  if (!x || !y || x->n_rows <= 0 || x->n_cols <= 0 || !x->colptr || !x->rowidx || !x->values) {
+    set_error("sgdnet_fit_sparse: invalid matrix");
+    return SGDNET_EINVAL;
+  }
+  Features X;
+  X.sparse = true;
+  X.n = x->n_rows;
+  X.p = x->n_cols;
+  X.colptr = x->colptr;
+  X.rowidx = x->rowidx;
+  const int64_t n = X.n, p = X.p, nnz = x->colptr[p];
+  X.val.assign(x->values, x->values + nnz);
+  X.x_center.assign((size_t)p, 0.0);
+  X.x_scale.assign((size_t)p, 1.0);
+  X.x_center_scaled.assign((size_t)p, 0.0);
+  if (ctl->standardize) {                                     // utils.h:110-121, math.h:66-79,89-112
+    for (int64_t j = 0; j < p; ++j) {
+      const int64_t q0 = x->colptr[j], q1 = x->colptr[j + 1];
+      double s = 0.0;
+      for (int64_t q = q0; q < q1; ++q) s += X.val[(size_t)q];
+      const double mean = s / (double)n;
+      double var = 0.0;
+      for (int64_t q = q0; q < q1; ++q) var += pow(X.val[(size_t)q] - mean, 2) / (double)n;
+      var += (double)(n - (q1 - q0)) * mean * mean / (double)n;
+      const double sd = (var == 0.0) ? 1.0 : sqrt(var);
+      for (int64_t q = q0; q < q1; ++q) X.val[(size_t)q] /= sd;
+      X.x_center[(size_t)j] = mean;
+      X.x_scale[(size_t)j] = sd;
+      X.x_center_scaled[(size_t)j] = mean / sd;             // sgdnet.cpp:150
+    }
+  }
+  // AdaptiveTranspose (utils.h:276-281): counting sort into sample-major order
+  X.sptr.assign((size_t)n + 1, 0);
+  for (int64_t q = 0; q < nnz; ++q) {
+    const int32_t r = x->rowidx[q];
+    if (r < 0 || r >= n) {
+      set_error("row index %d out of range at position %lld", r, (long long)q);
+      return SGDNET_EINVAL;
+    }
+    X.sptr[(size_t)r + 1]++;
+  }
+  for (int64_t i = 0; i < n; ++i) X.sptr[(size_t)i + 1] += X.sptr[(size_t)i];
+  X.sidx.resize((size_t)nnz);
+  X.sval.resize((size_t)nnz);
+  {
+    std::vector<int64_t> fill(X.sptr.begin(), X.sptr.end() - 1);
+    for (int64_t j = 0; j < p; ++j)
+      for (int64_t q = x->colptr[j]; q < x->colptr[j + 1]; ++q) {
+        const int64_t dst = fill[(size_t)x->rowidx[q]]++;
+        X.sidx[(size_t)dst] = (int32_t)j;
+        X.sval[(size_t)dst] = X.val[(size_t)q];
+      }
+  }
+  return fit_common(X, y, y_cols, ctl, out);
+}
+
+int sgdnet_fit_dense(const double* x, int64_t n, int64_t p, const double* y, int y_cols,
+                     const sgdnet_control* ctl, sgdnet_result* out) {
+  int rc = validate(ctl, out, y_cols);
+  if (rc) return rc;
+  if (!x || !y || n <= 0 || p <= 0) {
+    set_error("sgdnet_fit_dense: invalid matrix");
+    return SGDNET_EINVAL;
+  }
+  Features X;
+  X.sparse = false;
+  X.n = n;
+  X.p = p;
+  X.xd.assign(x, x + n * p);
+  X.x_center.assign((size_t)p, 0.0);
+  X.x_scale.assign((size_t)p, 1.0);
+  X.x_center_scaled.assign((size_t)p, 0.0);                   // sgdnet.cpp:151
+  if (ctl->standardize) {                                     // utils.h:99-108
+    col_mean_sd(X.xd.data(), n, p, X.x_center.data(), X.x_scale.data());
+    standardize_cols(X.xd.data(), n, p, X.x_center.data(), X.x_scale.data());
+  }
+  X.xt.resize((size_t)(n * p));                               // utils.h:283-288
+  for (int64_t i = 0; i < n; ++i)
+    for (int64_t j = 0; j < p; ++j) X.xt[(size_t)(j + i * p)] = X.xd[(size_t)(i + j * n)];
+  return fit_common(X, y, y_cols, ctl, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,417 @@
+// Batched ("B-stale") sparse SAGA kernels for gfx950: the throughput path.
+//
+// A batch is `m` consecutive draws of the sample stream evaluated against one
+// snapshot of (w, intercept).  In unscaled coordinates (true w = wscale * w of
+// the reference) the reference iteration src/saga-sparse.h:258-337 applied to
+// the batch becomes, per feature j (DESIGN.md "Batched mode"):
+//
+//   gather : per draw i   lp = w . x_s + b ; g = Gradient(lp, y_s)            (:274, :279)
+//                         gc = g - g_memory[s] ; g_memory[s] = g              (:281-282)
+//                         D[:, j] += x_sj * gc   for j in nz(x_s)             (:306-313, :328-335)
+//   sweep  : per feature  w_j = r^m w_j - gamma LS_m G_j - gamma D_j ; prox   (:316-325 + penalties.h)
+//                         G_j += D_j / n ;  D_j = 0
+//            intercept    gb += d0/n ; b -= gamma (0.01 m gb + d0/n)          (:300-304)
+//
+// with r = 1 - alpha*gamma and LS_m = sum_{k<m} r^k (= lag_scaling[m], :229-240).
+// m == 1 is the reference iteration itself.  A sample drawn twice inside one
+// batch sees the same snapshot, so its second draw has gc == 0: the first draw
+// claims the sample (atomic exchange) and later ones contribute nothing.
+//
+// Memory behaviour: the gather kernel is the HBM-bound one -- per draw it pulls
+// one stream entry, two row pointers, z indices, z values, y and the gradient
+// memory (algorithmic 16 + 12 z + 16 K bytes) at random sample
+// positions; 16-lane groups own one draw so that a wavefront has 4 independent
+// gathers in flight and reduces x.w with intra-row shuffles.  w, D and G are
+// K*p doubles (80 KB at 10k features) and stay L2 / Infinity-Cache resident.
+#include "device_math.hpp"
+
+namespace sgdnet {
+
+namespace {
+
+constexpr int kGroup = 16;          // lanes per draw
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ double group_sum(double v) {
+  v += __shfl_xor(v, 8, kGroup);
+  v += __shfl_xor(v, 4, kGroup);
+  v += __shfl_xor(v, 2, kGroup);
+  v += __shfl_xor(v, 1, kGroup);
+  return v;
+}
+
+__device__ __forceinline__ void atomic_add_f64(double* p, double v) {
+  // no-return global_atomic_add_f64
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v) {
+  // v >= 0: the IEEE bit pattern is monotone in v
+  __hip_atomic_fetch_max(p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------
+// gather: one 16-lane group per draw, one draw per group (every draw of the
+// batch is in flight at once: the kernel is a chain of dependent loads
+// stream -> rowptr -> idx/val -> w, so parallelism, not per-thread work, hides
+// the HBM latency).  The claim exchange, y and the old gradient memory do not
+// depend on the row and are issued first so that they overlap the chain.
+// --------------------------------------------------------------------------
+template <int KMAX>
+__global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, const LamParams* lamp,
+                                                                   int64_t t0_in_epoch, int m,
+                                                                   int batch_id_offset) {
+  const int K = KMAX == 1 ? 1 : d.K;
+  const int gl = threadIdx.x & (kGroup - 1);
+  const int i = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const bool active = i < m;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+
+  double gc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;
+
+  if (active) {
+    const uint32_t s = d.stream[t0 + i];
+    const int64_t q0 = d.ptr[s], q1 = d.ptr[s + 1];
+
+    // independent of the row: claim, response, old gradient memory
+    int prev = batch_id;
+    if (gl == 0)
+      prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double* ys = d.y + (int64_t)s * d.Ky;
+    double yv[KMAX];
+    double mold[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      yv[k] = (k < d.Ky) ? ys[k] : 0.0;
+      mold[k] = (k < K) ? d.M[k + (int64_t)s * K] : 0.0;
+    }
+
+    double acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
+
+    // first (usually only) chunk of the row stays in registers for the scatter
+    int64_t jf = -1;
+    double vf = 0.0;
+    {
+      const int64_t q = q0 + gl;
+      if (q < q1) {
+        jf = d.idx[q];
+        vf = d.val[q];
+        const double* wj = d.w + jf * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K) acc[k] += vf * wj[k];
+      }
+    }
+    for (int64_t q = q0 + kGroup + gl; q < q1; q += kGroup) {
+      const int64_t j = d.idx[q];
+      const double v = d.val[q];
+      const double* wj = d.w + j * K;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) acc[k] += v * wj[k];
+    }
+
+    double lp[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) lp[k] = group_sum(acc[k]) + ((k < K) ? d.b[k] : 0.0);
+
+    const int first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
+    if (first) {
+      // gradient: every lane of the group computes the same K values
+      double g[KMAX];
+      if (d.family == SGDNET_MULTINOMIAL) {
+        const double lse = log_sum_exp(lp, K);
+        const unsigned cls = (unsigned)(yv[0] + 0.5);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          g[k] = 0.0;
+          if (k < K) {
+            g[k] = exp(lp[k] - lse);
+            if ((unsigned)k == cls) g[k] -= 1.0;
+          }
+        }
+      } else if (d.family == SGDNET_BINOMIAL) {
+        g[0] = 1.0 - yv[0] - 1.0 / (1.0 + exp(lp[0]));
+      } else {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) g[k] = (k < K) ? lp[k] - yv[k] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          gc[k] = g[k] - mold[k];
+          if (gl == (k & (kGroup - 1))) d.M[k + (int64_t)s * K] = g[k];
+        }
+      }
+
+      // scatter into D
+      if (jf >= 0) {
+        double* dj = d.D + jf * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K && gc[k] != 0.0) atomic_add_f64(dj + k, vf * gc[k]);
+      }
+      for (int64_t q = q0 + kGroup + gl; q < q1; q += kGroup) {
+        const int64_t j = d.idx[q];
+        const double v = d.val[q];
+        double* dj = d.D + j * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K && gc[k] != 0.0) atomic_add_f64(dj + k, v * gc[k]);
+      }
+    }
+    if (gl != 0) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;   // count each draw once below
+    }
+  }
+
+  // intercept accumulator: wave reduce, one atomic per wave and class
+  if (d.fit_intercept) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const double tot = wave_sum(gc[k]);
+        if ((threadIdx.x & 63) == 0 && tot != 0.0) atomic_add_f64(d.d0 + k, tot);
+      }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// sweep: one thread per feature (all K classes: GroupLasso needs the column norm).
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, LamParams* lamp, int tail) {
+  const int K = d.K;
+  const int penalty = lamp->penalty;
+  const double gamma = lamp->gamma, beta = lamp->beta;
+  const double r_m = tail ? lamp->r_tail : lamp->r_full;
+  const double ls_m = tail ? lamp->ls_tail : lamp->ls_full;
+  const double m_d = (double)(tail ? lamp->m_tail : lamp->m_full);
+  const double n_d = d.n_total;
+  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (j < d.p) {
+    double* wj = d.w + j * K;
+    double* gj = d.G + j * K;
+    double* dj = d.D + j * K;
+    const double gls = gamma * ls_m;
+    if (penalty == SGDNET_GROUPLASSO) {
+      double nrm = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const double v = r_m * wj[k] - gls * gj[k] - gamma * dj[k];
+        wj[k] = v;
+        nrm += v * v;
+      }
+      nrm = sqrt(nrm);
+      const double factor = beta * gamma * ls_m / nrm;
+      if (factor < 1.0) {
+        for (int k = 0; k < K; ++k) wj[k] *= 1.0 - factor;
+      } else {
+        for (int k = 0; k < K; ++k) wj[k] = 0.0;
+      }
+      for (int k = 0; k < K; ++k) {
+        gj[k] += dj[k] / n_d;
+        dj[k] = 0.0;
+      }
+    } else {
+      const double tau = beta * gamma * ls_m;
+      for (int k = 0; k < K; ++k) {
+        const double dk = dj[k];
+        double v = r_m * wj[k] - gls * gj[k] - gamma * dk;
+        if (penalty == SGDNET_ELASTICNET) v = soft_threshold(v, tau);
+        wj[k] = v;
+        if (dk != 0.0) {
+          gj[k] += dk / n_d;
+          dj[k] = 0.0;
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < K && d.fit_intercept) {
+    const int k = threadIdx.x;
+    const double dk = d.d0[k] / n_d;
+    const double gbk = d.gb[k] + dk;
+    d.gb[k] = gbk;
+    d.b[k] -= gamma * (gbk * 0.01 * m_d + dk);
+    d.d0[k] = 0.0;
+  }
+}
+
+// Advances the epoch bookkeeping that graph replays read.
+__global__ void saga_epoch_end_kernel(LamParams* lamp, int batches) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    lamp->stream_base += lamp->draws_per_epoch;
+    lamp->batch_seq += batches;
+  }
+}
+
+// ConvergenceCheck (src/utils.h:240-262): max |w - w_prev| and max |w|, then w_prev = w.
+__global__ __launch_bounds__(kBlock) void saga_convergence_kernel(SagaDev d, LamParams* lamp) {
+  const int64_t len = (int64_t)d.K * d.p;
+  double max_change = 0.0, max_size = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+    const double v = d.w[i];
+    max_change = fmax(max_change, fabs(v - d.w_prev[i]));
+    max_size = fmax(max_size, fabs(v));
+    d.w_prev[i] = v;
+  }
+  max_change = wave_max(max_change);
+  max_size = wave_max(max_size);
+  if ((threadIdx.x & 63) == 0) {
+    atomic_max_bits(&lamp->max_change_bits, max_change);
+    atomic_max_bits(&lamp->max_size_bits, max_size);
+  }
+}
+
+// Sum of per-sample losses: Deviance / 2 (src/utils.h:304-329) or n * EpochLoss (:199-227).
+template <bool kSparse>
+__global__ __launch_bounds__(kBlock) void saga_loss_kernel(SagaDev d, LamParams* lamp) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lps = reinterpret_cast<double*>(smem);   // [groups per block][K]
+  const int K = d.K;
+  const int gl = threadIdx.x & (kGroup - 1);
+  const int gib = threadIdx.x / kGroup;
+  const int64_t group = ((int64_t)blockIdx.x * kBlock + threadIdx.x) / kGroup;
+  const int64_t ngroups = (int64_t)gridDim.x * (kBlock / kGroup);
+  double* lp = lps + (size_t)gib * K;
+  double loss = 0.0;
+  for (int64_t s = group; s < d.n; s += ngroups) {
+    for (int k = 0; k < K; ++k) {
+      double acc = 0.0;
+      if (kSparse) {
+        for (int64_t q = d.ptr[s] + gl; q < d.ptr[s + 1]; q += kGroup)
+          acc += d.val[q] * d.w[k + (int64_t)d.idx[q] * K];
+      } else {
+        for (int64_t j = gl; j < d.p; j += kGroup) acc += d.xd[s * d.p + j] * d.w[k + j * K];
+      }
+      if (kSparse && d.standardize)
+        for (int64_t j = gl; j < d.p; j += kGroup) acc -= d.w[k + j * K] * d.c[j];
+      acc = group_sum(acc);
+      if (gl == 0) lp[k] = acc + d.b[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (gl == 0) loss += family_loss(d.family, K, lp, d.y + s * d.Ky);
+    __builtin_amdgcn_wave_barrier();
+  }
+  loss = wave_sum(loss);
+  if ((threadIdx.x & 63) == 0 && loss != 0.0) atomic_add_f64(&lamp->loss_acc, loss);
+}
+
+// Multi-GPU merge helpers.  Layout: [dG (Kp) | dw (Kp) | dgb (K) | db (K)].
+__global__ __launch_bounds__(kBlock) void saga_delta_export_kernel(SagaDev d, const double* ref,
+                                                                   double* out) {
+  const int64_t KP = (int64_t)d.K * d.p;
+  const int64_t len = 2 * KP + 2 * d.K;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+    double cur;
+    if (i < KP) cur = d.G[i];
+    else if (i < 2 * KP) cur = d.w[i - KP];
+    else if (i < 2 * KP + d.K) cur = d.gb[i - 2 * KP];
+    else cur = d.b[i - 2 * KP - d.K];
+    out[i] = cur - ref[i];
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void saga_delta_apply_kernel(SagaDev d, const double* ref,
+                                                                  const double* merged, double w_weight) {
+  const int64_t KP = (int64_t)d.K * d.p;
+  const int64_t len = 2 * KP + 2 * d.K;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+    if (i < KP) d.G[i] = ref[i] + merged[i];
+    else if (i < 2 * KP) d.w[i - KP] = ref[i] + w_weight * merged[i];
+    else if (i < 2 * KP + d.K) d.gb[i - 2 * KP] = ref[i] + merged[i];
+    else d.b[i - 2 * KP - d.K] = ref[i] + w_weight * merged[i];
+  }
+}
+
+// ------------------------------ launchers ---------------------------------
+int batched_max_classes() { return 16; }
+
+int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
+                        int batch_id_offset, hipStream_t st) {
+  (void)tail;
+  const int draws_per_block = kBlock / kGroup;
+  int grid = (m + draws_per_block - 1) / draws_per_block;
+  if (grid < 1) grid = 1;
+  if (d.K == 1)
+    hipLaunchKernelGGL(saga_batch_gather_kernel<1>, dim3(grid), dim3(kBlock), 0, st, d, lam, t0_in_epoch,
+                       m, batch_id_offset);
+  else if (d.K <= 4)
+    hipLaunchKernelGGL(saga_batch_gather_kernel<4>, dim3(grid), dim3(kBlock), 0, st, d, lam, t0_in_epoch,
+                       m, batch_id_offset);
+  else if (d.K <= 16)
+    hipLaunchKernelGGL(saga_batch_gather_kernel<16>, dim3(grid), dim3(kBlock), 0, st, d, lam, t0_in_epoch,
+                       m, batch_id_offset);
+  else {
+    set_error("batched mode supports n_classes <= 16 (got %d)", d.K);
+    return SGDNET_EUNSUPPORTED;
+  }
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, hipStream_t st) {
+  const int grid = (int)((d.p + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, d, lam, tail);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_epoch_end(LamParams* lam, int batches, hipStream_t st) {
+  hipLaunchKernelGGL(saga_epoch_end_kernel, dim3(1), dim3(64), 0, st, lam, batches);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st) {
+  const int64_t len = (int64_t)d.K * d.p;
+  int grid = (int)((len + kBlock * 4 - 1) / (kBlock * 4));
+  if (grid < 1) grid = 1;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(saga_convergence_kernel, dim3(grid), dim3(kBlock), 0, st, d, lam);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st) {
+  const int64_t groups = d.n;
+  int grid = (int)((groups + (kBlock / kGroup) * 8 - 1) / ((kBlock / kGroup) * 8));
+  if (grid < 1) grid = 1;
+  if (grid > 4096) grid = 4096;
+  const size_t lds = sizeof(double) * (size_t)(kBlock / kGroup) * (size_t)d.K;
+  if (sparse)
+    hipLaunchKernelGGL(saga_loss_kernel<true>, dim3(grid), dim3(kBlock), lds, st, d, lam);
+  else
+    hipLaunchKernelGGL(saga_loss_kernel<false>, dim3(grid), dim3(kBlock), lds, st, d, lam);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_delta_export(const SagaDev& d, const double* ref, double* out, hipStream_t st) {
+  const int64_t len = 2 * (int64_t)d.K * d.p + 2 * d.K;
+  int grid = (int)((len + kBlock - 1) / kBlock);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(saga_delta_export_kernel, dim3(grid), dim3(kBlock), 0, st, d, ref, out);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_delta_apply(const SagaDev& d, const double* ref, const double* merged, double w_weight,
+                       hipStream_t st) {
+  const int64_t len = 2 * (int64_t)d.K * d.p + 2 * d.K;
+  int grid = (int)((len + kBlock - 1) / kBlock);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(saga_delta_apply_kernel, dim3(grid), dim3(kBlock), 0, st, d, ref, merged, w_weight);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+}  // namespace sgdnet

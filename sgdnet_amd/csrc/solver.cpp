@@ -1,0 +1,719 @@
+// Device-resident SAGA solver behind the sgdnet_solver_* C ABI (include/sgdnet_hip.h).
+//
+// Owns the HBM copies of the sample-major data and of the five state arrays the
+// reference keeps alive along the lambda path (src/sgdnet.cpp:187-198), and
+// drives the epoch kernels of saga_exact.hip / saga_batched.hip on its own HIP
+// stream.  Batched epochs are captured once per (batch, draws) shape into a
+// hipGraph and replayed, because an epoch is hundreds of microsecond-scale
+// launches (DESIGN.md "Launch structure").
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace sgdnet {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+}  // namespace sgdnet
+
+using namespace sgdnet;
+
+struct sgdnet_solver {
+  SagaDev d{};
+  bool sparse = false;
+  int device = 0;
+  hipStream_t st = nullptr;
+  LamParams lam{};
+  LamParams* lam_dev = nullptr;
+  // owned device buffers
+  std::vector<void*> owned;
+  double* ref = nullptr;        // snapshot for the multi-GPU merge
+  double* LS_dev = nullptr;     // lag_scaling table (exact sparse)
+  int64_t LS_len = 0;
+  double LS_alpha = -1.0, LS_gamma = -1.0;
+  int* out_dev = nullptr;
+  uint32_t* stream_dev = nullptr;
+  int64_t stream_len = 0;
+  int64_t nnz = 0;
+  bool penalty_set = false;
+  // cached epoch graph
+  hipGraphExec_t gexec = nullptr;
+  hipGraph_t graph = nullptr;
+  int64_t g_batch = 0, g_draws = 0;
+  bool w_prev_valid = false;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(sgdnet_solver* s, T** out, size_t count, bool zero) {
+  void* p = nullptr;
+  const size_t bytes = sizeof(T) * (count ? count : 1);
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess) {
+    set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    return SGDNET_ENOMEM;
+  }
+  s->owned.push_back(p);
+  if (zero) SGD_HIP_TRY(hipMemsetAsync(p, 0, bytes, s->st));
+  *out = static_cast<T*>(p);
+  return SGDNET_OK;
+}
+
+template <typename T>
+int dev_upload(sgdnet_solver* s, T** out, const T* host, size_t count) {
+  int rc = dev_alloc(s, out, count, false);
+  if (rc) return rc;
+  if (count) SGD_HIP_TRY(hipMemcpyAsync(*out, host, sizeof(T) * count, hipMemcpyHostToDevice, s->st));
+  return SGDNET_OK;
+}
+
+int push_lam(sgdnet_solver* s) {
+  SGD_HIP_TRY(hipMemcpyAsync(s->lam_dev, &s->lam, sizeof(LamParams), hipMemcpyHostToDevice, s->st));
+  return SGDNET_OK;
+}
+
+// r^m and LS_m = sum_{k<m} r^k for r = 1 - alpha*gamma: closed form of the
+// reference's cumulative lag_scaling table (src/saga-sparse.h:229-240).
+void batch_factors(double alpha, double gamma, int64_t m, double* r_m, double* ls_m) {
+  const double a = 1.0 - (1.0 - alpha * gamma);  // 1 - r, exact for the rounded r
+  if (a == 0.0) {
+    *r_m = 1.0;
+    *ls_m = (double)m;
+  } else {
+    const double e = expm1((double)m * log1p(-a));  // r^m - 1
+    *r_m = 1.0 + e;
+    *ls_m = -e / a;
+  }
+}
+
+void drop_graph(sgdnet_solver* s) {
+  if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
+  if (s->graph) (void)hipGraphDestroy(s->graph);
+  s->gexec = nullptr;
+  s->graph = nullptr;
+  s->g_batch = s->g_draws = 0;
+}
+
+int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
+  if (batch < 1) batch = 1;
+  if (batch > draws) batch = draws;
+  const int64_t full = draws / batch;
+  const int64_t tail = draws - full * batch;
+  s->lam.m_full = batch;
+  s->lam.m_tail = tail;
+  batch_factors(s->lam.alpha, s->lam.gamma, batch, &s->lam.r_full, &s->lam.ls_full);
+  batch_factors(s->lam.alpha, s->lam.gamma, tail, &s->lam.r_tail, &s->lam.ls_tail);
+  s->lam.draws_per_epoch = draws;
+  return SGDNET_OK;
+}
+
+int n_batches(int64_t batch, int64_t draws) {
+  if (batch < 1) batch = 1;
+  if (batch > draws) batch = draws;
+  return (int)((draws + batch - 1) / batch);
+}
+
+// Enqueue the kernels of one batched epoch (eager or under stream capture).
+int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::vector<hipEvent_t>* ev) {
+  if (batch < 1) batch = 1;
+  if (batch > draws) batch = draws;
+  const int nb = n_batches(batch, draws);
+  for (int k = 0; k < nb; ++k) {
+    const int64_t t0 = (int64_t)k * batch;
+    const int64_t m = (draws - t0 < batch) ? draws - t0 : batch;
+    const int tail = (m != batch) ? 1 : 0;
+    if (ev) {
+      hipEvent_t a, b, c;
+      SGD_HIP_TRY(hipEventCreate(&a));
+      SGD_HIP_TRY(hipEventCreate(&b));
+      SGD_HIP_TRY(hipEventCreate(&c));
+      SGD_HIP_TRY(hipEventRecord(a, s->st));
+      int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
+      if (rc) return rc;
+      SGD_HIP_TRY(hipEventRecord(b, s->st));
+      rc = launch_batch_sweep(s->d, s->lam_dev, tail, s->st);
+      if (rc) return rc;
+      SGD_HIP_TRY(hipEventRecord(c, s->st));
+      ev->push_back(a);
+      ev->push_back(b);
+      ev->push_back(c);
+    } else {
+      int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
+      if (rc) return rc;
+      rc = launch_batch_sweep(s->d, s->lam_dev, tail, s->st);
+      if (rc) return rc;
+    }
+  }
+  return launch_epoch_end(s->lam_dev, nb, s->st);
+}
+
+int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
+  if (s->gexec && s->g_batch == batch && s->g_draws == draws) return SGDNET_OK;
+  drop_graph(s);
+  SGD_HIP_TRY(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
+  int rc = enqueue_epoch_kernels(s, batch, draws, nullptr);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s->st, &g);
+  if (rc) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (e != hipSuccess) {
+    set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    return SGDNET_EHIP;
+  }
+  s->graph = g;
+  SGD_HIP_TRY(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
+  s->g_batch = batch;
+  s->g_draws = draws;
+  return SGDNET_OK;
+}
+
+int check_batched_ok(const sgdnet_solver* s) {
+  if (!s->sparse) {
+    set_error("batched mode is implemented for sparse x only; dense x runs in exact mode");
+    return SGDNET_EUNSUPPORTED;
+  }
+  if (s->d.standardize) {
+    set_error("batched mode does not implement implicit centring (sparse standardize=TRUE)");
+    return SGDNET_EUNSUPPORTED;
+  }
+  if (s->d.K > batched_max_classes()) {
+    set_error("batched mode supports n_classes <= %d (got %d)", batched_max_classes(), s->d.K);
+    return SGDNET_EUNSUPPORTED;
+  }
+  return SGDNET_OK;
+}
+
+int check_stream(const sgdnet_solver* s, int64_t off, int64_t need) {
+  if (!s->stream_dev || off < 0 || off + need > s->stream_len) {
+    set_error("sample stream too short: need [%lld, %lld) but %lld entries are resident",
+              (long long)off, (long long)(off + need), (long long)s->stream_len);
+    return SGDNET_ESTREAM;
+  }
+  return SGDNET_OK;
+}
+
+int read_convergence(sgdnet_solver* s, double tol, int* converged) {
+  LamParams back;
+  SGD_HIP_TRY(hipMemcpyAsync(&back, s->lam_dev, sizeof(LamParams), hipMemcpyDeviceToHost, s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  double max_change, max_size;
+  memcpy(&max_change, &back.max_change_bits, 8);
+  memcpy(&max_size, &back.max_size_bits, 8);
+  const bool all_zero = (max_size == 0.0) && (max_change == 0.0);
+  const bool no_change = (max_size != 0.0) && (max_change / max_size <= tol);
+  *converged = (all_zero || no_change) ? 1 : 0;
+  return SGDNET_OK;
+}
+
+int device_convergence(sgdnet_solver* s, double tol, int* converged) {
+  const size_t off = offsetof(LamParams, max_change_bits);
+  SGD_HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(s->lam_dev) + off, 0, 16, s->st));
+  int rc = launch_convergence(s->d, s->lam_dev, s->st);
+  if (rc) return rc;
+  return read_convergence(s, tol, converged);
+}
+
+int device_loss_sum(sgdnet_solver* s, double* out) {
+  const size_t off = offsetof(LamParams, loss_acc);
+  SGD_HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(s->lam_dev) + off, 0, 8, s->st));
+  int rc = launch_loss(s->d, s->lam_dev, s->sparse, s->st);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipMemcpyAsync(out, reinterpret_cast<char*>(s->lam_dev) + off, 8, hipMemcpyDeviceToHost,
+                             s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int ensure_ls_table(sgdnet_solver* s, int64_t nit) {
+  if (s->LS_dev && s->LS_len == nit + 1 && s->LS_alpha == s->lam.alpha && s->LS_gamma == s->lam.gamma)
+    return SGDNET_OK;
+  // saga-sparse.h:229-240, same sequential arithmetic
+  std::vector<double> ls((size_t)(nit + 1 > 2 ? nit + 1 : 2));
+  ls[0] = 0.0;
+  ls[1] = 1.0;
+  double geo = 1.0;
+  const double upd = 1.0 - s->lam.alpha * s->lam.gamma;
+  for (int64_t i = 2; i < nit + 1; ++i) {
+    geo *= upd;
+    ls[(size_t)i] = ls[(size_t)i - 1] + geo;
+  }
+  if (!s->LS_dev || s->LS_len != nit + 1) {
+    if (s->LS_dev) {
+      SGD_HIP_TRY(hipStreamSynchronize(s->st));
+      SGD_HIP_TRY(hipFree(s->LS_dev));
+      s->LS_dev = nullptr;
+    }
+    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->LS_dev), sizeof(double) * ls.size()));
+  }
+  SGD_HIP_TRY(hipMemcpy(s->LS_dev, ls.data(), sizeof(double) * ls.size(), hipMemcpyHostToDevice));
+  s->LS_len = nit + 1;
+  s->LS_alpha = s->lam.alpha;
+  s->LS_gamma = s->lam.gamma;
+  return SGDNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sgdnet_abi_version(void) { return SGDNET_ABI_VERSION; }
+
+const char* sgdnet_last_error(void) { return g_last_error.c_str(); }
+
+int sgdnet_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
+  if (!pb || !out) {
+    set_error("sgdnet_solver_create: null argument");
+    return SGDNET_EINVAL;
+  }
+  *out = nullptr;
+  if (pb->n_samples <= 0 || pb->n_features <= 0 || pb->n_classes <= 0 || !pb->y || pb->y_rows <= 0 ||
+      (!pb->x_dense && !(pb->rowptr && pb->colidx && pb->values))) {
+    set_error("sgdnet_solver_create: invalid problem description");
+    return SGDNET_EINVAL;
+  }
+  if (pb->family < SGDNET_GAUSSIAN || pb->family > SGDNET_MGAUSSIAN) {
+    set_error("sgdnet_solver_create: unknown family %d", pb->family);
+    return SGDNET_EINVAL;
+  }
+  if (pb->n_samples > 0xFFFFFFFFll) {
+    set_error("sgdnet_solver_create: n_samples exceeds the reference's unsigned range");
+    return SGDNET_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    set_error("no HIP device available: the SAGA backend has no CPU fallback");
+    return SGDNET_ENODEVICE;
+  }
+  if (pb->device < 0 || pb->device >= ndev) {
+    set_error("device %d out of range (%d devices)", pb->device, ndev);
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(pb->device));
+
+  sgdnet_solver* s = new sgdnet_solver();
+  s->device = pb->device;
+  s->sparse = pb->x_dense == nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete s;
+    return SGDNET_EHIP;
+  }
+  SagaDev& d = s->d;
+  d.family = pb->family;
+  d.K = pb->n_classes;
+  d.Ky = pb->y_rows;
+  d.fit_intercept = pb->fit_intercept;
+  d.standardize = (s->sparse && pb->standardize && pb->x_center_scaled) ? 1 : 0;
+  d.n = pb->n_samples;
+  d.p = pb->n_features;
+  d.n_total = (double)(pb->n_total > 0 ? pb->n_total : pb->n_samples);
+
+  const size_t n = (size_t)d.n, p = (size_t)d.p, K = (size_t)d.K;
+  int rc = SGDNET_OK;
+#define TRY(x)                     \
+  do {                             \
+    rc = (x);                      \
+    if (rc) {                      \
+      sgdnet_solver_destroy(s);    \
+      return rc;                   \
+    }                              \
+  } while (0)
+  if (s->sparse) {
+    s->nnz = pb->rowptr[n];
+    int64_t* ptr;
+    int32_t* idx;
+    double* val;
+    TRY(dev_upload(s, &ptr, pb->rowptr, n + 1));
+    TRY(dev_upload(s, &idx, pb->colidx, (size_t)s->nnz));
+    TRY(dev_upload(s, &val, pb->values, (size_t)s->nnz));
+    d.ptr = ptr;
+    d.idx = idx;
+    d.val = val;
+  } else {
+    double* xd;
+    TRY(dev_upload(s, &xd, pb->x_dense, n * p));
+    d.xd = xd;
+  }
+  {
+    double* y;
+    TRY(dev_upload(s, &y, pb->y, n * (size_t)d.Ky));
+    d.y = y;
+    if (d.standardize) {
+      double* c;
+      TRY(dev_upload(s, &c, pb->x_center_scaled, p));
+      d.c = c;
+    }
+  }
+  TRY(dev_alloc(s, &d.w, K * p, true));
+  TRY(dev_alloc(s, &d.G, K * p, true));
+  TRY(dev_alloc(s, &d.M, K * n, true));
+  TRY(dev_alloc(s, &d.b, K, true));
+  TRY(dev_alloc(s, &d.gb, K, true));
+  TRY(dev_alloc(s, &d.w_prev, K * p, true));
+  TRY(dev_alloc(s, &d.lag, p, true));
+  TRY(dev_alloc(s, &d.D, K * p, true));
+  TRY(dev_alloc(s, &d.d0, K, true));
+  TRY(dev_alloc(s, &d.claim, n, false));
+  TRY(dev_alloc(s, &s->ref, 2 * K * p + 2 * K, true));
+  TRY(dev_alloc(s, &s->out_dev, 4, true));
+  TRY(dev_alloc(s, &s->lam_dev, 1, true));
+#undef TRY
+  e = hipMemsetAsync(d.claim, 0xFF, sizeof(int) * n, s->st);  // -1: never a batch id
+  if (e == hipSuccess) e = hipStreamSynchronize(s->st);
+  if (e != hipSuccess) {
+    set_error("solver initialisation failed: %s", hipGetErrorString(e));
+    sgdnet_solver_destroy(s);
+    return SGDNET_EHIP;
+  }
+  memset(&s->lam, 0, sizeof(s->lam));
+  *out = s;
+  return SGDNET_OK;
+}
+
+void sgdnet_solver_destroy(sgdnet_solver* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->st) (void)hipStreamSynchronize(s->st);
+  drop_graph(s);
+  for (void* p : s->owned) (void)hipFree(p);
+  if (s->LS_dev) (void)hipFree(s->LS_dev);
+  if (s->stream_dev) (void)hipFree(s->stream_dev);
+  if (s->st) (void)hipStreamDestroy(s->st);
+  delete s;
+}
+
+int sgdnet_solver_set_penalty(sgdnet_solver* s, int penalty, double gamma, double alpha, double beta) {
+  if (!s || penalty < SGDNET_RIDGE || penalty > SGDNET_GROUPLASSO || !(gamma > 0.0)) {
+    set_error("sgdnet_solver_set_penalty: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  s->lam.penalty = penalty;
+  s->lam.gamma = gamma;
+  s->lam.alpha = alpha;
+  s->lam.beta = beta;
+  s->penalty_set = true;
+  return push_lam(s);
+}
+
+static int state_ptr(sgdnet_solver* s, int which, double** p, size_t* count) {
+  const size_t K = (size_t)s->d.K, n = (size_t)s->d.n, pp = (size_t)s->d.p;
+  switch (which) {
+    case 0: *p = s->d.w; *count = K * pp; break;
+    case 1: *p = s->d.b; *count = K; break;
+    case 2: *p = s->d.M; *count = K * n; break;
+    case 3: *p = s->d.G; *count = K * pp; break;
+    case 4: *p = s->d.gb; *count = K; break;
+    default:
+      set_error("unknown state array %d", which);
+      return SGDNET_EINVAL;
+  }
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_get_state(sgdnet_solver* s, int which, double* host) {
+  if (!s || !host) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  double* p;
+  size_t count;
+  int rc = state_ptr(s, which, &p, &count);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipMemcpyAsync(host, p, sizeof(double) * count, hipMemcpyDeviceToHost, s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_set_state(sgdnet_solver* s, int which, const double* host) {
+  if (!s || !host) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  double* p;
+  size_t count;
+  int rc = state_ptr(s, which, &p, &count);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipMemcpyAsync(p, host, sizeof(double) * count, hipMemcpyHostToDevice, s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  if (which == 0) s->w_prev_valid = false;
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_upload_stream(sgdnet_solver* s, const uint32_t* host, int64_t count) {
+  if (!s || !host || count <= 0) {
+    set_error("sgdnet_solver_upload_stream: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  if (count > s->stream_len || !s->stream_dev) {
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    if (s->stream_dev) SGD_HIP_TRY(hipFree(s->stream_dev));
+    s->stream_dev = nullptr;
+    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->stream_dev), sizeof(uint32_t) * (size_t)count));
+    drop_graph(s);  // captured kernels hold the old pointer
+  }
+  s->stream_len = count;
+  s->d.stream = s->stream_dev;
+  SGD_HIP_TRY(hipMemcpyAsync(s->stream_dev, host, sizeof(uint32_t) * (size_t)count, hipMemcpyHostToDevice,
+                             s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_offset,
+                      int64_t draws_per_epoch, unsigned max_epochs, double tol, unsigned* epochs_run,
+                      int* converged_out, double* losses) {
+  if (!s || draws_per_epoch <= 0 || max_epochs == 0 || !epochs_run || !converged_out) {
+    set_error("sgdnet_solver_run: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  if (!s->penalty_set) {
+    set_error("sgdnet_solver_run: call sgdnet_solver_set_penalty first");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = check_stream(s, stream_offset, draws_per_epoch);
+  if (rc) return rc;
+  const size_t wbytes = sizeof(double) * (size_t)s->d.K * (size_t)s->d.p;
+  unsigned done = 0;
+  int converged = 0;
+
+  if (mode == SGDNET_MODE_EXACT) {
+    if (s->sparse) {
+      rc = ensure_ls_table(s, draws_per_epoch);
+      if (rc) return rc;
+    }
+    const size_t lds_cap = 160 * 1024 - 256;
+    const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true);
+    const bool stage = lds_full <= lds_cap;
+    const size_t lds = stage ? lds_full
+                             : (s->sparse ? sparse_exact_lds_bytes(s->d, false)
+                                          : dense_exact_lds_bytes(s->d, false));
+    if (lds > lds_cap) {
+      set_error("exact mode: per-iteration scratch (%zu bytes) exceeds LDS", lds);
+      return SGDNET_EUNSUPPORTED;
+    }
+    while (done < max_epochs && !converged) {
+      const int64_t avail = (s->stream_len - stream_offset) / draws_per_epoch;
+      if (avail <= 0) {
+        set_error("sample stream exhausted after %u epochs", done);
+        return SGDNET_ESTREAM;
+      }
+      unsigned chunk = max_epochs - done;
+      if ((int64_t)chunk > avail) chunk = (unsigned)avail;
+      if (losses) chunk = 1;  // per-epoch loss needs a launch boundary
+      ExactCtl ctl{};
+      ctl.stream_off = stream_offset;
+      ctl.nit = draws_per_epoch;
+      ctl.max_epochs = chunk;
+      ctl.tol = tol;
+      ctl.LS = s->LS_dev;
+      ctl.use_lds = stage ? 1 : 0;
+      ctl.out = s->out_dev;
+      rc = s->sparse ? launch_sparse_exact(s->d, s->lam_dev, ctl, lds, s->st)
+                     : launch_dense_exact(s->d, s->lam_dev, ctl, lds, s->st);
+      if (rc) return rc;
+      int out[2] = {0, 0};
+      SGD_HIP_TRY(hipMemcpyAsync(out, s->out_dev, sizeof(out), hipMemcpyDeviceToHost, s->st));
+      SGD_HIP_TRY(hipStreamSynchronize(s->st));
+      if (losses) {
+        double sum = 0.0;
+        rc = device_loss_sum(s, &sum);
+        if (rc) return rc;
+        losses[done] = sum / (double)s->d.n;
+      }
+      done += (unsigned)out[0];
+      converged = out[1];
+      stream_offset += (int64_t)out[0] * draws_per_epoch;
+    }
+    s->w_prev_valid = true;
+  } else if (mode == SGDNET_MODE_BATCHED) {
+    rc = check_batched_ok(s);
+    if (rc) return rc;
+    if (batch < 1) batch = 1;
+    if (batch > draws_per_epoch) batch = draws_per_epoch;
+    set_batch_shape(s, batch, draws_per_epoch);
+    s->lam.stream_base = stream_offset;
+    rc = push_lam(s);
+    if (rc) return rc;
+    // ConvergenceCheck{w, tol}: w_prev starts as the warm-start w (saga-sparse.h:251)
+    SGD_HIP_TRY(hipMemcpyAsync(s->d.w_prev, s->d.w, wbytes, hipMemcpyDeviceToDevice, s->st));
+    rc = ensure_graph(s, batch, draws_per_epoch);
+    if (rc) return rc;
+    const int nb = n_batches(batch, draws_per_epoch);
+    while (done < max_epochs && !converged) {
+      rc = check_stream(s, s->lam.stream_base, draws_per_epoch);
+      if (rc) return rc;
+      SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
+      s->lam.stream_base += draws_per_epoch;  // mirrors saga_epoch_end_kernel
+      s->lam.batch_seq += nb;
+      if (losses) {
+        double sum = 0.0;
+        rc = device_loss_sum(s, &sum);
+        if (rc) return rc;
+        losses[done] = sum / (double)s->d.n;
+      }
+      rc = device_convergence(s, tol, &converged);
+      if (rc) return rc;
+      ++done;
+    }
+    s->w_prev_valid = true;
+  } else {
+    set_error("unknown mode %d", mode);
+    return SGDNET_EINVAL;
+  }
+  *epochs_run = done;
+  *converged_out = converged;
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream_offset,
+                                 int64_t draws_per_epoch, int n_epochs) {
+  if (!s || draws_per_epoch <= 0 || n_epochs <= 0 || !s->penalty_set) {
+    set_error("sgdnet_solver_enqueue_epochs: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = check_batched_ok(s);
+  if (rc) return rc;
+  rc = check_stream(s, stream_offset, draws_per_epoch * n_epochs);
+  if (rc) return rc;
+  if (batch < 1) batch = 1;
+  if (batch > draws_per_epoch) batch = draws_per_epoch;
+  set_batch_shape(s, batch, draws_per_epoch);
+  s->lam.stream_base = stream_offset;
+  rc = push_lam(s);
+  if (rc) return rc;
+  rc = ensure_graph(s, batch, draws_per_epoch);
+  if (rc) return rc;
+  const int nb = n_batches(batch, draws_per_epoch);
+  for (int e = 0; e < n_epochs; ++e) {
+    SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
+    s->lam.stream_base += draws_per_epoch;
+    s->lam.batch_seq += nb;
+  }
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_sync(sgdnet_solver* s) {
+  if (!s) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_offset,
+                                int64_t draws_per_epoch, double* gather_ms, int* gather_launches,
+                                double* sweep_ms, int* sweep_launches) {
+  if (!s || draws_per_epoch <= 0 || !s->penalty_set) {
+    set_error("sgdnet_solver_profile_epoch: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = check_batched_ok(s);
+  if (rc) return rc;
+  rc = check_stream(s, stream_offset, draws_per_epoch);
+  if (rc) return rc;
+  if (batch < 1) batch = 1;
+  if (batch > draws_per_epoch) batch = draws_per_epoch;
+  set_batch_shape(s, batch, draws_per_epoch);
+  s->lam.stream_base = stream_offset;
+  rc = push_lam(s);
+  if (rc) return rc;
+  std::vector<hipEvent_t> ev;
+  rc = enqueue_epoch_kernels(s, batch, draws_per_epoch, &ev);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  s->lam.stream_base += draws_per_epoch;
+  s->lam.batch_seq += n_batches(batch, draws_per_epoch);
+  double g = 0.0, w = 0.0;
+  int ng = 0;
+  for (size_t i = 0; i + 2 < ev.size(); i += 3) {
+    float ms = 0.f;
+    SGD_HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
+    g += ms;
+    SGD_HIP_TRY(hipEventElapsedTime(&ms, ev[i + 1], ev[i + 2]));
+    w += ms;
+    ++ng;
+  }
+  for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  if (gather_ms) *gather_ms = g;
+  if (gather_launches) *gather_launches = ng;
+  if (sweep_ms) *sweep_ms = w;
+  if (sweep_launches) *sweep_launches = ng;
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_deviance(sgdnet_solver* s, double* out) {
+  if (!s || !out) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  double sum = 0.0;
+  int rc = device_loss_sum(s, &sum);
+  if (rc) return rc;
+  *out = 2.0 * sum;
+  return SGDNET_OK;
+}
+
+int64_t sgdnet_solver_delta_len(const sgdnet_solver* s) {
+  if (!s) return 0;
+  return 2 * (int64_t)s->d.K * s->d.p + 2 * s->d.K;
+}
+
+int sgdnet_solver_snapshot(sgdnet_solver* s) {
+  if (!s) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  const size_t KP = (size_t)s->d.K * (size_t)s->d.p, K = (size_t)s->d.K;
+  SGD_HIP_TRY(hipMemcpyAsync(s->ref, s->d.G, 8 * KP, hipMemcpyDeviceToDevice, s->st));
+  SGD_HIP_TRY(hipMemcpyAsync(s->ref + KP, s->d.w, 8 * KP, hipMemcpyDeviceToDevice, s->st));
+  SGD_HIP_TRY(hipMemcpyAsync(s->ref + 2 * KP, s->d.gb, 8 * K, hipMemcpyDeviceToDevice, s->st));
+  SGD_HIP_TRY(hipMemcpyAsync(s->ref + 2 * KP + K, s->d.b, 8 * K, hipMemcpyDeviceToDevice, s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_export_delta(sgdnet_solver* s, void* device_buf) {
+  if (!s || !device_buf) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = launch_delta_export(s->d, s->ref, static_cast<double*>(device_buf), s->st);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_apply_merged(sgdnet_solver* s, const void* device_buf, double w_weight) {
+  if (!s || !device_buf) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = launch_delta_apply(s->d, s->ref, static_cast<const double*>(device_buf), w_weight, s->st);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged) {
+  if (!s || !converged) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  return device_convergence(s, tol, converged);
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+"""Python handle on the device-resident SAGA solver (sgdnet_solver_* of the C ABI).
+
+Host-side plumbing only: every method is one call into libsgdnet_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import FAMILIES, MODES, PENALTIES, check, dptr
+
+STATE = {"w": 0, "intercept": 1, "g_memory": 2, "g_sum": 3, "g_sum_intercept": 4}
+
+
+class RRng:
+    """R-compatible Mersenne-Twister: RRng(seed) draws what set.seed(seed) draws."""
+
+    def __init__(self, seed):
+        self._L = _lib.load()
+        self.state = _lib.Rng()
+        self._L.sgdnet_rng_seed(C.byref(self.state), C.c_uint32(seed))
+
+    def unif(self, count=1):
+        return np.array([self._L.sgdnet_rng_unif(C.byref(self.state)) for _ in range(count)])
+
+    def stream(self, n_samples, count):
+        out = np.empty(count, dtype=np.uint32)
+        self._L.sgdnet_rng_fill(C.byref(self.state), C.c_uint32(n_samples),
+                                out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(count))
+        return out
+
+
+class SagaSolver:
+    """One problem resident in HBM: sample-major x, y and the five SAGA state arrays
+    (reference src/sgdnet.cpp:187-198).
+
+    x: scipy.sparse matrix of shape (p, n) in CSC form (column i = sample i), or a dense
+       (p, n) array (sample i contiguous, Fortran order).
+    y: (Ky, n) response, Fortran order.
+    """
+
+    def __init__(self, x, y, *, family, n_classes, fit_intercept=True, x_center_scaled=None,
+                 n_total=0, device=0):
+        import scipy.sparse as sp
+
+        self._L = _lib.load()
+        self.sparse = sp.issparse(x)
+        p, n = x.shape
+        self.n, self.p, self.K = n, p, n_classes
+        y = np.asfortranarray(np.asarray(y, dtype=np.float64).reshape(-1, n) if np.ndim(y) == 1
+                              else np.asarray(y, dtype=np.float64))
+        pb = _lib.Problem()
+        pb.family = FAMILIES[family]
+        pb.n_classes = n_classes
+        pb.n_samples = n
+        pb.n_total = n_total
+        pb.n_features = p
+        pb.fit_intercept = int(fit_intercept)
+        keep = [y]
+        if self.sparse:
+            x = x.tocsc()
+            x.sort_indices()
+            ptr = np.ascontiguousarray(x.indptr, dtype=np.int64)
+            idx = np.ascontiguousarray(x.indices, dtype=np.int32)
+            val = np.ascontiguousarray(x.data, dtype=np.float64)
+            pb.rowptr = ptr.ctypes.data_as(C.POINTER(C.c_int64))
+            pb.colidx = idx.ctypes.data_as(C.POINTER(C.c_int32))
+            pb.values = dptr(val)
+            self.nnz = int(ptr[-1])
+            self.row_nnz = np.diff(ptr)
+            keep += [ptr, idx, val]
+        else:
+            xd = np.asfortranarray(x, dtype=np.float64)
+            pb.x_dense = dptr(xd)
+            self.nnz = n * p
+            self.row_nnz = None
+            keep.append(xd)
+        if x_center_scaled is not None:
+            c = np.ascontiguousarray(x_center_scaled, dtype=np.float64)
+            pb.x_center_scaled = dptr(c)
+            pb.standardize = 1
+            keep.append(c)
+        pb.y = dptr(y)
+        pb.y_rows = y.shape[0]
+        pb.device = device
+        h = C.c_void_p()
+        check(self._L.sgdnet_solver_create(C.byref(pb), C.byref(h)))
+        self._h = h
+        self.stream_len = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sgdnet_solver_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_penalty(self, penalty, gamma, alpha, beta):
+        check(self._L.sgdnet_solver_set_penalty(self._h, PENALTIES[penalty], gamma, alpha, beta))
+
+    def _shape(self, name):
+        return {"w": (self.K, self.p), "g_sum": (self.K, self.p), "g_memory": (self.K, self.n),
+                "intercept": (self.K,), "g_sum_intercept": (self.K,)}[name]
+
+    def get(self, name):
+        out = np.zeros(self._shape(name), order="F")
+        check(self._L.sgdnet_solver_get_state(self._h, STATE[name], dptr(out)))
+        return out
+
+    def set(self, name, value):
+        v = np.asfortranarray(value, dtype=np.float64)
+        assert v.shape == self._shape(name), (v.shape, self._shape(name))
+        check(self._L.sgdnet_solver_set_state(self._h, STATE[name], dptr(v)))
+
+    def upload_stream(self, stream):
+        s = np.ascontiguousarray(stream, dtype=np.uint32)
+        check(self._L.sgdnet_solver_upload_stream(
+            self._h, s.ctypes.data_as(C.POINTER(C.c_uint32)), s.size))
+        self.stream_len = s.size
+
+    def run(self, *, mode="exact", batch=0, stream_offset=0, draws_per_epoch=None, max_epochs=1,
+            tol=0.0, losses=False):
+        """Saga() for the current penalty; returns (epochs, converged[, losses])."""
+        draws = self.n if draws_per_epoch is None else draws_per_epoch
+        ep, conv = C.c_uint(0), C.c_int(0)
+        lbuf = np.zeros(max_epochs) if losses else None
+        check(self._L.sgdnet_solver_run(self._h, MODES[mode], batch, stream_offset, draws,
+                                        max_epochs, tol, C.byref(ep), C.byref(conv),
+                                        dptr(lbuf) if losses else None))
+        if losses:
+            return ep.value, bool(conv.value), lbuf[:ep.value]
+        return ep.value, bool(conv.value)
+
+    def enqueue_epochs(self, n_epochs, *, batch, stream_offset=0, draws_per_epoch=None):
+        draws = self.n if draws_per_epoch is None else draws_per_epoch
+        check(self._L.sgdnet_solver_enqueue_epochs(self._h, batch, stream_offset, draws, n_epochs))
+
+    def sync(self):
+        check(self._L.sgdnet_solver_sync(self._h))
+
+    def profile_epoch(self, *, batch, stream_offset=0, draws_per_epoch=None):
+        draws = self.n if draws_per_epoch is None else draws_per_epoch
+        g, w = C.c_double(0), C.c_double(0)
+        ng, nw = C.c_int(0), C.c_int(0)
+        check(self._L.sgdnet_solver_profile_epoch(self._h, batch, stream_offset, draws, C.byref(g),
+                                                  C.byref(ng), C.byref(w), C.byref(nw)))
+        return dict(gather_ms=g.value, gather_launches=ng.value, sweep_ms=w.value,
+                    sweep_launches=nw.value)
+
+    def deviance(self):
+        out = C.c_double(0)
+        check(self._L.sgdnet_solver_deviance(self._h, C.byref(out)))
+        return out.value
+
+    def convergence(self, tol):
+        c = C.c_int(0)
+        check(self._L.sgdnet_solver_convergence(self._h, tol, C.byref(c)))
+        return bool(c.value)
+
+    # ---- multi-GPU merge hooks (device pointers; see sgdnet_amd/parallel.py) ----
+    def delta_len(self):
+        return int(self._L.sgdnet_solver_delta_len(self._h))
+
+    def snapshot(self):
+        check(self._L.sgdnet_solver_snapshot(self._h))
+
+    def export_delta(self, device_ptr):
+        check(self._L.sgdnet_solver_export_delta(self._h, C.c_void_p(device_ptr)))
+
+    def apply_merged(self, device_ptr, w_weight):
+        check(self._L.sgdnet_solver_apply_merged(self._h, C.c_void_p(device_ptr), w_weight))
