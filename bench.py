@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""Benchmark of the SAGA hot path: epochs/s + achieved HBM GB/s (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one SAGA epoch (n inner iterations over the whole job) of the batched
+HIP path on synthetic data of BASELINE config 4 -- CSC 10M x 10k, 0.1 % nnz,
+family=binomial, alpha=0.5, lambda=1/n, intercept, standardize=FALSE -- with the
+sample order, the matrix, y and the solver state resident in HBM before the
+timed region.  For N > 1 the driver launches one process per GPU
+(torch.distributed.run); samples are sharded, and every epoch ends with one RCCL
+all-reduce of the packed state deltas (sgdnet_amd/parallel.py), so the total
+work is fixed as N grows ("strong" scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel
+(saga_batch_gather_kernel) by the algorithmic bytes of SURVEY.md 8d divided by
+its HIP-event-measured average launch duration; `cpu_baseline` times the CPU
+oracle (single-threaded restatement of the reference loop) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n, p, density, family, K, seed)
+    "C4": (10_000_000, 10_000, 0.001, "binomial", 1, 4),
+    "C3": (1_000_000, 1_000, 0.01, "binomial", 1, 3),
+    "tiny": (100_000, 1_000, 0.01, "binomial", 1, 7),
+}
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="staleness window; 0 = automatic (2p)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-epochs", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run "
+                     "(one process per GPU)")
+        args.gpus = world
+
+    import torch
+    import sgdnet_amd as sa
+    from sgdnet_amd import data as D
+    from sgdnet_amd.parallel import HipShard, ShardedSaga, shard_bounds
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device: the SAGA backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    n, p, density, family, K, seed = WORKLOADS[args.workload]
+    lo, hi = shard_bounds(n, world, rank)
+    n_local = hi - lo
+    t_gen = time.time()
+    prob = D.make_sparse_glm(n, p, density, family=family, n_classes=K, seed=seed, lo=lo, hi=hi)
+    X = D.as_scipy(prob)
+    t_gen = time.time() - t_gen
+
+    # fit settings: alpha = 0.5, lambda = 1/n, intercept, no standardisation
+    mix, lam = 0.5, 1.0 / n
+    a_l2, b_l1 = (1.0 - mix) * lam, mix * lam
+    row_sq = np.add.reduceat(prob["val"] ** 2, prob["ptr"][:-1])
+    stats = torch.tensor([float(row_sq.max()), float(prob["y"].sum())], dtype=torch.float64,
+                         device="cuda")
+    if world > 1:
+        mx = stats[:1].clone()
+        sm = stats[1:].clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        stats = torch.cat([mx, sm])
+    max_sq, ysum = float(stats[0]), float(stats[1])
+    gamma = D.step_size(max_sq, a_l2, True, family, n)          # src/utils.h:31-51
+    ybar = min(max(ysum / n, 1e-9), 1 - 1e-9)
+    b0 = np.array([np.log(ybar / (1 - ybar))])                  # families.h:190-201
+
+    batch = args.batch if args.batch > 0 else min(65536, 2 * p)
+    batch = min(batch, n_local)
+    epochs_total = args.warmup + args.steps + 1                 # +1: the event-profiled epoch
+    # sample order: R's Mersenne-Twister, set.seed(config id [+ rank])
+    stream = sa.RRng(seed + rank).stream(n_local, n_local * epochs_total)
+
+    S = sa.SagaSolver(X, prob["y"], family=family, n_classes=K, fit_intercept=True, n_total=n,
+                      device=local_rank)
+    S.set_penalty("elasticnet", gamma, a_l2, b_l1)
+    S.set("intercept", b0)
+    S.upload_stream(stream)
+    shard = HipShard(S, batch=batch, draws_per_epoch=n_local, device=torch.device("cuda", local_rank))
+    job = ShardedSaga(shard, world)
+
+    def fence():
+        S.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.epoch()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.epoch()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+
+    # dominant kernel, HIP events around every launch of one more epoch (same stream)
+    off = shard.offset
+    prof = S.profile_epoch(batch=batch, stream_offset=off, draws_per_epoch=n_local)
+    alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, stream[off:off + n_local], K)
+    gather_s = prof["gather_ms"] * 1e-3
+    achieved = alg_bytes_epoch / gather_s / 1e9
+    alg_all = torch.tensor([alg_bytes_epoch], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(alg_all, op=dist.ReduceOp.SUM)
+    job_gbps = float(alg_all[0]) / (elapsed / args.steps) / 1e9
+
+    out = {
+        "metric": "saga_epochs_per_sec",
+        "value": args.steps / elapsed,
+        "unit": "epochs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "achieved_hbm_gbps_job": job_gbps,
+        "config": {
+            "workload": f"{args.workload}: synthetic CSC {n}x{p}, {density:.4%} nnz, family={family}, "
+                        f"alpha={mix}, lambda=1/n, intercept, standardize=FALSE",
+            "mode": "batched", "batch": batch, "samples_per_gpu": n_local,
+            "sample_order": f"R MT19937 set.seed({seed}+rank), with replacement",
+            "merge": "none" if world == 1 else "per-epoch RCCL all-reduce, w averaged",
+            "gen_s": round(t_gen, 2),
+        },
+        "roofline": {
+            "bound": "hbm", "kernel": "saga_batch_gather_kernel",
+            "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+            "launches": prof["gather_launches"],
+            "avg_launch_us": 1e3 * prof["gather_ms"] / max(1, prof["gather_launches"]),
+            "algorithmic_bytes_per_launch": alg_bytes_epoch / max(1, prof["gather_launches"]),
+            "sweep_avg_launch_us": 1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po   # the checker/baseline leg only
+        st = po.new_state(K, p, n_local)
+        st["intercept"][:] = b0
+        ce = max(1, args.cpu_epochs)
+        tc = time.perf_counter()
+        po.saga(X, prob["y"], st, family=family, penalty="elasticnet", gamma=gamma, alpha=a_l2,
+                beta=b_l1, fit_intercept=True, max_iter=ce, tol=0.0, stream=stream[:n_local * ce])
+        tc = time.perf_counter() - tc
+        out["cpu_baseline"] = {
+            "value": ce / tc, "unit": "epochs/s", "cores": 1, "kind": "port",
+            "sample": f"{ce} epochs ({ce * n_local} inner iterations) of the same workload and "
+                      f"sample stream, exact reference iteration, gcc -O2, {tc:.1f} s",
+            "algorithmic_gbps": alg_bytes_epoch * ce / tc / 1e9,
+            "host_cpus": os.cpu_count(),
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    S.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,7 +39,8 @@ class _SagaParams(C.Structure):
                 ("n_samples", C.c_int64), ("n_features", C.c_int64),
                 ("fit_intercept", C.c_int), ("standardize", C.c_int),
                 ("gamma", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
-                ("max_iter", C.c_uint), ("tol", C.c_double), ("debug", C.c_int)]
+                ("max_iter", C.c_uint), ("tol", C.c_double), ("debug", C.c_int),
+                ("n_total", C.c_int64)]
 
 
 class _Control(C.Structure):
@@ -116,7 +117,7 @@ def batch_factors(alpha, gamma, m):
 
 def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True,
          standardize=False, x_center_scaled=None, max_iter=1, tol=0.0, stream=None, rng=None,
-         batch=0, debug=False):
+         batch=0, debug=False, n_total=0):
     """Run the SAGA loop for one (gamma, alpha, beta) on sample-major data.
 
     x: scipy.sparse CSC of shape (p, n) (column i = sample i) or dense ndarray (p, n)
@@ -133,7 +134,7 @@ def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True
     sparse = sp.issparse(x)
     p, n = x.shape
     P = _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n, p, int(fit_intercept),
-                    int(standardize), gamma, alpha, beta, max_iter, tol, int(debug))
+                    int(standardize), gamma, alpha, beta, max_iter, tol, int(debug), n_total)
     y = np.asfortranarray(y, dtype=np.float64)
     if y.ndim == 1:
         y = y.reshape(1, -1)

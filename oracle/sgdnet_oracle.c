@@ -558,6 +558,7 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
   const int K = P->n_classes;
   const int64_t n = P->n_samples, p = P->n_features;
   const double gamma = P->gamma, beta = P->beta;
+  const double nt = (double)(P->n_total > 0 ? P->n_total : P->n_samples);
   int k;
   int64_t j, q, i;
   double* D = (double*)calloc((size_t)(K * p), sizeof(double));
@@ -613,14 +614,14 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
           }
         }
         for (k = 0; k < K; ++k) {
-          gj[k] += dj[k] / (double)n;
+          gj[k] += dj[k] / nt;
           dj[k] = 0.0;
         }
       }
       if (P->fit_intercept) {
         for (k = 0; k < K; ++k) {
-          gb[k] += d0[k] / (double)n;
-          intercept[k] -= gamma * (gb[k] * 0.01 * (double)m + d0[k] / (double)n);
+          gb[k] += d0[k] / nt;
+          intercept[k] -= gamma * (gb[k] * 0.01 * (double)m + d0[k] / nt);
         }
       }
       for (k = 0; k < K; ++k) d0[k] = 0.0;

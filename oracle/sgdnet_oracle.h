@@ -60,6 +60,8 @@ typedef struct {
   unsigned max_iter;
   double   tol;
   int      debug;
+  int64_t  n_total;       /* batched oracle only: samples of the whole (sharded) job that the
+                             gradient average divides by; 0 => n_samples */
 } orc_saga_params;
 
 /* Sparse SAGA, sample-major CSC (column i = sample i): reference

@@ -1,0 +1,83 @@
+"""Sample-sharded SAGA across the GPUs of one node (BASELINE north star).
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Rank r
+holds a contiguous shard of the samples and their gradient-memory rows; the model
+state (w, g_sum, intercept, g_sum_intercept) is replicated.  One job epoch =
+n_total inner iterations, n_total / world of them on every rank, followed by ONE
+all-reduce of the packed deltas [dG | dw | dgb | db] (2*K*p + 2*K doubles; 160 KB
+at 10k features, i.e. latency-bound, so a single fused buffer):
+
+    g_sum, g_sum_intercept  <-  ref + sum_r delta_r        (exact: g_sum is linear in
+                                                            the per-sample memory)
+    w, intercept            <-  ref + w_weight * sum_r delta_r   (w_weight = 1/world)
+
+The fixed point is the reference's: at the optimum every delta is zero.  The
+trajectory is not the sequential one, so parity for world > 1 is asserted at
+convergence (tests/test_parallel_gloo.py).
+
+The local solver is duck-typed (`snapshot`, `local_epoch`, `export_delta`,
+`apply_merged`) so that the merge logic is testable on CPU with gloo; the product
+binding is HipShard below.  The torch import is plumbing (process group, device
+buffer), not compute.
+"""
+
+
+class HipShard:
+    """Adapter: SagaSolver (libsgdnet_hip.so) + a torch device buffer for the all-reduce."""
+
+    def __init__(self, solver, *, batch, draws_per_epoch, device):
+        import torch
+
+        self.solver = solver
+        self.batch = batch
+        self.draws = draws_per_epoch
+        self.buf = torch.zeros(solver.delta_len(), dtype=torch.float64, device=device)
+        self.offset = 0
+
+    def snapshot(self):
+        self.solver.snapshot()
+
+    def local_epoch(self):
+        self.solver.enqueue_epochs(1, batch=self.batch, stream_offset=self.offset,
+                                   draws_per_epoch=self.draws)
+        self.offset += self.draws
+
+    def export_delta(self):
+        self.solver.export_delta(self.buf.data_ptr())   # synchronises the solver's stream
+        return self.buf
+
+    def apply_merged(self, buf, w_weight):
+        import torch
+
+        torch.cuda.synchronize()                        # all-reduce ran on torch's stream
+        self.solver.apply_merged(buf.data_ptr(), w_weight)
+
+
+class ShardedSaga:
+    """Per-epoch driver of the sharded job; identical on every rank."""
+
+    def __init__(self, shard, world_size, w_weight=None, group=None):
+        self.shard = shard
+        self.world = world_size
+        self.w_weight = (1.0 / world_size) if w_weight is None else w_weight
+        self.group = group
+
+    def epoch(self):
+        sh = self.shard
+        if self.world == 1:
+            sh.local_epoch()
+            return
+        import torch.distributed as dist
+
+        sh.snapshot()
+        sh.local_epoch()
+        buf = sh.export_delta()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        sh.apply_merged(buf, self.w_weight)
+
+
+def shard_bounds(n_total, world, rank):
+    """Contiguous sample shard of `rank`: [lo, hi)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

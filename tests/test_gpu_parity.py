@@ -1,0 +1,332 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs, against the committed golden fixtures,
+and -- at BASELINE.json's full sizes -- through size-independent properties.
+
+Tolerances (fp64): exact mode executes the reference iteration in the same order, so only
+libm rounding differs: 1e-10 relative (observed ~1e-15).  Batched mode sums scatter
+contributions with atomics in arbitrary order: 1e-9 relative (observed ~1e-14).
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+STATE = ("w", "intercept", "g_sum", "g_memory", "g_sum_intercept")
+TOL_EXACT, TOL_BATCHED = 1e-10, 1e-9
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import sgdnet_amd
+    if sgdnet_amd.load().sgdnet_device_count() < 1:
+        pytest.fail("GPU tests need a HIP device; the backend has no CPU fallback")
+    return sgdnet_amd
+
+
+def relerr(a, b):
+    return float(np.abs(np.asarray(a) - np.asarray(b)).max() / max(1e-300, np.abs(b).max()))
+
+
+def make_problem(family, K, n, p, dens, seed, dense=False):
+    from sgdnet_amd import data as D
+    if dense:
+        rng = np.random.default_rng(seed)
+        x = np.asfortranarray(rng.standard_normal((p, n)))
+        lp = rng.standard_normal((K, p)) @ x
+        if family == "gaussian":
+            y = lp[0] + 0.1 * rng.standard_normal(n)
+        elif family == "binomial":
+            y = (rng.random(n) < 1 / (1 + np.exp(-lp[0]))).astype(float)
+        elif family == "multinomial":
+            y = np.argmax(lp + rng.gumbel(size=lp.shape), axis=0).astype(float)
+        else:
+            y = lp + 0.1 * rng.standard_normal(lp.shape)
+        return x, np.asfortranarray(np.reshape(y, (-1, n)))
+    pr = D.make_sparse_glm(n, p, dens, family=family, n_classes=K, seed=seed)
+    return D.as_scipy(pr), pr["y"]
+
+
+def run_both(sa, oracle, x, y, *, family, K, penalty, gamma, alpha, beta, epochs, mode="exact",
+             batch=0, fit_intercept=True, c=None, stream=None, tol=0.0, seed=5):
+    p, n = x.shape
+    if stream is None:
+        stream = oracle.Rng(seed).stream(n, n * epochs)
+    st = oracle.new_state(K, p, n)
+    ep, rc, _ = oracle.saga(x, y, st, family=family, penalty=penalty, gamma=gamma, alpha=alpha,
+                            beta=beta, fit_intercept=fit_intercept, standardize=c is not None,
+                            x_center_scaled=c, max_iter=epochs, tol=tol, stream=stream,
+                            batch=batch if mode == "batched" else 0)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K, fit_intercept=fit_intercept,
+                      x_center_scaled=c)
+    S.set_penalty(penalty, gamma, alpha, beta)
+    S.upload_stream(stream)
+    ep2, conv = S.run(mode=mode, batch=batch, max_epochs=epochs, tol=tol)
+    got = {k: S.get(k) for k in STATE}
+    S.close()
+    return (ep, rc, st), (ep2, conv, got)
+
+
+CASES = [("binomial", 1, "elasticnet"), ("binomial", 1, "ridge"), ("gaussian", 1, "elasticnet"),
+         ("multinomial", 3, "elasticnet"), ("multinomial", 10, "ridge"),
+         ("mgaussian", 2, "grouplasso"), ("mgaussian", 3, "ridge")]
+
+
+@pytest.mark.parametrize("family,K,penalty", CASES)
+@pytest.mark.parametrize("fit_intercept", [True, False])
+def test_sparse_exact_matches_oracle(sa, oracle, family, K, penalty, fit_intercept):
+    x, y = make_problem(family, K, 2500, 120, 0.06, seed=3)
+    (ep, rc, st), (ep2, conv, got) = run_both(
+        sa, oracle, x, y, family=family, K=K, penalty=penalty, gamma=0.02, alpha=1e-3,
+        beta=0.0 if penalty == "ridge" else 2e-3, epochs=3, fit_intercept=fit_intercept)
+    assert ep2 == ep
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_EXACT, k
+
+
+@pytest.mark.parametrize("family,K,penalty", CASES)
+def test_dense_exact_matches_oracle(sa, oracle, family, K, penalty):
+    x, y = make_problem(family, K, 700, 7, None, seed=4, dense=True)
+    (ep, rc, st), (ep2, conv, got) = run_both(
+        sa, oracle, x, y, family=family, K=K, penalty=penalty, gamma=0.01, alpha=1e-3,
+        beta=0.0 if penalty == "ridge" else 2e-3, epochs=3)
+    assert ep2 == ep
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_EXACT, k
+
+
+def test_dense_exact_wide_matrix(sa, oracle):
+    # p > 256: beyond the register-prefetched part of a row
+    x, y = make_problem("gaussian", 1, 300, 300, None, seed=6, dense=True)
+    (ep, rc, st), (ep2, conv, got) = run_both(sa, oracle, x, y, family="gaussian", K=1,
+                                              penalty="elasticnet", gamma=1e-3, alpha=1e-3,
+                                              beta=1e-3, epochs=2)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_EXACT, k
+
+
+@pytest.mark.parametrize("family,K,penalty", CASES)
+@pytest.mark.parametrize("batch", [1, 7, 64, 1000, 5000])
+def test_sparse_batched_matches_batched_oracle(sa, oracle, family, K, penalty, batch):
+    if batch == 1 and K > 1:
+        pytest.skip("batch=1 covered for K=1")
+    x, y = make_problem(family, K, 2500, 120, 0.06, seed=7)
+    (ep, rc, st), (ep2, conv, got) = run_both(
+        sa, oracle, x, y, family=family, K=K, penalty=penalty, gamma=0.004, alpha=1e-3,
+        beta=0.0 if penalty == "ridge" else 2e-3, epochs=3, mode="batched", batch=batch)
+    assert ep2 == ep
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_BATCHED, k
+
+
+def test_batched_handles_repeats_and_empty_rows(sa, oracle):
+    # a stream that draws the same few samples over and over inside one batch, on a
+    # matrix with empty samples and one long row (several 16-lane chunks)
+    rng = np.random.default_rng(8)
+    n, p = 400, 90
+    X = sp.random(p, n, density=0.05, random_state=3, data_rvs=rng.standard_normal).tolil()
+    X[:, 5] = 0.0
+    X[:, 17] = 0.0
+    X[:, 9] = rng.standard_normal((p, 1))
+    X = X.tocsc()
+    y = np.asfortranarray((rng.random(n) < 0.5).astype(float).reshape(1, n))
+    stream = rng.choice([5, 9, 9, 17, 3, 3, 3, 250], size=n * 2).astype(np.uint32)
+    for mode, batch, tol in (("exact", 0, TOL_EXACT), ("batched", 50, TOL_BATCHED)):
+        (ep, rc, st), (ep2, conv, got) = run_both(
+            sa, oracle, X, y, family="binomial", K=1, penalty="elasticnet", gamma=0.01, alpha=1e-3,
+            beta=1e-3, epochs=2, mode=mode, batch=batch, stream=stream)
+        for k in STATE:
+            assert relerr(got[k], st[k]) < tol, (mode, k)
+
+
+def test_exact_wscale_reset_branch(sa, oracle):
+    # alpha*gamma = 0.3: wscale falls below SMALL every ~90 iterations, forcing the
+    # mid-epoch Reset of saga-sparse.h:285-295 (and saga-dense.h:162-166)
+    x, y = make_problem("gaussian", 1, 1500, 60, 0.1, seed=9)
+    (_, _, st), (_, _, got) = run_both(sa, oracle, x, y, family="gaussian", K=1, penalty="elasticnet",
+                                       gamma=0.3, alpha=1.0, beta=1e-3, epochs=2)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_EXACT, k
+    xd, yd = make_problem("gaussian", 1, 600, 5, None, seed=9, dense=True)
+    (_, _, st), (_, _, got) = run_both(sa, oracle, xd, yd, family="gaussian", K=1, penalty="ridge",
+                                       gamma=0.1, alpha=3.0, beta=0.0, epochs=2)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_EXACT, k
+
+
+def test_sparse_exact_implicit_centring(sa, oracle):
+    # standardize=TRUE on sparse x: the dense O(p) terms of saga-sparse.h:127-128,276-277
+    x, y = make_problem("binomial", 1, 1200, 40, 0.1, seed=10)
+    c = np.random.default_rng(1).normal(0, 0.05, 40)
+    (_, _, st), (_, _, got) = run_both(sa, oracle, x, y, family="binomial", K=1, penalty="elasticnet",
+                                       gamma=0.02, alpha=1e-3, beta=1e-3, epochs=2, c=c)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < 1e-9, k
+
+
+def test_in_kernel_convergence_and_epoch_count(sa, oracle):
+    x, y = make_problem("gaussian", 1, 800, 20, 0.2, seed=12)
+    for mode, batch in (("exact", 0), ("batched", 16)):
+        (ep, rc, st), (ep2, conv, got) = run_both(
+            sa, oracle, x, y, family="gaussian", K=1, penalty="elasticnet", gamma=0.05, alpha=0.05,
+            beta=0.01, epochs=200, tol=1e-6, mode=mode, batch=batch)
+        assert 1 < ep < 200 and ep2 == ep and conv and rc == 0
+        assert relerr(got["w"], st["w"]) < 1e-9
+
+
+def test_golden_sparse_epochs(sa):
+    g = np.load(os.path.join(GOLD, "sparse_binomial_epochs.npz"))
+    n = g["y"].shape[1]
+    p = g["w_exact"].shape[1]
+    X = sp.csc_matrix((g["val"], g["idx"], g["ptr"]), shape=(p, n))
+    for tag, mode, batch, tol in (("exact", "exact", 0, TOL_EXACT), ("batch64", "batched", 64, TOL_BATCHED)):
+        S = sa.SagaSolver(X, g["y"], family="binomial", n_classes=1)
+        S.set_penalty("elasticnet", float(g["gamma"]), float(g["alpha"]), float(g["beta"]))
+        S.upload_stream(g["stream"])
+        S.run(mode=mode, batch=batch, max_epochs=3, tol=0.0)
+        assert relerr(S.get("w"), g[f"w_{tag}"]) < tol
+        assert relerr(S.get("intercept"), g[f"b_{tag}"]) < tol
+        assert relerr(S.get("g_sum"), g[f"G_{tag}"]) < tol
+        S.close()
+
+
+def test_config1_iris_multinomial_path(sa):
+    # BASELINE config 1: iris 150x4, multinomial, alpha = 0.8, default lambda path
+    d = np.load(os.path.join(GOLD, "iris.npz"))
+    gold = np.load(os.path.join(GOLD, "iris_multinomial_path.npz"))
+    fit = sa.sgdnet(d["x"], d["y"], family="multinomial", alpha=0.8, seed=1)
+    assert fit.npasses == float(gold["npasses"])
+    assert relerr(fit.lambda_, gold["lambda_"]) < 1e-12
+    beta = np.stack(fit.beta)                     # (K, p, n_lambda)
+    assert relerr(beta, gold["beta"]) < 1e-8
+    a0 = gold["a0"] - gold["a0"].mean(axis=0, keepdims=True)   # R/sgdnet.R:409-410
+    assert relerr(fit.a0, a0) < 1e-8
+    assert relerr(fit.dev_ratio, gold["dev_ratio"]) < 1e-8
+    assert fit.nulldev == pytest.approx(float(gold["nulldev"]), rel=1e-12)
+    assert fit.draws_used == int(fit.npasses) * 150
+
+
+def test_config2_abalone_gaussian_path(sa):
+    # BASELINE config 2: abalone, gaussian, full lambda path (dense kernel bring-up)
+    d = np.load(os.path.join(GOLD, "abalone.npz"))
+    gold = np.load(os.path.join(GOLD, "abalone_gaussian_path.npz"))
+    fit = sa.sgdnet(d["x"], d["y"], family="gaussian", seed=2)
+    assert fit.npasses == float(gold["npasses"])
+    assert relerr(fit.lambda_, gold["lambda_"]) < 1e-12
+    assert relerr(fit.beta, gold["beta"][0]) < 1e-8
+    assert relerr(fit.a0, gold["a0"][0]) < 1e-8
+    assert relerr(fit.dev_ratio, gold["dev_ratio"]) < 1e-8
+
+
+@pytest.mark.parametrize("family", ["gaussian", "binomial", "multinomial", "mgaussian"])
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("standardize", [True, False])
+def test_fit_paths_match_oracle(sa, oracle, family, sparse, standardize):
+    rng = np.random.default_rng(14)
+    n, p = 400, 6
+    x = rng.standard_normal((n, p)) * (rng.random((n, p)) < 0.5)
+    z = x @ rng.uniform(-1, 1, (p, 3)) + 0.3
+    y = {"gaussian": z[:, 0] + 0.1 * rng.standard_normal(n),
+         "binomial": (rng.random(n) < 1 / (1 + np.exp(-z[:, 0]))).astype(float),
+         "multinomial": np.argmax(z + rng.gumbel(size=z.shape), axis=1).astype(float),
+         "mgaussian": z[:, :2] + 0.1 * rng.standard_normal((n, 2))}[family]
+    xx = sp.csc_matrix(x) if sparse else x
+    kw = dict(family=family, alpha=0.6, nlambda=6, thresh=1e-5, standardize=standardize)
+    fit = sa.sgdnet(xx, y, seed=3, debug=True, **kw)
+    ref = oracle.fit(xx, y, seed=3, debug=True, **kw)
+    assert fit.npasses == ref["npasses"]
+    beta = np.stack(fit.beta) if isinstance(fit.beta, list) else fit.beta[None]
+    assert relerr(beta, ref["beta"]) < 1e-8
+    a0 = ref["a0"] - ref["a0"].mean(axis=0, keepdims=True) if family == "multinomial" else ref["a0"]
+    assert relerr(np.atleast_2d(fit.a0), a0) < 1e-8
+    assert relerr(fit.dev_ratio, ref["dev_ratio"]) < 1e-8
+    assert fit.nulldev == pytest.approx(ref["nulldev"], rel=1e-12)
+    for got, want in zip(fit.diagnostics["loss"], ref["losses"]):
+        assert len(got) == len(want) and relerr(got, want) < 1e-9
+
+
+def test_fit_batched_mode_reaches_the_exact_optimum(sa, oracle):
+    # BASELINE config 3 shape scaled down: the relaxed mode is checked at tight convergence
+    from sgdnet_amd import data as D
+    n, p = 20000, 300
+    pr = D.make_sparse_glm(n, p, 0.03, family="binomial", seed=15)
+    X = D.as_scipy(pr).T.tocsc()               # n x p, as R would pass it
+    y = pr["y"][0]
+    kw = dict(family="binomial", alpha=0.5, lambda_=[20.0 / n], standardize=False, thresh=1e-11,
+              maxit=2000)
+    ref = oracle.fit(X, y, seed=4, **kw)
+    fit = sa.sgdnet(X, y, seed=4, mode="batched", batch=512, **kw)
+    assert fit.return_codes[0] == 0
+    assert relerr(fit.beta[:, 0], ref["beta"][0, :, 0]) < 1e-8
+    assert abs(fit.a0[0] - ref["a0"][0, 0]) < 1e-8
+
+
+def test_unsupported_and_stream_errors(sa):
+    from sgdnet_amd import SgdnetError
+    x, y = make_problem("gaussian", 1, 200, 5, None, seed=1, dense=True)
+    S = sa.SagaSolver(x, y, family="gaussian", n_classes=1)
+    S.set_penalty("ridge", 0.01, 1e-3, 0.0)
+    S.upload_stream(np.zeros(100, dtype=np.uint32))
+    with pytest.raises(SgdnetError) as e:
+        S.run(mode="exact", max_epochs=1)          # 200 draws needed, 100 resident
+    assert e.value.code == -6
+    S.upload_stream(np.zeros(200, dtype=np.uint32))
+    with pytest.raises(SgdnetError) as e:
+        S.run(mode="batched", batch=8, max_epochs=1)   # dense x has no batched path
+    assert e.value.code == -5
+    S.close()
+
+
+def _gradient_average_invariant(S, X, n_total):
+    """g_sum == (1/n) sum_i x_i g_memory[:, i]^T -- the invariant every SAGA variant keeps
+    (saga-sparse.h:281-282, 328-335); checked on the host from the device state."""
+    M = S.get("g_memory")                      # (K, n)
+    G = S.get("g_sum")                         # (K, p)
+    want = (X @ M.T).T / n_total               # (K, p)
+    scale = max(np.abs(want).max(), 1e-300)
+    return float(np.abs(G - want).max() / scale), float(
+        np.abs(S.get("g_sum_intercept") - M.sum(axis=1) / n_total).max())
+
+
+@pytest.mark.parametrize("workload", ["C3", "C4"])
+def test_full_size_invariants(sa, workload):
+    # BASELINE configs 3 and 4 at full size: size-independent properties of the batched path
+    from sgdnet_amd import data as D
+    n, p, dens, seed = {"C3": (1_000_000, 1_000, 0.01, 3), "C4": (10_000_000, 10_000, 0.001, 4)}[workload]
+    pr = D.make_sparse_glm(n, p, dens, family="binomial", seed=seed)
+    X = D.as_scipy(pr)
+    epochs = 2
+    stream = sa.RRng(seed).stream(n, n * epochs)
+    row_sq = np.add.reduceat(pr["val"] ** 2, pr["ptr"][:-1])
+    a_l2 = b_l1 = 0.5 / n
+    gamma = D.step_size(row_sq.max(), a_l2, True, "binomial", n)
+    batch = min(65536, 2 * p)
+    S = sa.SagaSolver(X, pr["y"], family="binomial", n_classes=1)
+    S.set_penalty("elasticnet", gamma, a_l2, b_l1)
+    S.upload_stream(stream)
+    dev0 = S.deviance()
+    S.enqueue_epochs(epochs, batch=batch)
+    S.sync()
+    err_g, err_gb = _gradient_average_invariant(S, X, n)
+    assert err_g < 1e-9 and err_gb < 1e-12
+    # every drawn sample holds sigma(lp) - y in (-1, 1); untouched samples still hold 0
+    M = S.get("g_memory")[0]
+    touched = np.zeros(n, dtype=bool)
+    touched[stream] = True
+    assert np.all(M[~touched] == 0.0) and np.all(np.abs(M) < 1.0)
+    assert np.count_nonzero(M) == np.count_nonzero(touched)
+    # two epochs of SAGA reduce the deviance, and the run is reproducible to rounding
+    dev1 = S.deviance()
+    assert dev1 < dev0
+    w1 = S.get("w")
+    S2 = sa.SagaSolver(X, pr["y"], family="binomial", n_classes=1)
+    S2.set_penalty("elasticnet", gamma, a_l2, b_l1)
+    S2.upload_stream(stream)
+    S2.enqueue_epochs(epochs, batch=batch)
+    S2.sync()
+    assert relerr(S2.get("w"), w1) < 1e-9
+    S.close()
+    S2.close()
