@@ -50,7 +50,7 @@ struct SagaDev {
   unsigned* lag;
   // batched-mode scratch
   double* D;      // K x p scatter accumulator
-  double* d0;     // K     intercept accumulator
+  double* d0_part;  // blocks x K  per-block partial sums of the intercept accumulator
   int* claim;     // n     first-occurrence claims (K > 1)
   const uint32_t* stream;
 };
@@ -96,7 +96,8 @@ size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state);
 
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
                         int batch_id_offset, hipStream_t st);
-int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, hipStream_t st);
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st);
+int batch_gather_blocks(int m);
 int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);

@@ -174,14 +174,24 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
     }
   }
 
-  // intercept accumulator: wave reduce, one atomic per wave and class
+  // intercept accumulator: one partial per block and class, summed by the sweep in a fixed
+  // order (thousands of same-address atomics would serialise at ~12 ns each)
   if (d.fit_intercept) {
+    __shared__ double part[kBlock / 64][KMAX];
+    const int wave = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       if (k < K) {
         const double tot = wave_sum(gc[k]);
-        if ((threadIdx.x & 63) == 0 && tot != 0.0) atomic_add_f64(d.d0 + k, tot);
+        if ((threadIdx.x & 63) == 0) part[wave][k] = tot;
       }
+    }
+    __syncthreads();
+    if (threadIdx.x < K) {
+      double tot = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < kBlock / 64; ++wv) tot += part[wv][threadIdx.x];
+      d.d0_part[(int64_t)blockIdx.x * K + threadIdx.x] = tot;
     }
   }
 }
@@ -189,7 +199,8 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
 // --------------------------------------------------------------------------
 // sweep: one thread per feature (all K classes: GroupLasso needs the column norm).
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, LamParams* lamp, int tail) {
+__global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
+                                                                  int n_parts) {
   const int K = d.K;
   const int penalty = lamp->penalty;
   const double gamma = lamp->gamma, beta = lamp->beta;
@@ -235,13 +246,25 @@ __global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, Lam
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < K && d.fit_intercept) {
-    const int k = threadIdx.x;
-    const double dk = d.d0[k] / n_d;
-    const double gbk = d.gb[k] + dk;
-    d.gb[k] = gbk;
-    d.b[k] -= gamma * (gbk * 0.01 * m_d + dk);
-    d.d0[k] = 0.0;
+  if (blockIdx.x == 0 && d.fit_intercept) {
+    // d0 = sum of the gather kernel's per-block partials, fixed order
+    __shared__ double red[kBlock / 64];
+    for (int k = 0; k < K; ++k) {
+      double acc = 0.0;
+      for (int i = threadIdx.x; i < n_parts; i += kBlock) acc += d.d0_part[(int64_t)i * K + k];
+      acc = wave_sum(acc);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int wv = 0; wv < kBlock / 64; ++wv) tot += red[wv];
+        const double dk = tot / n_d;
+        const double gbk = d.gb[k] + dk;
+        d.gb[k] = gbk;
+        d.b[k] -= gamma * (gbk * 0.01 * m_d + dk);
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -338,9 +361,7 @@ int batched_max_classes() { return 16; }
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
                         int batch_id_offset, hipStream_t st) {
   (void)tail;
-  const int draws_per_block = kBlock / kGroup;
-  int grid = (m + draws_per_block - 1) / draws_per_block;
-  if (grid < 1) grid = 1;
+  const int grid = batch_gather_blocks(m);
   if (d.K == 1)
     hipLaunchKernelGGL(saga_batch_gather_kernel<1>, dim3(grid), dim3(kBlock), 0, st, d, lam, t0_in_epoch,
                        m, batch_id_offset);
@@ -358,9 +379,16 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
   return SGDNET_OK;
 }
 
-int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, hipStream_t st) {
+int batch_gather_blocks(int m) {
+  const int draws_per_block = kBlock / kGroup;
+  const int grid = (m + draws_per_block - 1) / draws_per_block;
+  return grid < 1 ? 1 : grid;
+}
+
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st) {
   const int grid = (int)((d.p + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, d, lam, tail);
+  hipLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, d, lam, tail,
+                     batch_gather_blocks(m));
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

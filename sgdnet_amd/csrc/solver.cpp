@@ -56,6 +56,7 @@ struct sgdnet_solver {
   hipGraph_t graph = nullptr;
   int64_t g_batch = 0, g_draws = 0;
   bool w_prev_valid = false;
+  int64_t d0_parts_cap = 0;     // blocks the d0_part buffer can hold
 };
 
 namespace {
@@ -113,6 +114,16 @@ void drop_graph(sgdnet_solver* s) {
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   if (batch > draws) batch = draws;
+  const int64_t blocks = batch_gather_blocks((int)batch);
+  if (blocks > s->d0_parts_cap) {
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    if (s->d.d0_part) SGD_HIP_TRY(hipFree(s->d.d0_part));
+    s->d.d0_part = nullptr;
+    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d.d0_part),
+                          sizeof(double) * (size_t)blocks * (size_t)s->d.K));
+    s->d0_parts_cap = blocks;
+    drop_graph(s);  // captured kernels hold the old pointer
+  }
   const int64_t full = draws / batch;
   const int64_t tail = draws - full * batch;
   s->lam.m_full = batch;
@@ -147,7 +158,7 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
       int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
       if (rc) return rc;
       SGD_HIP_TRY(hipEventRecord(b, s->st));
-      rc = launch_batch_sweep(s->d, s->lam_dev, tail, s->st);
+      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, s->st);
       if (rc) return rc;
       SGD_HIP_TRY(hipEventRecord(c, s->st));
       ev->push_back(a);
@@ -156,7 +167,7 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
     } else {
       int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
       if (rc) return rc;
-      rc = launch_batch_sweep(s->d, s->lam_dev, tail, s->st);
+      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, s->st);
       if (rc) return rc;
     }
   }
@@ -377,7 +388,6 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
   TRY(dev_alloc(s, &d.w_prev, K * p, true));
   TRY(dev_alloc(s, &d.lag, p, true));
   TRY(dev_alloc(s, &d.D, K * p, true));
-  TRY(dev_alloc(s, &d.d0, K, true));
   TRY(dev_alloc(s, &d.claim, n, false));
   TRY(dev_alloc(s, &s->ref, 2 * K * p + 2 * K, true));
   TRY(dev_alloc(s, &s->out_dev, 4, true));
@@ -402,6 +412,7 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   drop_graph(s);
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
+  if (s->d.d0_part) (void)hipFree(s->d.d0_part);
   if (s->stream_dev) (void)hipFree(s->stream_dev);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
@@ -554,7 +565,8 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     if (rc) return rc;
     if (batch < 1) batch = 1;
     if (batch > draws_per_epoch) batch = draws_per_epoch;
-    set_batch_shape(s, batch, draws_per_epoch);
+    rc = set_batch_shape(s, batch, draws_per_epoch);
+    if (rc) return rc;
     s->lam.stream_base = stream_offset;
     rc = push_lam(s);
     if (rc) return rc;
@@ -602,7 +614,8 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   if (rc) return rc;
   if (batch < 1) batch = 1;
   if (batch > draws_per_epoch) batch = draws_per_epoch;
-  set_batch_shape(s, batch, draws_per_epoch);
+  rc = set_batch_shape(s, batch, draws_per_epoch);
+  if (rc) return rc;
   s->lam.stream_base = stream_offset;
   rc = push_lam(s);
   if (rc) return rc;
@@ -638,7 +651,8 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   if (rc) return rc;
   if (batch < 1) batch = 1;
   if (batch > draws_per_epoch) batch = draws_per_epoch;
-  set_batch_shape(s, batch, draws_per_epoch);
+  rc = set_batch_shape(s, batch, draws_per_epoch);
+  if (rc) return rc;
   s->lam.stream_base = stream_offset;
   rc = push_lam(s);
   if (rc) return rc;
