@@ -95,8 +95,10 @@ size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state);
 size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state);
 
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
-                        int batch_id_offset, hipStream_t st);
-int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st);
+                        int batch_id_offset, hipStream_t st, hipEvent_t ev0 = nullptr,
+                        hipEvent_t ev1 = nullptr);
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st,
+                       hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int batch_gather_blocks(int m);
 int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);

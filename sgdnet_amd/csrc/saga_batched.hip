@@ -23,6 +23,8 @@
 // positions; 16-lane groups own one draw so that a wavefront has 4 independent
 // gathers in flight and reduces x.w with intra-row shuffles.  w, D and G are
 // K*p doubles (80 KB at 10k features) and stay L2 / Infinity-Cache resident.
+#include <hip/hip_ext.h>
+
 #include "device_math.hpp"
 
 namespace sgdnet {
@@ -358,19 +360,27 @@ __global__ __launch_bounds__(kBlock) void saga_delta_apply_kernel(SagaDev d, con
 // ------------------------------ launchers ---------------------------------
 int batched_max_classes() { return 16; }
 
+int batch_gather_blocks(int m) {
+  const int draws_per_block = kBlock / kGroup;
+  const int grid = (m + draws_per_block - 1) / draws_per_block;
+  return grid < 1 ? 1 : grid;
+}
+
+// ev0/ev1 (optional): dispatch start/stop timestamps of exactly this kernel
+// (hipExtLaunchKernelGGL), used by the benchmark's per-kernel timing.
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
-                        int batch_id_offset, hipStream_t st) {
+                        int batch_id_offset, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   (void)tail;
   const int grid = batch_gather_blocks(m);
   if (d.K == 1)
-    hipLaunchKernelGGL(saga_batch_gather_kernel<1>, dim3(grid), dim3(kBlock), 0, st, d, lam, t0_in_epoch,
-                       m, batch_id_offset);
+    hipExtLaunchKernelGGL(saga_batch_gather_kernel<1>, dim3(grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
+                          lam, t0_in_epoch, m, batch_id_offset);
   else if (d.K <= 4)
-    hipLaunchKernelGGL(saga_batch_gather_kernel<4>, dim3(grid), dim3(kBlock), 0, st, d, lam, t0_in_epoch,
-                       m, batch_id_offset);
+    hipExtLaunchKernelGGL(saga_batch_gather_kernel<4>, dim3(grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
+                          lam, t0_in_epoch, m, batch_id_offset);
   else if (d.K <= 16)
-    hipLaunchKernelGGL(saga_batch_gather_kernel<16>, dim3(grid), dim3(kBlock), 0, st, d, lam, t0_in_epoch,
-                       m, batch_id_offset);
+    hipExtLaunchKernelGGL(saga_batch_gather_kernel<16>, dim3(grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
+                          lam, t0_in_epoch, m, batch_id_offset);
   else {
     set_error("batched mode supports n_classes <= 16 (got %d)", d.K);
     return SGDNET_EUNSUPPORTED;
@@ -379,16 +389,11 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
   return SGDNET_OK;
 }
 
-int batch_gather_blocks(int m) {
-  const int draws_per_block = kBlock / kGroup;
-  const int grid = (m + draws_per_block - 1) / draws_per_block;
-  return grid < 1 ? 1 : grid;
-}
-
-int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st) {
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0,
+                       hipEvent_t ev1) {
   const int grid = (int)((d.p + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, d, lam, tail,
-                     batch_gather_blocks(m));
+  hipExtLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0, ev1,
+                        0, d, lam, tail, batch_gather_blocks(m));
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

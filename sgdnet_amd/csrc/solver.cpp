@@ -150,20 +150,14 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
     const int64_t m = (draws - t0 < batch) ? draws - t0 : batch;
     const int tail = (m != batch) ? 1 : 0;
     if (ev) {
-      hipEvent_t a, b, c;
-      SGD_HIP_TRY(hipEventCreate(&a));
-      SGD_HIP_TRY(hipEventCreate(&b));
-      SGD_HIP_TRY(hipEventCreate(&c));
-      SGD_HIP_TRY(hipEventRecord(a, s->st));
-      int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
+      // dispatch-level start/stop timestamps of each kernel (no host gaps inside the interval)
+      hipEvent_t e[4];
+      for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
+      int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st, e[0], e[1]);
       if (rc) return rc;
-      SGD_HIP_TRY(hipEventRecord(b, s->st));
-      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, s->st);
+      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, s->st, e[2], e[3]);
       if (rc) return rc;
-      SGD_HIP_TRY(hipEventRecord(c, s->st));
-      ev->push_back(a);
-      ev->push_back(b);
-      ev->push_back(c);
+      for (auto x : e) ev->push_back(x);
     } else {
       int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
       if (rc) return rc;
@@ -664,11 +658,11 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   s->lam.batch_seq += n_batches(batch, draws_per_epoch);
   double g = 0.0, w = 0.0;
   int ng = 0;
-  for (size_t i = 0; i + 2 < ev.size(); i += 3) {
+  for (size_t i = 0; i + 3 < ev.size(); i += 4) {
     float ms = 0.f;
     SGD_HIP_TRY(hipEventElapsedTime(&ms, ev[i], ev[i + 1]));
     g += ms;
-    SGD_HIP_TRY(hipEventElapsedTime(&ms, ev[i + 1], ev[i + 2]));
+    SGD_HIP_TRY(hipEventElapsedTime(&ms, ev[i + 2], ev[i + 3]));
     w += ms;
     ++ng;
   }

@@ -1,0 +1,188 @@
+/*
+ * sgdnet_shim.c -- the .Call shim that replaces the reference's generated
+ * src/RcppExports.cpp (lines 9-45 there) in the sgdnet R package.
+ *
+ * It exports exactly the three symbols the R front-end expects
+ * (R/RcppExports.R:68-75, NAMESPACE:26 `useDynLib(sgdnet, .registration = TRUE)`):
+ *
+ *     _sgdnet_SgdnetDense(x, y, control)
+ *     _sgdnet_SgdnetSparse(x, y, control)
+ *     R_init_sgdnet(DllInfo*)
+ *
+ * and forwards to the C ABI of libsgdnet_hip.so (include/sgdnet_hip.h).  Nothing
+ * else of the reference's src/ is needed; R/ stays untouched.
+ *
+ * Build (on a machine that has R; neither this container nor the GPU box does,
+ * so this file is compiled by nobody here -- see INTEGRATION.md):
+ *
+ *     R CMD SHLIB -o sgdnet.so sgdnet_shim.c -I<repo>/include \
+ *         -L<repo>/sgdnet_amd/lib -lsgdnet_hip -Wl,-rpath,<repo>/sgdnet_amd/lib
+ *
+ * Semantics kept from the reference:
+ *   - control fields are looked up BY NAME (src/sgdnet.cpp:76-78,129-138,305,319,326);
+ *   - the sample order comes from R's own RNG between GetRNGstate()/PutRNGstate()
+ *     (Rcpp::RNGScope, src/RcppExports.cpp:14,27): one unif_rand() per inner
+ *     iteration (src/saga-sparse.h:261), so set.seed() reproducibility and the
+ *     RNG state after the call are those of the reference;
+ *   - the returned list has the reference's names, order and shapes
+ *     (src/sgdnet.cpp:275-284);
+ *   - inputs are borrowed read-only; failures become R errors after cleanup.
+ * Backend extensions are read from R options so that the R code needs no change:
+ *   options(sgdnet.mode = "exact" | "batched", sgdnet.batch = <int>, sgdnet.device = <int>)
+ */
+#include <R.h>
+#include <Rinternals.h>
+#include <R_ext/Random.h>
+#include <R_ext/Rdynload.h>
+#include <string.h>
+
+#include "sgdnet_hip.h"
+
+static SEXP list_get(SEXP list, const char* name) {
+  SEXP names = Rf_getAttrib(list, R_NamesSymbol);
+  for (R_xlen_t i = 0; i < XLENGTH(list); ++i)
+    if (strcmp(CHAR(STRING_ELT(names, i)), name) == 0) return VECTOR_ELT(list, i);
+  Rf_error("control list lacks field '%s'", name);
+  return R_NilValue;
+}
+
+static int family_code(const char* f) {
+  if (strcmp(f, "gaussian") == 0) return SGDNET_GAUSSIAN;
+  if (strcmp(f, "binomial") == 0) return SGDNET_BINOMIAL;
+  if (strcmp(f, "multinomial") == 0) return SGDNET_MULTINOMIAL;
+  if (strcmp(f, "mgaussian") == 0) return SGDNET_MGAUSSIAN;
+  Rf_error("unknown family '%s'", f);
+  return -1;
+}
+
+static double r_unif(void* ctx) { (void)ctx; return unif_rand(); }
+
+static void fill_control(SEXP control, sgdnet_control* c) {
+  memset(c, 0, sizeof(*c));
+  c->debug = Rf_asLogical(list_get(control, "debug"));
+  c->elasticnet_mix = Rf_asReal(list_get(control, "elasticnet_mix"));
+  c->family = family_code(CHAR(Rf_asChar(list_get(control, "family"))));
+  c->intercept = Rf_asLogical(list_get(control, "intercept"));
+  c->is_sparse = Rf_asLogical(list_get(control, "is_sparse"));
+  SEXP lambda = list_get(control, "lambda");
+  c->n_lambda_user = (int)XLENGTH(lambda);
+  c->lambda = c->n_lambda_user ? REAL(lambda) : NULL;
+  c->lambda_min_ratio = Rf_asReal(list_get(control, "lambda_min_ratio"));
+  c->max_iter = (unsigned)Rf_asInteger(list_get(control, "max_iter"));
+  c->n_lambda = Rf_asInteger(list_get(control, "n_lambda"));
+  c->n_classes = Rf_asInteger(list_get(control, "n_classes"));
+  c->standardize = Rf_asLogical(list_get(control, "standardize"));
+  c->standardize_response = Rf_asLogical(list_get(control, "standardize_response"));
+  c->tol = Rf_asReal(list_get(control, "tol"));
+  c->type_multinomial =
+      strcmp(CHAR(Rf_asChar(list_get(control, "type_multinomial"))), "grouped") == 0;
+  c->unif = r_unif;                    /* R's RNG, whatever RNGkind() is active */
+  SEXP opt = Rf_GetOption1(Rf_install("sgdnet.mode"));
+  if (opt != R_NilValue && strcmp(CHAR(Rf_asChar(opt)), "batched") == 0) c->mode = SGDNET_MODE_BATCHED;
+  opt = Rf_GetOption1(Rf_install("sgdnet.batch"));
+  if (opt != R_NilValue) c->batch = (int64_t)Rf_asReal(opt);
+  opt = Rf_GetOption1(Rf_install("sgdnet.device"));
+  if (opt != R_NilValue) c->device = Rf_asInteger(opt);
+}
+
+/* builds the list of src/sgdnet.cpp:275-284 from a filled sgdnet_result */
+static SEXP wrap_result(const sgdnet_control* c, const sgdnet_result* r, int K, R_xlen_t p) {
+  const int nl = c->n_lambda;
+  SEXP out = PROTECT(Rf_allocVector(VECSXP, 8));
+  SEXP names = PROTECT(Rf_allocVector(STRSXP, 8));
+  const char* nm[8] = {"a0", "beta", "losses", "npasses", "nulldev", "dev.ratio", "lambda",
+                       "return_codes"};
+  for (int i = 0; i < 8; ++i) SET_STRING_ELT(names, i, Rf_mkChar(nm[i]));
+  Rf_setAttrib(out, R_NamesSymbol, names);
+
+  SEXP a0 = PROTECT(Rf_allocVector(VECSXP, nl));
+  SEXP beta = PROTECT(Rf_allocVector(VECSXP, nl));
+  for (int i = 0; i < nl; ++i) {
+    SEXP a = PROTECT(Rf_allocVector(REALSXP, K));
+    memcpy(REAL(a), r->a0 + (size_t)i * K, sizeof(double) * K);
+    SET_VECTOR_ELT(a0, i, a);
+    SEXP b = PROTECT(Rf_allocMatrix(REALSXP, K, (int)p));
+    memcpy(REAL(b), r->beta + (size_t)i * K * p, sizeof(double) * (size_t)K * p);
+    SET_VECTOR_ELT(beta, i, b);
+    UNPROTECT(2);
+  }
+  SEXP losses = PROTECT(Rf_allocVector(VECSXP, c->debug ? nl : 0));
+  if (c->debug)
+    for (int i = 0; i < nl; ++i) {
+      SEXP l = PROTECT(Rf_allocVector(REALSXP, r->losses_len[i]));
+      memcpy(REAL(l), r->losses + (size_t)i * c->max_iter, sizeof(double) * r->losses_len[i]);
+      SET_VECTOR_ELT(losses, i, l);
+      UNPROTECT(1);
+    }
+  SEXP dev = PROTECT(Rf_allocVector(REALSXP, nl));
+  SEXP lam = PROTECT(Rf_allocVector(REALSXP, nl));
+  SEXP rc = PROTECT(Rf_allocVector(REALSXP, nl));
+  memcpy(REAL(dev), r->dev_ratio, sizeof(double) * nl);
+  memcpy(REAL(lam), r->lambda, sizeof(double) * nl);
+  memcpy(REAL(rc), r->return_codes, sizeof(double) * nl);
+  SET_VECTOR_ELT(out, 0, a0);
+  SET_VECTOR_ELT(out, 1, beta);
+  SET_VECTOR_ELT(out, 2, losses);
+  SET_VECTOR_ELT(out, 3, Rf_ScalarReal(r->npasses));
+  SET_VECTOR_ELT(out, 4, Rf_ScalarReal(r->nulldev));
+  SET_VECTOR_ELT(out, 5, dev);
+  SET_VECTOR_ELT(out, 6, lam);
+  SET_VECTOR_ELT(out, 7, rc);
+  UNPROTECT(8);
+  return out;
+}
+
+static SEXP run_fit(SEXP x, SEXP y, SEXP control, int sparse) {
+  sgdnet_control c;
+  fill_control(control, &c);
+  SEXP ydim = Rf_getAttrib(y, R_DimSymbol);
+  const int y_cols = INTEGER(ydim)[1];
+  R_xlen_t n, p;
+  sgdnet_csc csc;
+  if (sparse) {                                   /* dgCMatrix slots, R/sgdnet.R:226 */
+    SEXP dim = R_do_slot(x, Rf_install("Dim"));
+    n = INTEGER(dim)[0];
+    p = INTEGER(dim)[1];
+    csc.n_rows = n;
+    csc.n_cols = p;
+    csc.colptr = INTEGER(R_do_slot(x, Rf_install("p")));
+    csc.rowidx = INTEGER(R_do_slot(x, Rf_install("i")));
+    csc.values = REAL(R_do_slot(x, Rf_install("x")));
+  } else {
+    SEXP dim = Rf_getAttrib(x, R_DimSymbol);
+    n = INTEGER(dim)[0];
+    p = INTEGER(dim)[1];
+  }
+  const int K = c.n_classes, nl = c.n_lambda;
+  sgdnet_result r;
+  memset(&r, 0, sizeof(r));
+  /* R_alloc memory is reclaimed by R at the end of .Call, also on error */
+  r.a0 = (double*)R_alloc((size_t)K * nl, sizeof(double));
+  r.beta = (double*)R_alloc((size_t)K * p * nl, sizeof(double));
+  r.lambda = (double*)R_alloc(nl, sizeof(double));
+  r.dev_ratio = (double*)R_alloc(nl, sizeof(double));
+  r.return_codes = (double*)R_alloc(nl, sizeof(double));
+  if (c.debug) {
+    r.losses = (double*)R_alloc((size_t)nl * c.max_iter, sizeof(double));
+    r.losses_len = (int32_t*)R_alloc(nl, sizeof(int32_t));
+  }
+  GetRNGstate();                                  /* Rcpp::RNGScope */
+  int rc = sparse ? sgdnet_fit_sparse(&csc, REAL(y), y_cols, &c, &r)
+                  : sgdnet_fit_dense(REAL(x), n, p, REAL(y), y_cols, &c, &r);
+  PutRNGstate();
+  if (rc != SGDNET_OK) Rf_error("sgdnet (HIP backend): %s", sgdnet_last_error());
+  return wrap_result(&c, &r, K, p);
+}
+
+SEXP _sgdnet_SgdnetDense(SEXP x, SEXP y, SEXP control) { return run_fit(x, y, control, 0); }
+SEXP _sgdnet_SgdnetSparse(SEXP x, SEXP y, SEXP control) { return run_fit(x, y, control, 1); }
+
+static const R_CallMethodDef CallEntries[] = {
+    {"_sgdnet_SgdnetDense", (DL_FUNC)&_sgdnet_SgdnetDense, 3},
+    {"_sgdnet_SgdnetSparse", (DL_FUNC)&_sgdnet_SgdnetSparse, 3},
+    {NULL, NULL, 0}};
+
+void R_init_sgdnet(DllInfo* dll) {
+  R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
+  R_useDynamicSymbols(dll, FALSE);
+}
