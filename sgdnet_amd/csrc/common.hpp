@@ -40,6 +40,12 @@ struct SagaDev {
   const double* xd;   // dense p x n
   const double* c;    // x_center_scaled (p) or nullptr
   const double* y;    // Ky x n
+  // packed per-sample records for the batched gather (saga_batched.hip)
+  const char* rec;    // n records of rec_stride bytes
+  const char* ovf;    // overflow records (256 B each)
+  int rec_stride;
+  int rec_cap;        // entries held by the main record
+  int rec_val_off;    // byte offset of val[] inside a record
   // solver state (K fastest, like the reference's ArrayXXd K x p / K x n)
   double* w;
   double* G;      // g_sum

@@ -18,11 +18,12 @@
 // claims the sample (atomic exchange) and later ones contribute nothing.
 //
 // Memory behaviour: the gather kernel is the HBM-bound one -- per draw it pulls
-// one stream entry, two row pointers, z indices, z values, y and the gradient
-// memory (algorithmic 16 + 12 z + 16 K bytes) at random sample
-// positions; 16-lane groups own one draw so that a wavefront has 4 independent
-// gathers in flight and reduces x.w with intra-row shuffles.  w, D and G are
-// K*p doubles (80 KB at 10k features) and stay L2 / Infinity-Cache resident.
+// one stream entry, the sample's packed record (y, z indices, z values) and the
+// gradient memory (algorithmic 16 + 12 z + 16 K bytes) at random
+// sample positions; 16-lane groups own one draw so that a wavefront has 4
+// independent gathers in flight and reduces x.w with intra-row shuffles.  w, D
+// and G are K*p doubles (80 KB at 10k features) and stay L2 / Infinity-Cache
+// resident.
 #include <hip/hip_ext.h>
 
 #include "device_math.hpp"
@@ -56,11 +57,49 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
 }  // namespace
 
 // --------------------------------------------------------------------------
+// Packed sample records (built once per solver, solver.cpp: build_records).
+// HBM random access on MI355X is request-rate bound (~20 G line requests/s
+// whatever the record size up to 128 B), so a draw should touch as few 64-B
+// lines as possible and need no pointer hop:
+//
+//   record s at rec + s*stride (stride = 64-B multiple sized for the 90th
+//   percentile row):  [f64 y][i32 nnz][i32 ovf][i32 idx[cap]] pad8 [f64 val[cap]]
+//   rows longer than cap continue in 256-B overflow records:
+//                     [i32 next][i32 cnt][i32 idx[20]][f64 val[20]]
+//
+// At z = 10 a draw is 3 line requests (was: 2 row pointers + y + idx + val ~ 6).
+// --------------------------------------------------------------------------
+constexpr int kOvfStride = 256;
+constexpr int kOvfCap = 20;
+
+template <class F>
+__device__ __forceinline__ void row_tail_for_each(const SagaDev& d, const char* base, int nnz, int ovf,
+                                                  int gl, F f) {
+  const int cap = d.rec_cap;
+  const int cnt0 = nnz < cap ? nnz : cap;
+  const int* ridx = reinterpret_cast<const int*>(base + 16);
+  const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
+  for (int e = kGroup + gl; e < cnt0; e += kGroup) f((int64_t)ridx[e], rval[e]);
+  int rem = nnz - cnt0;
+  while (rem > 0) {
+    const char* ob = d.ovf + (size_t)ovf * kOvfStride;
+    const int next = reinterpret_cast<const int*>(ob)[0];
+    const int c = reinterpret_cast<const int*>(ob)[1];
+    const int* oi = reinterpret_cast<const int*>(ob + 8);
+    const double* ov = reinterpret_cast<const double*>(ob + 8 + 4 * kOvfCap);
+    for (int e = gl; e < c; e += kGroup) f((int64_t)oi[e], ov[e]);
+    rem -= c;
+    ovf = next;
+  }
+}
+
+// --------------------------------------------------------------------------
 // gather: one 16-lane group per draw, one draw per group (every draw of the
 // batch is in flight at once: the kernel is a chain of dependent loads
-// stream -> rowptr -> idx/val -> w, so parallelism, not per-thread work, hides
-// the HBM latency).  The claim exchange, y and the old gradient memory do not
-// depend on the row and are issued first so that they overlap the chain.
+// stream -> record -> w, so parallelism, not per-thread work, hides the HBM
+// latency).  K == 1: the gradient memory is claimed, read and updated by ONE
+// atomic exchange (a repeated draw reads back the value just stored, so its
+// gc is exactly 0).  K > 1: an int claim per sample, then plain loads/stores.
 // --------------------------------------------------------------------------
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, const LamParams* lamp,
@@ -79,20 +118,22 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
 
   if (active) {
     const uint32_t s = d.stream[t0 + i];
-    const int64_t q0 = d.ptr[s], q1 = d.ptr[s + 1];
+    const char* base = d.rec + (size_t)s * d.rec_stride;
 
-    // independent of the row: claim, response, old gradient memory
+    // independent of the row (K > 1): claim and old gradient memory
     int prev = batch_id;
-    if (gl == 0)
-      prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double* ys = d.y + (int64_t)s * d.Ky;
-    double yv[KMAX];
     double mold[KMAX];
+    if (KMAX > 1) {
+      if (gl == 0)
+        prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      yv[k] = (k < d.Ky) ? ys[k] : 0.0;
-      mold[k] = (k < K) ? d.M[k + (int64_t)s * K] : 0.0;
+      for (int k = 0; k < KMAX; ++k) mold[k] = (k < K) ? d.M[k + (int64_t)s * K] : 0.0;
     }
+
+    const double y0 = *reinterpret_cast<const double*>(base);
+    const int nnz = *reinterpret_cast<const int*>(base + 8);
+    const int ovf = *reinterpret_cast<const int*>(base + 12);
+    const int cnt0 = nnz < d.rec_cap ? nnz : d.rec_cap;
 
     double acc[KMAX];
 #pragma unroll
@@ -101,59 +142,74 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
     // first (usually only) chunk of the row stays in registers for the scatter
     int64_t jf = -1;
     double vf = 0.0;
-    {
-      const int64_t q = q0 + gl;
-      if (q < q1) {
-        jf = d.idx[q];
-        vf = d.val[q];
-        const double* wj = d.w + jf * K;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-          if (k < K) acc[k] += vf * wj[k];
-      }
-    }
-    for (int64_t q = q0 + kGroup + gl; q < q1; q += kGroup) {
-      const int64_t j = d.idx[q];
-      const double v = d.val[q];
-      const double* wj = d.w + j * K;
+    if (gl < cnt0) {
+      jf = reinterpret_cast<const int*>(base + 16)[gl];
+      vf = reinterpret_cast<const double*>(base + d.rec_val_off)[gl];
+      const double* wj = d.w + jf * K;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
-        if (k < K) acc[k] += v * wj[k];
+        if (k < K) acc[k] += vf * wj[k];
+    }
+    const bool has_tail = nnz > cnt0 || cnt0 > kGroup;   // overflow records or a wide main record
+    if (has_tail) {
+      row_tail_for_each(d, base, nnz, ovf, gl, [&](int64_t j, double v) {
+        const double* wj = d.w + j * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K) acc[k] += v * wj[k];
+      });
     }
 
     double lp[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) lp[k] = group_sum(acc[k]) + ((k < K) ? d.b[k] : 0.0);
 
-    const int first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
-    if (first) {
-      // gradient: every lane of the group computes the same K values
-      double g[KMAX];
-      if (d.family == SGDNET_MULTINOMIAL) {
-        const double lse = log_sum_exp(lp, K);
-        const unsigned cls = (unsigned)(yv[0] + 0.5);
+    int first;
+    if (KMAX == 1) {
+      double g0;
+      if (d.family == SGDNET_BINOMIAL)
+        g0 = 1.0 - y0 - 1.0 / (1.0 + exp(lp[0]));
+      else
+        g0 = lp[0] - y0;
+      double gcv = 0.0;
+      if (gl == 0) {
+        const double old = __hip_atomic_exchange(d.M + s, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gcv = g0 - old;
+      }
+      gc[0] = __shfl(gcv, 0, kGroup);
+      first = gc[0] != 0.0;
+    } else {
+      first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
+      if (first) {
+        // gradient: every lane of the group computes the same K values
+        double g[KMAX];
+        if (d.family == SGDNET_MULTINOMIAL) {
+          const double lse = log_sum_exp(lp, K);
+          const unsigned cls = (unsigned)(y0 + 0.5);
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            g[k] = 0.0;
+            if (k < K) {
+              g[k] = exp(lp[k] - lse);
+              if ((unsigned)k == cls) g[k] -= 1.0;
+            }
+          }
+        } else {
+          const double* ys = d.y + (int64_t)s * d.Ky;   // mgaussian: Ky == K responses
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) g[k] = (k < K) ? lp[k] - ys[k] : 0.0;
+        }
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
-          g[k] = 0.0;
           if (k < K) {
-            g[k] = exp(lp[k] - lse);
-            if ((unsigned)k == cls) g[k] -= 1.0;
+            gc[k] = g[k] - mold[k];
+            if (gl == (k & (kGroup - 1))) d.M[k + (int64_t)s * K] = g[k];
           }
         }
-      } else if (d.family == SGDNET_BINOMIAL) {
-        g[0] = 1.0 - yv[0] - 1.0 / (1.0 + exp(lp[0]));
-      } else {
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) g[k] = (k < K) ? lp[k] - yv[k] : 0.0;
       }
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        if (k < K) {
-          gc[k] = g[k] - mold[k];
-          if (gl == (k & (kGroup - 1))) d.M[k + (int64_t)s * K] = g[k];
-        }
-      }
+    }
 
+    if (first) {
       // scatter into D
       if (jf >= 0) {
         double* dj = d.D + jf * K;
@@ -161,13 +217,13 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
         for (int k = 0; k < KMAX; ++k)
           if (k < K && gc[k] != 0.0) atomic_add_f64(dj + k, vf * gc[k]);
       }
-      for (int64_t q = q0 + kGroup + gl; q < q1; q += kGroup) {
-        const int64_t j = d.idx[q];
-        const double v = d.val[q];
-        double* dj = d.D + j * K;
+      if (has_tail) {
+        row_tail_for_each(d, base, nnz, ovf, gl, [&](int64_t j, double v) {
+          double* dj = d.D + j * K;
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-          if (k < K && gc[k] != 0.0) atomic_add_f64(dj + k, v * gc[k]);
+          for (int k = 0; k < KMAX; ++k)
+            if (k < K && gc[k] != 0.0) atomic_add_f64(dj + k, v * gc[k]);
+        });
       }
     }
     if (gl != 0) {

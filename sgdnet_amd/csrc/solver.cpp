@@ -203,6 +203,10 @@ int check_batched_ok(const sgdnet_solver* s) {
     set_error("batched mode supports n_classes <= %d (got %d)", batched_max_classes(), s->d.K);
     return SGDNET_EUNSUPPORTED;
   }
+  if (!s->d.rec) {
+    set_error("batched mode: packed sample records were not built");
+    return SGDNET_EUNSUPPORTED;
+  }
   return SGDNET_OK;
 }
 
@@ -272,6 +276,90 @@ int ensure_ls_table(sgdnet_solver* s, int64_t nit) {
   s->LS_len = nit + 1;
   s->LS_alpha = s->lam.alpha;
   s->LS_gamma = s->lam.gamma;
+  return SGDNET_OK;
+}
+
+
+// Packs the sample-major CSR rows into fixed-stride records for the batched gather
+// (layout: saga_batched.hip "Packed sample records").
+constexpr int kOvfStride = 256;
+constexpr int kOvfCap = 20;
+
+int build_records(sgdnet_solver* s, const sgdnet_problem* pb) {
+  const int64_t n = pb->n_samples;
+  SagaDev& d = s->d;
+  // capacity: 90th percentile of the row lengths (histogram; rows rarely exceed a few hundred)
+  std::vector<int64_t> hist(65, 0);
+  int64_t zmax = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    const int64_t z = pb->rowptr[i + 1] - pb->rowptr[i];
+    hist[(size_t)(z < 64 ? z : 64)]++;
+    zmax = z > zmax ? z : zmax;
+  }
+  int cap = 1;
+  {
+    int64_t acc = 0;
+    const int64_t want = (int64_t)(0.9 * (double)n);
+    for (int z = 0; z <= 64; ++z) {
+      acc += hist[(size_t)z];
+      cap = z < 1 ? 1 : z;
+      if (acc >= want) break;
+    }
+    if (cap >= 64) cap = (int)(zmax < 512 ? zmax : 512);
+  }
+  auto rec_bytes = [](int c) { return 16 + ((4 * c + 7) & ~7) + 8 * c; };
+  const int stride = (rec_bytes(cap) + 63) & ~63;
+  while (rec_bytes(cap + 1) <= stride) ++cap;
+  const int val_off = 16 + ((4 * cap + 7) & ~7);
+  if ((double)n * stride > 64e9) {
+    set_error("packed records would need %.1f GB", (double)n * stride / 1e9);
+    return SGDNET_ENOMEM;
+  }
+  std::vector<char> rec((size_t)n * (size_t)stride, 0);
+  std::vector<char> ovf;
+  const bool y_in_rec = pb->y_rows == 1;
+  for (int64_t i = 0; i < n; ++i) {
+    char* base = rec.data() + (size_t)i * (size_t)stride;
+    const int64_t q0 = pb->rowptr[i];
+    const int nnz = (int)(pb->rowptr[i + 1] - q0);
+    const double y0 = y_in_rec ? pb->y[i] : 0.0;
+    memcpy(base, &y0, 8);
+    memcpy(base + 8, &nnz, 4);
+    const int c0 = nnz < cap ? nnz : cap;
+    memcpy(base + 16, pb->colidx + q0, sizeof(int32_t) * (size_t)c0);
+    memcpy(base + val_off, pb->values + q0, sizeof(double) * (size_t)c0);
+    int done = c0;
+    int32_t* link = reinterpret_cast<int32_t*>(base + 12);   // where the next record's index goes
+    size_t link_off = (size_t)(reinterpret_cast<char*>(link) - rec.data());
+    bool link_in_rec = true;
+    while (done < nnz) {
+      const int c = (nnz - done) < kOvfCap ? (nnz - done) : kOvfCap;
+      const int32_t id = (int32_t)(ovf.size() / kOvfStride);
+      ovf.resize(ovf.size() + kOvfStride, 0);
+      char* ob = ovf.data() + (size_t)id * kOvfStride;
+      memcpy(ob + 4, &c, 4);
+      memcpy(ob + 8, pb->colidx + q0 + done, sizeof(int32_t) * (size_t)c);
+      memcpy(ob + 8 + 4 * kOvfCap, pb->values + q0 + done, sizeof(double) * (size_t)c);
+      // patch the previous link (vectors may have been reallocated: use offsets)
+      if (link_in_rec) memcpy(rec.data() + link_off, &id, 4);
+      else memcpy(ovf.data() + link_off, &id, 4);
+      link_off = (size_t)id * kOvfStride;
+      link_in_rec = false;
+      done += c;
+    }
+  }
+  char* rec_dev = nullptr;
+  char* ovf_dev = nullptr;
+  int rc = dev_upload(s, &rec_dev, rec.data(), rec.size());
+  if (rc) return rc;
+  rc = dev_upload(s, &ovf_dev, ovf.data(), ovf.size());
+  if (rc) return rc;
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));   // host vectors die at return
+  d.rec = rec_dev;
+  d.ovf = ovf_dev;
+  d.rec_stride = stride;
+  d.rec_cap = cap;
+  d.rec_val_off = val_off;
   return SGDNET_OK;
 }
 
@@ -359,6 +447,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
     d.ptr = ptr;
     d.idx = idx;
     d.val = val;
+    if (!pb->standardize) TRY(build_records(s, pb));   // batched mode needs no centring
   } else {
     double* xd;
     TRY(dev_upload(s, &xd, pb->x_dense, n * p));
