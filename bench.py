@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="C4", choices=sorted(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=0, help="staleness window; 0 = automatic (2p)")
+    ap.add_argument("--batch", type=int, default=0, help="staleness window; 0 = automatic (sgdnet_auto_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-epochs", type=int, default=2)
     args = ap.parse_args()
@@ -97,7 +97,12 @@ def main():
     ybar = min(max(ysum / n, 1e-9), 1 - 1e-9)
     b0 = np.array([np.log(ybar / (1 - ybar))])                  # families.h:190-201
 
-    batch = args.batch if args.batch > 0 else min(65536, 2 * p)
+    # staleness window: the library's default rule, 2 * L_max / diag(X'X/n) clamped to 65536
+    col_sq = np.bincount(prob["idx"], weights=prob["val"] ** 2, minlength=p)
+    cs = torch.tensor(col_sq, dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(cs, op=dist.ReduceOp.SUM)
+    batch = args.batch if args.batch > 0 else sa.auto_batch(max_sq, float(cs.max()) / n)
     batch = min(batch, n_local)
     epochs_total = args.warmup + args.steps + 1                 # +1: the event-profiled epoch
     # sample order: R's Mersenne-Twister, set.seed(config id [+ rank])

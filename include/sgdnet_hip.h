@@ -220,6 +220,14 @@ int64_t sgdnet_solver_delta_len(const sgdnet_solver* s);
 /* ConvergenceCheck on the current w against the previous call's w (device-side). */
 int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged);
 
+/* max|w - w_prev| and max|w| of the most recent ConvergenceCheck (src/utils.h:248-249). */
+int sgdnet_solver_last_change(const sgdnet_solver* s, double* max_change, double* max_size);
+
+/* Default staleness window of the batched mode: about 2 * L_max / L_F, where L_max is the
+ * largest squared sample norm and L_F is bounded below by the largest mean squared feature
+ * value (the diagonal of X'X/n); clamped to [64, 65536].  DESIGN.md "Choosing the batch". */
+int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq);
+
 #ifdef __cplusplus
 }
 #endif

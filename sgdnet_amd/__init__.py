@@ -6,6 +6,6 @@ R front-end for the fit path plus benchmark/multi-GPU plumbing.
 """
 from ._lib import LIB_PATH, SgdnetError, load  # noqa: F401
 from .api import SgdnetFit, sgdnet  # noqa: F401
-from .solver import RRng, SagaSolver  # noqa: F401
+from .solver import RRng, SagaSolver, auto_batch  # noqa: F401
 
-__all__ = ["sgdnet", "SgdnetFit", "SagaSolver", "RRng", "SgdnetError", "load", "LIB_PATH"]
+__all__ = ["sgdnet", "SgdnetFit", "SagaSolver", "RRng", "auto_batch", "SgdnetError", "load", "LIB_PATH"]

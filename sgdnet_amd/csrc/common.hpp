@@ -105,7 +105,7 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
                         hipEvent_t ev1 = nullptr);
 int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st,
                        hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
-int batch_gather_blocks(int m);
+int batch_gather_blocks(const SagaDev& d, int m);
 int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);

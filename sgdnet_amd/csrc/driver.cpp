@@ -9,6 +9,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <cmath>
+
 #include <algorithm>
 #include <vector>
 
@@ -218,12 +220,15 @@ struct DrawSource {
   }
 };
 
-int64_t auto_batch(const Features& X) {
-  // Staleness window that keeps the stale-sum update inside the linear-scaling
-  // regime of mini-batch SAGA: about L_max / L_F draws, which for uniformly
-  // sparse data is a small multiple of n_features (DESIGN.md "Choosing the batch").
-  const int64_t b = 2 * X.p;
-  return std::max<int64_t>(64, std::min<int64_t>(b, 65536));
+int64_t auto_batch(const Features& X, double max_sample_sqnorm) {
+  // largest mean squared feature value = largest diagonal entry of X'X/n
+  double diag = 0.0;
+  for (int64_t j = 0; j < X.p; ++j) {
+    double s = 0.0;
+    for (int64_t q = X.colptr[j]; q < X.colptr[j + 1]; ++q) s += X.val[(size_t)q] * X.val[(size_t)q];
+    diag = std::max(diag, s / (double)X.n);
+  }
+  return sgdnet_auto_batch(max_sample_sqnorm, diag);
 }
 
 int validate(const sgdnet_control* c, const sgdnet_result* out, int y_cols) {
@@ -359,7 +364,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       set_error("batched mode is implemented for sparse x only; dense x runs in exact mode");
       return SGDNET_EUNSUPPORTED;
     }
-    if (batch <= 0) batch = auto_batch(X);
+    if (batch <= 0) batch = auto_batch(X, norm_max);
   } else if (mode != SGDNET_MODE_EXACT) {
     set_error("unknown mode %d", mode);
     return SGDNET_EINVAL;
@@ -412,6 +417,8 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
     unsigned epochs = 0;
     int converged = 0;
+    double best_ratio = HUGE_VAL;
+    int worse = 0;
     // one epoch per launch: exactly the draws the reference would consume are taken
     // from the source (R's RNG state after the call matches, SURVEY.md 8b "RNG")
     while (epochs < ctl->max_iter && !converged) {
@@ -424,6 +431,25 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
                              ctl->debug ? losses.data() + epochs : nullptr);
       if (rc) return rc;
       epochs += ran;
+      if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && batch > 64) {
+        // guard of the automatic window: the stale-sum step is only stable below ~L_max/L_F
+        // draws, and the bound used by sgdnet_auto_batch is optimistic for correlated
+        // features.  A change ratio that keeps growing (or stops being finite) halves it.
+        double ch = 0.0, sz = 0.0;
+        sgdnet_solver_last_change(S, &ch, &sz);
+        const double ratio = sz > 0.0 ? ch / sz : 0.0;
+        if (!std::isfinite(ratio) || !std::isfinite(sz)) {
+          set_error("batched mode diverged (non-finite coefficients); pass a smaller control.batch");
+          return SGDNET_EUNSUPPORTED;
+        }
+        if (ratio > 4.0 * best_ratio) ++worse; else worse = 0;
+        best_ratio = std::min(best_ratio, ratio);
+        if (worse >= 2) {
+          batch = std::max<int64_t>(64, batch / 2);
+          worse = 0;
+          best_ratio = ratio;
+        }
+      }
     }
     n_iter += (double)epochs;
     out->return_codes[li] = (epochs == ctl->max_iter) ? 1.0 : 0.0;               // saga-sparse.h:376-382

@@ -25,6 +25,7 @@
 // and G are K*p doubles (80 KB at 10k features) and stay L2 / Infinity-Cache
 // resident.
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 
 #include "device_math.hpp"
 
@@ -94,12 +95,168 @@ __device__ __forceinline__ void row_tail_for_each(const SagaDev& d, const char* 
 }
 
 // --------------------------------------------------------------------------
-// gather: one 16-lane group per draw, one draw per group (every draw of the
-// batch is in flight at once: the kernel is a chain of dependent loads
-// stream -> record -> w, so parallelism, not per-thread work, hides the HBM
-// latency).  K == 1: the gradient memory is claimed, read and updated by ONE
-// atomic exchange (a repeated draw reads back the value just stored, so its
-// gc is exactly 0).  K > 1: an int claim per sample, then plain loads/stores.
+// One draw, executed by a 16-lane group: gather the record, x.w, gradient,
+// gradient-memory update, scatter of x*gc into Dt.  K == 1: the gradient memory
+// is claimed, read and updated by ONE atomic exchange (a repeated draw reads back
+// the value just stored, so its gc is exactly 0).  K > 1: an int claim per
+// sample, then plain loads/stores.  kLds: Dt is a workgroup-private LDS copy of D
+// (ds_add_f64), else the global D (global_atomic_add_f64).
+// gc[] returns the draw's gradient change on lane 0 of the group, 0 elsewhere.
+// --------------------------------------------------------------------------
+template <bool kLds>
+__device__ __forceinline__ void scatter_add(double* p, double v) {
+  if (kLds)
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int KMAX, bool kLds>
+__device__ __forceinline__ void saga_draw(const SagaDev& d, const uint32_t s, const int gl,
+                                          const int batch_id, double* Dt, double (&gc)[KMAX]) {
+  const int K = KMAX == 1 ? 1 : d.K;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;
+  const char* base = d.rec + (size_t)s * d.rec_stride;
+
+  // independent of the row (K > 1): claim and old gradient memory
+  int prev = batch_id;
+  double mold[KMAX];
+  if (KMAX > 1) {
+    if (gl == 0)
+      prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) mold[k] = (k < K) ? d.M[k + (int64_t)s * K] : 0.0;
+  }
+
+  const double y0 = *reinterpret_cast<const double*>(base);
+  const int nnz = *reinterpret_cast<const int*>(base + 8);
+  const int ovf = *reinterpret_cast<const int*>(base + 12);
+  const int cnt0 = nnz < d.rec_cap ? nnz : d.rec_cap;
+  const bool has_tail = nnz > cnt0 || cnt0 > kGroup;   // overflow records or a wide main record
+
+  double acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
+
+  // first (usually only) chunk of the row stays in registers for the scatter
+  int64_t jf = -1;
+  double vf = 0.0;
+  if (gl < cnt0) {
+    jf = reinterpret_cast<const int*>(base + 16)[gl];
+    vf = reinterpret_cast<const double*>(base + d.rec_val_off)[gl];
+    const double* wj = d.w + jf * K;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) acc[k] += vf * wj[k];
+  }
+  if (has_tail) {
+    row_tail_for_each(d, base, nnz, ovf, gl, [&](int64_t j, double v) {
+      const double* wj = d.w + j * K;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) acc[k] += v * wj[k];
+    });
+  }
+
+  double lp[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) lp[k] = group_sum(acc[k]) + ((k < K) ? d.b[k] : 0.0);
+
+  int first;
+  if (KMAX == 1) {
+    double g0;
+    if (d.family == SGDNET_BINOMIAL)
+      g0 = 1.0 - y0 - 1.0 / (1.0 + exp(lp[0]));
+    else
+      g0 = lp[0] - y0;
+    double gcv = 0.0;
+    if (gl == 0) {
+      const double old = __hip_atomic_exchange(d.M + s, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gcv = g0 - old;
+    }
+    gc[0] = __shfl(gcv, 0, kGroup);
+    first = gc[0] != 0.0;
+  } else {
+    first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
+    if (first) {
+      // gradient: every lane of the group computes the same K values
+      double g[KMAX];
+      if (d.family == SGDNET_MULTINOMIAL) {
+        const double lse = log_sum_exp(lp, K);
+        const unsigned cls = (unsigned)(y0 + 0.5);
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          g[k] = 0.0;
+          if (k < K) {
+            g[k] = exp(lp[k] - lse);
+            if ((unsigned)k == cls) g[k] -= 1.0;
+          }
+        }
+      } else {
+        const double* ys = d.y + (int64_t)s * d.Ky;   // mgaussian: Ky == K responses
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) g[k] = (k < K) ? lp[k] - ys[k] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          gc[k] = g[k] - mold[k];
+          if (gl == (k & (kGroup - 1))) d.M[k + (int64_t)s * K] = g[k];
+        }
+      }
+    }
+  }
+
+  if (first) {
+    if (jf >= 0) {
+      double* dj = Dt + jf * K;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && gc[k] != 0.0) scatter_add<kLds>(dj + k, vf * gc[k]);
+    }
+    if (has_tail) {
+      row_tail_for_each(d, base, nnz, ovf, gl, [&](int64_t j, double v) {
+        double* dj = Dt + j * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K && gc[k] != 0.0) scatter_add<kLds>(dj + k, v * gc[k]);
+      });
+    }
+  }
+  if (gl != 0) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;   // count each draw once in the intercept sum
+  }
+}
+
+// Intercept accumulator: one partial per block and class, summed by the sweep in a
+// fixed order (thousands of same-address atomics would serialise at ~12 ns each).
+template <int KMAX, int kThreads>
+__device__ __forceinline__ void store_d0_partial(const SagaDev& d, int K, const double (&gc)[KMAX]) {
+  __shared__ double part[kThreads / 64][KMAX];
+  const int wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    if (k < K) {
+      const double tot = wave_sum(gc[k]);
+      if ((threadIdx.x & 63) == 0) part[wave][k] = tot;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double tot = 0.0;
+#pragma unroll
+    for (int wv = 0; wv < kThreads / 64; ++wv) tot += part[wv][threadIdx.x];
+    d.d0_part[(int64_t)blockIdx.x * K + threadIdx.x] = tot;
+  }
+}
+
+// --------------------------------------------------------------------------
+// gather, global-scatter form: one draw per 16-lane group, every draw of the
+// batch in flight at once (the kernel is a chain of dependent loads stream ->
+// record -> w, so parallelism, not per-thread work, hides the HBM latency).
+// Scattered fp64 atomics run at ~20 G requests/s chip-wide: 10 per draw at z = 10.
 // --------------------------------------------------------------------------
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, const LamParams* lamp,
@@ -108,150 +265,149 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
   const int K = KMAX == 1 ? 1 : d.K;
   const int gl = threadIdx.x & (kGroup - 1);
   const int i = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
-  const bool active = i < m;
   const int64_t t0 = lamp->stream_base + t0_in_epoch;
   const int batch_id = lamp->batch_seq + batch_id_offset;
-
   double gc[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;
+  if (i < m) saga_draw<KMAX, false>(d, d.stream[t0 + i], gl, batch_id, d.D, gc);
+  if (d.fit_intercept) store_d0_partial<KMAX, kBlock>(d, K, gc);
+}
 
-  if (active) {
-    const uint32_t s = d.stream[t0 + i];
-    const char* base = d.rec + (size_t)s * d.rec_stride;
-
-    // independent of the row (K > 1): claim and old gradient memory
-    int prev = batch_id;
-    double mold[KMAX];
-    if (KMAX > 1) {
-      if (gl == 0)
-        prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// --------------------------------------------------------------------------
+// K == 1 software pipeline for the LDS-privatised gather: a 16-lane group keeps U
+// draws in flight.  The source is ordered in phases (stream -> records -> w ->
+// gradient -> gradient-memory exchange -> LDS scatter) with no atomic between the
+// loads of a phase, so the U round trips of every phase overlap.  A record's first
+// `cap` slots are always readable (zero padded), so the idx/val loads do not wait
+// for the header.
+// --------------------------------------------------------------------------
+template <int U>
+__device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint32_t* sp, const int i,
+                                                    const int hi, const int step, const int gl,
+                                                    double* Dl) {
+  const int cap = d.rec_cap;
+  uint32_t s[U];
+  bool valid[U];
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k) mold[k] = (k < K) ? d.M[k + (int64_t)s * K] : 0.0;
-    }
-
-    const double y0 = *reinterpret_cast<const double*>(base);
-    const int nnz = *reinterpret_cast<const int*>(base + 8);
-    const int ovf = *reinterpret_cast<const int*>(base + 12);
-    const int cnt0 = nnz < d.rec_cap ? nnz : d.rec_cap;
-
-    double acc[KMAX];
+  for (int u = 0; u < U; ++u) {
+    const int iu = i + u * step;
+    valid[u] = iu < hi;
+    s[u] = sp[valid[u] ? iu : i];
+  }
+  const char* base[U];
+  double y0[U], vf[U];
+  int nnz[U], ovf[U], jf[U];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
-
-    // first (usually only) chunk of the row stays in registers for the scatter
-    int64_t jf = -1;
-    double vf = 0.0;
-    if (gl < cnt0) {
-      jf = reinterpret_cast<const int*>(base + 16)[gl];
-      vf = reinterpret_cast<const double*>(base + d.rec_val_off)[gl];
-      const double* wj = d.w + jf * K;
+  for (int u = 0; u < U; ++u) {
+    base[u] = d.rec + (size_t)s[u] * d.rec_stride;
+    y0[u] = *reinterpret_cast<const double*>(base[u]);
+    nnz[u] = *reinterpret_cast<const int*>(base[u] + 8);
+    ovf[u] = *reinterpret_cast<const int*>(base[u] + 12);
+    jf[u] = gl < cap ? reinterpret_cast<const int*>(base[u] + 16)[gl] : 0;
+    vf[u] = gl < cap ? reinterpret_cast<const double*>(base[u] + d.rec_val_off)[gl] : 0.0;
+  }
+  double acc[U];
+  bool in[U], tail[U];
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
-        if (k < K) acc[k] += vf * wj[k];
-    }
-    const bool has_tail = nnz > cnt0 || cnt0 > kGroup;   // overflow records or a wide main record
-    if (has_tail) {
-      row_tail_for_each(d, base, nnz, ovf, gl, [&](int64_t j, double v) {
-        const double* wj = d.w + j * K;
+  for (int u = 0; u < U; ++u) {
+    const int cnt0 = nnz[u] < cap ? nnz[u] : cap;
+    in[u] = valid[u] && gl < cnt0 && gl < kGroup;
+    tail[u] = valid[u] && (nnz[u] > cnt0 || cnt0 > kGroup);
+    acc[u] = in[u] ? vf[u] * d.w[jf[u]] : 0.0;
+  }
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-          if (k < K) acc[k] += v * wj[k];
-      });
-    }
-
-    double lp[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) lp[k] = group_sum(acc[k]) + ((k < K) ? d.b[k] : 0.0);
-
-    int first;
-    if (KMAX == 1) {
-      double g0;
-      if (d.family == SGDNET_BINOMIAL)
-        g0 = 1.0 - y0 - 1.0 / (1.0 + exp(lp[0]));
-      else
-        g0 = lp[0] - y0;
-      double gcv = 0.0;
-      if (gl == 0) {
-        const double old = __hip_atomic_exchange(d.M + s, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gcv = g0 - old;
-      }
-      gc[0] = __shfl(gcv, 0, kGroup);
-      first = gc[0] != 0.0;
-    } else {
-      first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
-      if (first) {
-        // gradient: every lane of the group computes the same K values
-        double g[KMAX];
-        if (d.family == SGDNET_MULTINOMIAL) {
-          const double lse = log_sum_exp(lp, K);
-          const unsigned cls = (unsigned)(y0 + 0.5);
-#pragma unroll
-          for (int k = 0; k < KMAX; ++k) {
-            g[k] = 0.0;
-            if (k < K) {
-              g[k] = exp(lp[k] - lse);
-              if ((unsigned)k == cls) g[k] -= 1.0;
-            }
-          }
-        } else {
-          const double* ys = d.y + (int64_t)s * d.Ky;   // mgaussian: Ky == K responses
-#pragma unroll
-          for (int k = 0; k < KMAX; ++k) g[k] = (k < K) ? lp[k] - ys[k] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k) {
-          if (k < K) {
-            gc[k] = g[k] - mold[k];
-            if (gl == (k & (kGroup - 1))) d.M[k + (int64_t)s * K] = g[k];
-          }
-        }
-      }
-    }
-
-    if (first) {
-      // scatter into D
-      if (jf >= 0) {
-        double* dj = d.D + jf * K;
-#pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-          if (k < K && gc[k] != 0.0) atomic_add_f64(dj + k, vf * gc[k]);
-      }
-      if (has_tail) {
-        row_tail_for_each(d, base, nnz, ovf, gl, [&](int64_t j, double v) {
-          double* dj = d.D + j * K;
-#pragma unroll
-          for (int k = 0; k < KMAX; ++k)
-            if (k < K && gc[k] != 0.0) atomic_add_f64(dj + k, v * gc[k]);
-        });
-      }
-    }
-    if (gl != 0) {
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;   // count each draw once below
+  for (int u = 0; u < U; ++u) {
+    if (tail[u]) {
+      double a = 0.0;
+      row_tail_for_each(d, base[u], nnz[u], ovf[u], gl, [&](int64_t j, double v) { a += v * d.w[j]; });
+      acc[u] += a;
     }
   }
-
-  // intercept accumulator: one partial per block and class, summed by the sweep in a fixed
-  // order (thousands of same-address atomics would serialise at ~12 ns each)
-  if (d.fit_intercept) {
-    __shared__ double part[kBlock / 64][KMAX];
-    const int wave = threadIdx.x >> 6;
+  const double b0 = d.b[0];
+  double g0[U];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (k < K) {
-        const double tot = wave_sum(gc[k]);
-        if ((threadIdx.x & 63) == 0) part[wave][k] = tot;
-      }
-    }
-    __syncthreads();
-    if (threadIdx.x < K) {
-      double tot = 0.0;
+  for (int u = 0; u < U; ++u) {
+    const double lp = group_sum(acc[u]) + b0;
+    g0[u] = d.family == SGDNET_BINOMIAL ? 1.0 - y0[u] - 1.0 / (1.0 + exp(lp)) : lp - y0[u];
+  }
+  double gcv[U];
 #pragma unroll
-      for (int wv = 0; wv < kBlock / 64; ++wv) tot += part[wv][threadIdx.x];
-      d.d0_part[(int64_t)blockIdx.x * K + threadIdx.x] = tot;
+  for (int u = 0; u < U; ++u) {
+    gcv[u] = 0.0;
+    if (gl == 0 && valid[u]) {
+      const double old =
+          __hip_atomic_exchange(d.M + s[u], g0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gcv[u] = g0[u] - old;
     }
   }
+  double tot = 0.0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const double gc = __shfl(gcv[u], 0, kGroup);
+    if (gc != 0.0) {
+      if (in[u]) scatter_add<true>(Dl + jf[u], vf[u] * gc);
+      if (tail[u])
+        row_tail_for_each(d, base[u], nnz[u], ovf[u], gl,
+                          [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
+    }
+    tot += gcv[u];
+  }
+  return tot;   // non-zero on lane 0 of the group only
+}
+
+// --------------------------------------------------------------------------
+// gather, LDS-privatised scatter ("LDS staging of the gradient-average slice"):
+// a 1024-thread workgroup owns `draws_per_block` consecutive draws and
+// accumulates x*gc into a dense LDS copy of D (K*p doubles, ds_add_f64); at the
+// end the copy is flushed with line-coalesced global atomics: lanes i..i+7 of a
+// wave hit one 64-B line, so a workgroup issues at most K*p/8 atomic requests
+// instead of one per non-zero.
+// --------------------------------------------------------------------------
+constexpr int kLdsBlock = 1024;
+
+template <int KMAX>
+__global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDev d, const LamParams* lamp,
+                                                                          int64_t t0_in_epoch, int m,
+                                                                          int batch_id_offset,
+                                                                          int draws_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double Dl[];
+  const int K = KMAX == 1 ? 1 : d.K;
+  const int64_t KP = (int64_t)K * d.p;
+  for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) Dl[i] = 0.0;
+  __syncthreads();
+
+  const int gl = threadIdx.x & (kGroup - 1);
+  const int group = threadIdx.x / kGroup;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  const int lo = blockIdx.x * draws_per_block;
+  const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
+
+  double gct[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) gct[k] = 0.0;
+  constexpr int kGroups = kLdsBlock / kGroup;
+  if (KMAX == 1) {
+    constexpr int U = 4;
+    for (int i = lo + group; i < hi; i += kGroups * U)
+      gct[0] += saga_draws_k1_lds<U>(d, d.stream + t0, i, hi, kGroups, gl, Dl);
+  } else {
+    for (int i = lo + group; i < hi; i += kGroups) {
+      double gc[KMAX];
+      saga_draw<KMAX, true>(d, d.stream[t0 + i], gl, batch_id, Dl, gc);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) gct[k] += gc[k];
+    }
+  }
+  __syncthreads();
+
+  // flush: consecutive lanes -> consecutive doubles, 8 lanes per 64-B atomic request
+  for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) {
+    const double v = Dl[i];
+    if (v != 0.0) atomic_add_f64(d.D + i, v);
+  }
+  if (d.fit_intercept) store_d0_partial<KMAX, kLdsBlock>(d, K, gct);
 }
 
 // --------------------------------------------------------------------------
@@ -416,30 +572,87 @@ __global__ __launch_bounds__(kBlock) void saga_delta_apply_kernel(SagaDev d, con
 // ------------------------------ launchers ---------------------------------
 int batched_max_classes() { return 16; }
 
-int batch_gather_blocks(int m) {
-  const int draws_per_block = kBlock / kGroup;
-  const int grid = (m + draws_per_block - 1) / draws_per_block;
-  return grid < 1 ? 1 : grid;
+// Launch geometry of the gather for a batch of m draws.  The LDS-privatised form
+// needs the dense K*p table in LDS twice per CU (2 workgroups per CU) and enough
+// draws per workgroup to amortise its flush.
+struct GatherPlan {
+  bool lds;
+  int grid;
+  int draws_per_block;
+  size_t lds_bytes;
+};
+
+static GatherPlan plan_gather(const SagaDev& d, int m) {
+  GatherPlan g{};
+  const size_t table = sizeof(double) * (size_t)d.K * (size_t)d.p;
+  static const int force = [] {
+    const char* e = getenv("SGDNET_GATHER");   // "lds" | "global": experiments only
+    return !e ? 0 : (e[0] == 'l' ? 1 : 2);
+  }();
+  static const int target_grid = [] {
+    const char* e = getenv("SGDNET_LDS_GRID");
+    return e ? atoi(e) : 256;
+  }();
+  const bool fits = table <= 80 * 1024;
+  g.lds = fits && force != 2 && (force == 1 || m >= 8192);
+  if (g.lds) {
+    int dpb = (m + target_grid - 1) / target_grid;
+    const int per_round = kLdsBlock / kGroup;
+    if (dpb < per_round) dpb = per_round;
+    g.draws_per_block = dpb;
+    g.grid = (m + dpb - 1) / dpb;
+    g.lds_bytes = table;
+  } else {
+    g.draws_per_block = kBlock / kGroup;
+    g.grid = (m + g.draws_per_block - 1) / g.draws_per_block;
+  }
+  if (g.grid < 1) g.grid = 1;
+  return g;
 }
+
+int batch_gather_blocks(const SagaDev& d, int m) { return plan_gather(d, m).grid; }
 
 // ev0/ev1 (optional): dispatch start/stop timestamps of exactly this kernel
 // (hipExtLaunchKernelGGL), used by the benchmark's per-kernel timing.
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
                         int batch_id_offset, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   (void)tail;
-  const int grid = batch_gather_blocks(m);
-  if (d.K == 1)
-    hipExtLaunchKernelGGL(saga_batch_gather_kernel<1>, dim3(grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
-                          lam, t0_in_epoch, m, batch_id_offset);
-  else if (d.K <= 4)
-    hipExtLaunchKernelGGL(saga_batch_gather_kernel<4>, dim3(grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
-                          lam, t0_in_epoch, m, batch_id_offset);
-  else if (d.K <= 16)
-    hipExtLaunchKernelGGL(saga_batch_gather_kernel<16>, dim3(grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
-                          lam, t0_in_epoch, m, batch_id_offset);
-  else {
+  if (d.K > 16) {
     set_error("batched mode supports n_classes <= 16 (got %d)", d.K);
     return SGDNET_EUNSUPPORTED;
+  }
+  const GatherPlan g = plan_gather(d, m);
+  if (g.lds) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      const int cap = 96 * 1024;   // the dense table is limited to 80 KiB (plan_gather)
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+      attr_done = true;
+    }
+    if (d.K == 1)
+      hipExtLaunchKernelGGL(saga_batch_gather_lds_kernel<1>, dim3(g.grid), dim3(kLdsBlock), g.lds_bytes, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    else if (d.K <= 4)
+      hipExtLaunchKernelGGL(saga_batch_gather_lds_kernel<4>, dim3(g.grid), dim3(kLdsBlock), g.lds_bytes, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    else
+      hipExtLaunchKernelGGL(saga_batch_gather_lds_kernel<16>, dim3(g.grid), dim3(kLdsBlock), g.lds_bytes,
+                            st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+  } else {
+    if (d.K == 1)
+      hipExtLaunchKernelGGL(saga_batch_gather_kernel<1>, dim3(g.grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
+                            lam, t0_in_epoch, m, batch_id_offset);
+    else if (d.K <= 4)
+      hipExtLaunchKernelGGL(saga_batch_gather_kernel<4>, dim3(g.grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
+                            lam, t0_in_epoch, m, batch_id_offset);
+    else
+      hipExtLaunchKernelGGL(saga_batch_gather_kernel<16>, dim3(g.grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
+                            lam, t0_in_epoch, m, batch_id_offset);
   }
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
@@ -449,7 +662,7 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStr
                        hipEvent_t ev1) {
   const int grid = (int)((d.p + kBlock - 1) / kBlock);
   hipExtLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0, ev1,
-                        0, d, lam, tail, batch_gather_blocks(m));
+                        0, d, lam, tail, batch_gather_blocks(d, m));
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

@@ -57,6 +57,7 @@ struct sgdnet_solver {
   int64_t g_batch = 0, g_draws = 0;
   bool w_prev_valid = false;
   int64_t d0_parts_cap = 0;     // blocks the d0_part buffer can hold
+  double last_change = 0.0, last_size = 0.0;
 };
 
 namespace {
@@ -114,7 +115,7 @@ void drop_graph(sgdnet_solver* s) {
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   if (batch > draws) batch = draws;
-  const int64_t blocks = batch_gather_blocks((int)batch);
+  const int64_t blocks = batch_gather_blocks(s->d, (int)batch);
   if (blocks > s->d0_parts_cap) {
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     if (s->d.d0_part) SGD_HIP_TRY(hipFree(s->d.d0_part));
@@ -229,6 +230,8 @@ int read_convergence(sgdnet_solver* s, double tol, int* converged) {
   const bool all_zero = (max_size == 0.0) && (max_change == 0.0);
   const bool no_change = (max_size != 0.0) && (max_change / max_size <= tol);
   *converged = (all_zero || no_change) ? 1 : 0;
+  s->last_change = max_change;
+  s->last_size = max_size;
   return SGDNET_OK;
 }
 
@@ -805,6 +808,20 @@ int sgdnet_solver_apply_merged(sgdnet_solver* s, const void* device_buf, double 
   if (rc) return rc;
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   return SGDNET_OK;
+}
+
+int sgdnet_solver_last_change(const sgdnet_solver* s, double* max_change, double* max_size) {
+  if (!s || !max_change || !max_size) return SGDNET_EINVAL;
+  *max_change = s->last_change;
+  *max_size = s->last_size;
+  return SGDNET_OK;
+}
+
+int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq) {
+  if (!(max_sample_sqnorm > 0.0) || !(max_feature_mean_sq > 0.0)) return 64;
+  const double b = 2.0 * max_sample_sqnorm / max_feature_mean_sq;
+  if (!(b < 65536.0)) return 65536;
+  return b < 64.0 ? 64 : (int64_t)b;
 }
 
 int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged) {

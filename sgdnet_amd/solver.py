@@ -30,6 +30,11 @@ class RRng:
         return out
 
 
+def auto_batch(max_sample_sqnorm, max_feature_mean_sq):
+    """Default staleness window of the batched mode (sgdnet_auto_batch of the C ABI)."""
+    return int(_lib.load().sgdnet_auto_batch(float(max_sample_sqnorm), float(max_feature_mean_sq)))
+
+
 class SagaSolver:
     """One problem resident in HBM: sample-major x, y and the five SAGA state arrays
     (reference src/sgdnet.cpp:187-198).
@@ -151,6 +156,12 @@ class SagaSolver:
         out = C.c_double(0)
         check(self._L.sgdnet_solver_deviance(self._h, C.byref(out)))
         return out.value
+
+    def last_change(self):
+        """(max|w - w_prev|, max|w|) of the most recent convergence check."""
+        ch, sz = C.c_double(0), C.c_double(0)
+        check(self._L.sgdnet_solver_last_change(self._h, C.byref(ch), C.byref(sz)))
+        return ch.value, sz.value
 
     def convergence(self, tol):
         c = C.c_int(0)
