@@ -225,7 +225,7 @@ int sgdnet_solver_last_change(const sgdnet_solver* s, double* max_change, double
 
 /* Default staleness window of the batched mode: about 2 * L_max / L_F, where L_max is the
  * largest squared sample norm and L_F is bounded below by the largest mean squared feature
- * value (the diagonal of X'X/n); clamped to [64, 65536].  DESIGN.md "Choosing the batch". */
+ * value (the diagonal of X'X/n); clamped to [64, 131072].  DESIGN.md "Choosing the batch". */
 int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq);
 
 #ifdef __cplusplus

@@ -33,6 +33,7 @@ struct SagaDev {
   int64_t n;     // resident samples
   int64_t p;     // features
   double n_total;  // samples of the whole job (the 1/n of the gradient average)
+  float avg_nnz;   // mean non-zeros per sample (sparse)
   // data, sample-major (SURVEY.md 8a "x")
   const int64_t* ptr;
   const int32_t* idx;
@@ -57,6 +58,7 @@ struct SagaDev {
   // batched-mode scratch
   double* D;      // K x p scatter accumulator
   double* d0_part;  // blocks x K  per-block partial sums of the intercept accumulator
+  double* slab;     // blocks x K x p  per-workgroup copies of D (LDS-privatised gather) or nullptr
   int* claim;     // n     first-occurrence claims (K > 1)
   const uint32_t* stream;
 };
@@ -106,6 +108,7 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
 int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st,
                        hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int batch_gather_blocks(const SagaDev& d, int m);
+int64_t batch_gather_slab_doubles(const SagaDev& d, int m);
 int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);

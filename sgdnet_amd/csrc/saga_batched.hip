@@ -402,83 +402,151 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   }
   __syncthreads();
 
-  // flush: consecutive lanes -> consecutive doubles, 8 lanes per 64-B atomic request
-  for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) {
-    const double v = Dl[i];
-    if (v != 0.0) atomic_add_f64(d.D + i, v);
-  }
+  // flush the private copy as this workgroup's slab: plain coalesced stores (atomics would
+  // cap the flush at the ~1.3 TB/s atomic rate); the sweep sums the slabs in a fixed order
+  double* slab = d.slab + (int64_t)blockIdx.x * KP;
+  for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
   if (d.fit_intercept) store_d0_partial<KMAX, kLdsBlock>(d, K, gct);
 }
 
 // --------------------------------------------------------------------------
-// sweep: one thread per feature (all K classes: GroupLasso needs the column norm).
+// sweep: per feature (all K classes: GroupLasso needs the column norm)
+//   w_j <- r^m w_j - gamma LS_m G_j - gamma D_j ; prox ; G_j += D_j / n
 // --------------------------------------------------------------------------
+struct SweepParams {
+  int penalty;
+  double gamma, beta, r_m, ls_m, m_d, n_d;
+};
+
+__device__ __forceinline__ SweepParams load_sweep_params(const SagaDev& d, const LamParams* lamp, int tail) {
+  SweepParams q;
+  q.penalty = lamp->penalty;
+  q.gamma = lamp->gamma;
+  q.beta = lamp->beta;
+  q.r_m = tail ? lamp->r_tail : lamp->r_full;
+  q.ls_m = tail ? lamp->ls_tail : lamp->ls_full;
+  q.m_d = (double)(tail ? lamp->m_tail : lamp->m_full);
+  q.n_d = d.n_total;
+  return q;
+}
+
+// dj: the K scatter sums of feature j (any address space)
+__device__ __forceinline__ void sweep_feature(const SagaDev& d, const SweepParams& q, int64_t j,
+                                              const double* dj) {
+  const int K = d.K;
+  double* wj = d.w + j * K;
+  double* gj = d.G + j * K;
+  const double gls = q.gamma * q.ls_m;
+  if (q.penalty == SGDNET_GROUPLASSO) {
+    double nrm = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double v = q.r_m * wj[k] - gls * gj[k] - q.gamma * dj[k];
+      wj[k] = v;
+      nrm += v * v;
+    }
+    nrm = sqrt(nrm);
+    const double factor = q.beta * q.gamma * q.ls_m / nrm;
+    if (factor < 1.0) {
+      for (int k = 0; k < K; ++k) wj[k] *= 1.0 - factor;
+    } else {
+      for (int k = 0; k < K; ++k) wj[k] = 0.0;
+    }
+    for (int k = 0; k < K; ++k) gj[k] += dj[k] / q.n_d;
+  } else {
+    const double tau = q.beta * q.gamma * q.ls_m;
+    for (int k = 0; k < K; ++k) {
+      const double dk = dj[k];
+      double v = q.r_m * wj[k] - gls * gj[k] - q.gamma * dk;
+      if (q.penalty == SGDNET_ELASTICNET) v = soft_threshold(v, tau);
+      wj[k] = v;
+      if (dk != 0.0) gj[k] += dk / q.n_d;
+    }
+  }
+}
+
+// intercept: gb += d0/n ; b -= gamma (0.01 m gb + d0/n), d0 = sum of the gather kernel's
+// per-block partials in a fixed order.  Executed by one whole block.
+template <int kThreads>
+__device__ __forceinline__ void sweep_intercept(const SagaDev& d, const SweepParams& q, int n_parts) {
+  __shared__ double red[kThreads / 64];
+  const int K = d.K;
+  for (int k = 0; k < K; ++k) {
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n_parts; i += kThreads) acc += d.d0_part[(int64_t)i * K + k];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int wv = 0; wv < kThreads / 64; ++wv) tot += red[wv];
+      const double dk = tot / q.n_d;
+      const double gbk = d.gb[k] + dk;
+      d.gb[k] = gbk;
+      d.b[k] -= q.gamma * (gbk * 0.01 * q.m_d + dk);
+    }
+    __syncthreads();
+  }
+}
+
+// D accumulated by global atomics (saga_batch_gather_kernel): one thread per feature.
 __global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
                                                                   int n_parts) {
-  const int K = d.K;
-  const int penalty = lamp->penalty;
-  const double gamma = lamp->gamma, beta = lamp->beta;
-  const double r_m = tail ? lamp->r_tail : lamp->r_full;
-  const double ls_m = tail ? lamp->ls_tail : lamp->ls_full;
-  const double m_d = (double)(tail ? lamp->m_tail : lamp->m_full);
-  const double n_d = d.n_total;
+  const SweepParams q = load_sweep_params(d, lamp, tail);
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (j < d.p) {
-    double* wj = d.w + j * K;
-    double* gj = d.G + j * K;
-    double* dj = d.D + j * K;
-    const double gls = gamma * ls_m;
-    if (penalty == SGDNET_GROUPLASSO) {
-      double nrm = 0.0;
+    double* dj = d.D + j * d.K;
+    sweep_feature(d, q, j, dj);
+    for (int k = 0; k < d.K; ++k) dj[k] = 0.0;
+  }
+  if (blockIdx.x == 0 && d.fit_intercept) sweep_intercept<kBlock>(d, q, n_parts);
+}
+
+// D held as per-workgroup slabs (saga_batch_gather_lds_kernel): a block owns F = 32/K
+// features; 8 thread groups each sum an eighth of the slabs (coalesced over the features),
+// the partial sums meet in LDS in a fixed order, then one thread per feature updates.
+constexpr int kSlabElems = 32;
+constexpr int kSlabGroups = kBlock / kSlabElems;
+
+__global__ __launch_bounds__(kBlock) void saga_batch_sweep_slab_kernel(SagaDev d, LamParams* lamp, int tail,
+                                                                       int n_parts) {
+  __shared__ double part[kSlabGroups][kSlabElems];
+  const SweepParams q = load_sweep_params(d, lamp, tail);
+  const int K = d.K;
+  const int F = kSlabElems / K;              // K <= 16
+  const int E = F * K;
+  const int64_t KP = (int64_t)K * d.p;
+  const int e = threadIdx.x % kSlabElems, g = threadIdx.x / kSlabElems;
+  const int64_t elem = (int64_t)blockIdx.x * E + e;
+  double acc = 0.0;
+  if (e < E && elem < KP) {
+    const double* sp = d.slab + elem;
+    int bidx = g;
+    for (; bidx + 3 * kSlabGroups < n_parts; bidx += 4 * kSlabGroups) {   // 4 loads in flight
+      const double a0 = sp[(int64_t)bidx * KP], a1 = sp[(int64_t)(bidx + kSlabGroups) * KP];
+      const double a2 = sp[(int64_t)(bidx + 2 * kSlabGroups) * KP];
+      const double a3 = sp[(int64_t)(bidx + 3 * kSlabGroups) * KP];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; bidx < n_parts; bidx += kSlabGroups) acc += sp[(int64_t)bidx * KP];
+  }
+  part[g][e] = acc;
+  __syncthreads();
+  if (threadIdx.x < F) {
+    const int64_t j = (int64_t)blockIdx.x * F + threadIdx.x;
+    if (j < d.p) {
+      double dj[16];
       for (int k = 0; k < K; ++k) {
-        const double v = r_m * wj[k] - gls * gj[k] - gamma * dj[k];
-        wj[k] = v;
-        nrm += v * v;
+        const int ee = threadIdx.x * K + k;
+        double t = 0.0;
+        for (int gg = 0; gg < kSlabGroups; ++gg) t += part[gg][ee];
+        dj[k] = t;
       }
-      nrm = sqrt(nrm);
-      const double factor = beta * gamma * ls_m / nrm;
-      if (factor < 1.0) {
-        for (int k = 0; k < K; ++k) wj[k] *= 1.0 - factor;
-      } else {
-        for (int k = 0; k < K; ++k) wj[k] = 0.0;
-      }
-      for (int k = 0; k < K; ++k) {
-        gj[k] += dj[k] / n_d;
-        dj[k] = 0.0;
-      }
-    } else {
-      const double tau = beta * gamma * ls_m;
-      for (int k = 0; k < K; ++k) {
-        const double dk = dj[k];
-        double v = r_m * wj[k] - gls * gj[k] - gamma * dk;
-        if (penalty == SGDNET_ELASTICNET) v = soft_threshold(v, tau);
-        wj[k] = v;
-        if (dk != 0.0) {
-          gj[k] += dk / n_d;
-          dj[k] = 0.0;
-        }
-      }
+      sweep_feature(d, q, j, dj);
     }
   }
   if (blockIdx.x == 0 && d.fit_intercept) {
-    // d0 = sum of the gather kernel's per-block partials, fixed order
-    __shared__ double red[kBlock / 64];
-    for (int k = 0; k < K; ++k) {
-      double acc = 0.0;
-      for (int i = threadIdx.x; i < n_parts; i += kBlock) acc += d.d0_part[(int64_t)i * K + k];
-      acc = wave_sum(acc);
-      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int wv = 0; wv < kBlock / 64; ++wv) tot += red[wv];
-        const double dk = tot / n_d;
-        const double gbk = d.gb[k] + dk;
-        d.gb[k] = gbk;
-        d.b[k] -= gamma * (gbk * 0.01 * m_d + dk);
-      }
-      __syncthreads();
-    }
+    __syncthreads();
+    sweep_intercept<kBlock>(d, q, n_parts);
   }
 }
 
@@ -594,7 +662,10 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     return e ? atoi(e) : 256;
   }();
   const bool fits = table <= 80 * 1024;
-  g.lds = fits && force != 2 && (force == 1 || m >= 8192);
+  // worthwhile once the batch's non-zeros outnumber the table ~48x: below that the fixed
+  // cost of writing and re-reading one table per workgroup exceeds the atomics it saves
+  const bool pays = (double)m * (double)d.avg_nnz >= 48.0 * (double)d.K * (double)d.p;
+  g.lds = d.slab != nullptr && fits && force != 2 && (force == 1 || pays);
   if (g.lds) {
     int dpb = (m + target_grid - 1) / target_grid;
     const int per_round = kLdsBlock / kGroup;
@@ -611,6 +682,15 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
 }
 
 int batch_gather_blocks(const SagaDev& d, int m) { return plan_gather(d, m).grid; }
+
+// Doubles of slab storage the LDS-privatised gather needs for batches of m draws (0: the
+// global-atomic form is used).
+int64_t batch_gather_slab_doubles(const SagaDev& d, int m) {
+  SagaDev probe = d;
+  probe.slab = reinterpret_cast<double*>(1);
+  const GatherPlan g = plan_gather(probe, m);
+  return g.lds ? (int64_t)g.grid * d.K * d.p : 0;
+}
 
 // ev0/ev1 (optional): dispatch start/stop timestamps of exactly this kernel
 // (hipExtLaunchKernelGGL), used by the benchmark's per-kernel timing.
@@ -660,9 +740,17 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
 
 int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0,
                        hipEvent_t ev1) {
-  const int grid = (int)((d.p + kBlock - 1) / kBlock);
-  hipExtLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0, ev1,
-                        0, d, lam, tail, batch_gather_blocks(d, m));
+  const GatherPlan g = plan_gather(d, m);
+  if (g.lds) {
+    const int F = kSlabElems / d.K;
+    const int grid = (int)((d.p + F - 1) / F);
+    hipExtLaunchKernelGGL(saga_batch_sweep_slab_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
+                          ev1, 0, d, lam, tail, g.grid);
+  } else {
+    const int grid = (int)((d.p + kBlock - 1) / kBlock);
+    hipExtLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0, ev1,
+                          0, d, lam, tail, g.grid);
+  }
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

@@ -58,6 +58,7 @@ struct sgdnet_solver {
   bool w_prev_valid = false;
   int64_t d0_parts_cap = 0;     // blocks the d0_part buffer can hold
   double last_change = 0.0, last_size = 0.0;
+  int64_t slab_cap = 0;         // doubles the slab buffer can hold
 };
 
 namespace {
@@ -115,6 +116,15 @@ void drop_graph(sgdnet_solver* s) {
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   if (batch > draws) batch = draws;
+  const int64_t slab_need = batch_gather_slab_doubles(s->d, (int)batch);
+  if (slab_need > s->slab_cap) {
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    if (s->d.slab) SGD_HIP_TRY(hipFree(s->d.slab));
+    s->d.slab = nullptr;
+    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d.slab), sizeof(double) * (size_t)slab_need));
+    s->slab_cap = slab_need;
+    drop_graph(s);
+  }
   const int64_t blocks = batch_gather_blocks(s->d, (int)batch);
   if (blocks > s->d0_parts_cap) {
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
@@ -441,6 +451,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
   } while (0)
   if (s->sparse) {
     s->nnz = pb->rowptr[n];
+    d.avg_nnz = (float)((double)s->nnz / (double)n);
     int64_t* ptr;
     int32_t* idx;
     double* val;
@@ -499,6 +510,7 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
   if (s->d.d0_part) (void)hipFree(s->d.d0_part);
+  if (s->d.slab) (void)hipFree(s->d.slab);
   if (s->stream_dev) (void)hipFree(s->stream_dev);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
@@ -820,7 +832,7 @@ int sgdnet_solver_last_change(const sgdnet_solver* s, double* max_change, double
 int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq) {
   if (!(max_sample_sqnorm > 0.0) || !(max_feature_mean_sq > 0.0)) return 64;
   const double b = 2.0 * max_sample_sqnorm / max_feature_mean_sq;
-  if (!(b < 65536.0)) return 65536;
+  if (!(b < 131072.0)) return 131072;
   return b < 64.0 ? 64 : (int64_t)b;
 }
 
