@@ -13,8 +13,8 @@ all-reduce of the packed state deltas (sgdnet_amd/parallel.py), so the total
 work is fixed as N grows ("strong" scaling).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel
-(saga_batch_gather_kernel) by the algorithmic bytes of SURVEY.md 8d divided by
-its HIP-event-measured average launch duration; `cpu_baseline` times the CPU
+(the batched gather kernel) by the algorithmic bytes of SURVEY.md 8d divided by
+its average dispatch duration (HIP events bound to every launch); `cpu_baseline` times the CPU
 oracle (single-threaded restatement of the reference loop) on a bounded sample.
 """
 import argparse
@@ -64,13 +64,22 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the SAGA backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
     dist = None
+    # SGDNET_BENCH_BACKEND=gloo (+ SGDNET_BENCH_ONE_GPU=1) rehearses the multi-rank control flow
+    # on a single GPU; measured runs use nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("SGDNET_BENCH_BACKEND", "nccl")
+    if os.environ.get("SGDNET_BENCH_ONE_GPU") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     n, p, density, family, K, seed = WORKLOADS[args.workload]
     lo, hi = shard_bounds(n, world, rank)
@@ -85,7 +94,7 @@ def main():
     a_l2, b_l1 = (1.0 - mix) * lam, mix * lam
     row_sq = np.add.reduceat(prob["val"] ** 2, prob["ptr"][:-1])
     stats = torch.tensor([float(row_sq.max()), float(prob["y"].sum())], dtype=torch.float64,
-                         device="cuda")
+                         device=red_dev)
     if world > 1:
         mx = stats[:1].clone()
         sm = stats[1:].clone()
@@ -99,7 +108,7 @@ def main():
 
     # staleness window: the library's default rule, 2 * L_max / diag(X'X/n) clamped to 65536
     col_sq = np.bincount(prob["idx"], weights=prob["val"] ** 2, minlength=p)
-    cs = torch.tensor(col_sq, dtype=torch.float64, device="cuda")
+    cs = torch.tensor(col_sq, dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
     batch = args.batch if args.batch > 0 else sa.auto_batch(max_sq, float(cs.max()) / n)
@@ -113,7 +122,8 @@ def main():
     S.set_penalty("elasticnet", gamma, a_l2, b_l1)
     S.set("intercept", b0)
     S.upload_stream(stream)
-    shard = HipShard(S, batch=batch, draws_per_epoch=n_local, device=torch.device("cuda", local_rank))
+    shard = HipShard(S, batch=batch, draws_per_epoch=n_local, device=torch.device("cuda", local_rank),
+                     stage_on_host=(backend != "nccl"))
     job = ShardedSaga(shard, world)
 
     def fence():
@@ -131,7 +141,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
@@ -141,7 +151,7 @@ def main():
     alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, stream[off:off + n_local], K)
     gather_s = prof["gather_ms"] * 1e-3
     achieved = alg_bytes_epoch / gather_s / 1e9
-    alg_all = torch.tensor([alg_bytes_epoch], dtype=torch.float64, device="cuda")
+    alg_all = torch.tensor([alg_bytes_epoch], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(alg_all, op=dist.ReduceOp.SUM)
     job_gbps = float(alg_all[0]) / (elapsed / args.steps) / 1e9
@@ -169,7 +179,7 @@ def main():
             "gen_s": round(t_gen, 2),
         },
         "roofline": {
-            "bound": "hbm", "kernel": "saga_batch_gather_kernel",
+            "bound": "hbm", "kernel": prof["gather_kernel"],
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
             "launches": prof["gather_launches"],

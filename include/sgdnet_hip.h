@@ -205,6 +205,10 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
                                 int64_t draws_per_epoch, double* gather_ms, int* gather_launches,
                                 double* sweep_ms, int* sweep_launches);
 
+/* Which gather kernel a batch of `batch` draws uses: 0 = saga_batch_gather_kernel (global
+ * atomics), 1 = saga_batch_gather_lds_kernel (LDS-privatised scatter). */
+int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch);
+
 /* 2 * sum_i Loss_i (src/utils.h:304-329) over the resident samples. */
 int sgdnet_solver_deviance(sgdnet_solver* s, double* out);
 

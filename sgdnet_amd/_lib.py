@@ -20,6 +20,7 @@ EXPORTS = [
     "sgdnet_solver_profile_epoch", "sgdnet_solver_deviance", "sgdnet_solver_snapshot",
     "sgdnet_solver_export_delta", "sgdnet_solver_apply_merged", "sgdnet_solver_delta_len",
     "sgdnet_solver_convergence", "sgdnet_solver_last_change", "sgdnet_auto_batch",
+    "sgdnet_solver_gather_form",
 ]
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
@@ -113,6 +114,7 @@ def load():
     L.sgdnet_solver_delta_len.argtypes = [C.c_void_p]
     L.sgdnet_solver_convergence.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int)]
     L.sgdnet_solver_last_change.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.sgdnet_solver_gather_form.argtypes = [C.c_void_p, C.c_int64]
     L.sgdnet_auto_batch.argtypes = [C.c_double, C.c_double]
     L.sgdnet_auto_batch.restype = C.c_int64
     L.sgdnet_fit_sparse.argtypes = [C.POINTER(Csc), C.POINTER(C.c_double), C.c_int,

@@ -778,6 +778,11 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   return SGDNET_OK;
 }
 
+int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch) {
+  if (!s || batch < 1) return 0;
+  return batch_gather_slab_doubles(s->d, (int)batch) > 0 ? 1 : 0;
+}
+
 int sgdnet_solver_deviance(sgdnet_solver* s, double* out) {
   if (!s || !out) return SGDNET_EINVAL;
   SGD_HIP_TRY(hipSetDevice(s->device));

@@ -25,13 +25,15 @@ buffer), not compute.
 class HipShard:
     """Adapter: SagaSolver (libsgdnet_hip.so) + a torch device buffer for the all-reduce."""
 
-    def __init__(self, solver, *, batch, draws_per_epoch, device):
+    def __init__(self, solver, *, batch, draws_per_epoch, device, stage_on_host=False):
         import torch
 
         self.solver = solver
         self.batch = batch
         self.draws = draws_per_epoch
         self.buf = torch.zeros(solver.delta_len(), dtype=torch.float64, device=device)
+        # functional rehearsals with a CPU-only backend (gloo) reduce a host copy
+        self.host = torch.zeros_like(self.buf, device="cpu") if stage_on_host else None
         self.offset = 0
 
     def snapshot(self):
@@ -44,13 +46,18 @@ class HipShard:
 
     def export_delta(self):
         self.solver.export_delta(self.buf.data_ptr())   # synchronises the solver's stream
+        if self.host is not None:
+            self.host.copy_(self.buf)
+            return self.host
         return self.buf
 
     def apply_merged(self, buf, w_weight):
         import torch
 
+        if self.host is not None:
+            self.buf.copy_(buf)
         torch.cuda.synchronize()                        # all-reduce ran on torch's stream
-        self.solver.apply_merged(buf.data_ptr(), w_weight)
+        self.solver.apply_merged(self.buf.data_ptr(), w_weight)
 
 
 class ShardedSaga:

@@ -149,8 +149,11 @@ class SagaSolver:
         ng, nw = C.c_int(0), C.c_int(0)
         check(self._L.sgdnet_solver_profile_epoch(self._h, batch, stream_offset, draws, C.byref(g),
                                                   C.byref(ng), C.byref(w), C.byref(nw)))
+        form = self._L.sgdnet_solver_gather_form(self._h, min(batch, draws))
         return dict(gather_ms=g.value, gather_launches=ng.value, sweep_ms=w.value,
-                    sweep_launches=nw.value)
+                    sweep_launches=nw.value,
+                    gather_kernel=("saga_batch_gather_lds_kernel" if form == 1
+                                   else "saga_batch_gather_kernel"))
 
     def deviance(self):
         out = C.c_double(0)

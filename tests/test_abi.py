@@ -61,3 +61,13 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "sgdnet_oracle" not in text, f
+
+
+def test_auto_batch_rule():
+    import sgdnet_amd as sa
+    # 2 * L_max / diag(X'X/n), clamped to [64, 131072]
+    assert sa.auto_batch(50.0, 0.001) == 100000
+    assert sa.auto_batch(50.0, 0.01) == 10000
+    assert sa.auto_batch(50.0, 1e-9) == 131072
+    assert sa.auto_batch(1.0, 1.0) == 64
+    assert sa.auto_batch(0.0, 0.0) == 64

@@ -339,3 +339,20 @@ def test_full_size_invariants(sa, workload):
     assert relerr(S2.get("w"), w1) < 1e-9
     S.close()
     S2.close()
+
+
+@pytest.mark.parametrize("family,K,penalty", [("binomial", 1, "elasticnet"), ("multinomial", 3, "elasticnet"),
+                                              ("mgaussian", 2, "grouplasso"), ("multinomial", 10, "ridge")])
+def test_lds_privatised_gather_matches_batched_oracle(sa, oracle, family, K, penalty):
+    # batch * mean nnz >= 48 * K * p: the LDS-privatised gather + slab sweep are selected
+    n, p, batch = 30000, 40, 15000
+    x, y = make_problem(family, K, n, p, 0.15, seed=16)
+    (ep, rc, st), (ep2, conv, got) = run_both(
+        sa, oracle, x, y, family=family, K=K, penalty=penalty, gamma=0.002, alpha=1e-3,
+        beta=0.0 if penalty == "ridge" else 2e-3, epochs=2, mode="batched", batch=batch)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K)
+    assert S._L.sgdnet_solver_gather_form(S._h, batch) == 1
+    assert S._L.sgdnet_solver_gather_form(S._h, 64) == 0
+    S.close()
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_BATCHED, k
