@@ -81,6 +81,12 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
+    verbose = os.environ.get("SGDNET_BENCH_VERBOSE") == "1"
+
+    def note(msg):
+        if verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
     n, p, density, family, K, seed = WORKLOADS[args.workload]
     lo, hi = shard_bounds(n, world, rank)
     n_local = hi - lo
@@ -88,6 +94,7 @@ def main():
     prob = D.make_sparse_glm(n, p, density, family=family, n_classes=K, seed=seed, lo=lo, hi=hi)
     X = D.as_scipy(prob)
     t_gen = time.time() - t_gen
+    note(f"generated shard [{lo}, {hi}) in {t_gen:.1f}s")
 
     # fit settings: alpha = 0.5, lambda = 1/n, intercept, no standardisation
     mix, lam = 0.5, 1.0 / n
@@ -113,6 +120,7 @@ def main():
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
     batch = args.batch if args.batch > 0 else sa.auto_batch(max_sq, float(cs.max()) / n)
     batch = min(batch, n_local)
+    note(f"gamma={gamma:.5g} batch={batch}")
     epochs_total = args.warmup + args.steps + 1                 # +1: the event-profiled epoch
     # sample order: R's Mersenne-Twister, set.seed(config id [+ rank])
     stream = sa.RRng(seed + rank).stream(n_local, n_local * epochs_total)
@@ -132,9 +140,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note("solver resident, stream uploaded")
     for _ in range(args.warmup):
         job.epoch()
     fence()
+    note("warmup done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.epoch()
@@ -145,6 +155,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
 
+    note(f"timed region done: {elapsed:.4f}s")
     # dominant kernel, HIP events around every launch of one more epoch (same stream)
     off = shard.offset
     prof = S.profile_epoch(batch=batch, stream_offset=off, draws_per_epoch=n_local)
@@ -189,6 +200,7 @@ def main():
         },
     }
 
+    note("profiled epoch done")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import pyoracle as po   # the checker/baseline leg only
         st = po.new_state(K, p, n_local)

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -40,6 +41,12 @@ struct sgdnet_solver {
   hipStream_t st = nullptr;
   LamParams lam{};
   LamParams* lam_dev = nullptr;
+  // pinned staging ring for the asynchronous upload of `lam`: the host copy keeps changing
+  // (stream_base, batch_seq) while earlier uploads may still be in flight
+  static constexpr int kLamSlots = 8;
+  LamParams* lam_stage = nullptr;
+  hipEvent_t lam_ev[kLamSlots] = {};
+  int lam_slot = 0;
   // owned device buffers
   std::vector<void*> owned;
   double* ref = nullptr;        // snapshot for the multi-GPU merge
@@ -87,7 +94,13 @@ int dev_upload(sgdnet_solver* s, T** out, const T* host, size_t count) {
 }
 
 int push_lam(sgdnet_solver* s) {
-  SGD_HIP_TRY(hipMemcpyAsync(s->lam_dev, &s->lam, sizeof(LamParams), hipMemcpyHostToDevice, s->st));
+  const int slot = s->lam_slot;
+  s->lam_slot = (slot + 1) % sgdnet_solver::kLamSlots;
+  SGD_HIP_TRY(hipEventSynchronize(s->lam_ev[slot]));   // the slot's previous upload has completed
+  s->lam_stage[slot] = s->lam;
+  SGD_HIP_TRY(hipMemcpyAsync(s->lam_dev, &s->lam_stage[slot], sizeof(LamParams), hipMemcpyHostToDevice,
+                             s->st));
+  SGD_HIP_TRY(hipEventRecord(s->lam_ev[slot], s->st));
   return SGDNET_OK;
 }
 
@@ -116,7 +129,11 @@ void drop_graph(sgdnet_solver* s) {
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   if (batch > draws) batch = draws;
-  const int64_t slab_need = batch_gather_slab_doubles(s->d, (int)batch);
+  // scratch must cover the full batches AND the tail batch, whose launch geometry (and even
+  // its gather form) can differ
+  const int64_t tail_m = draws - (draws / batch) * batch;
+  int64_t slab_need = batch_gather_slab_doubles(s->d, (int)batch);
+  if (tail_m > 0) slab_need = std::max(slab_need, batch_gather_slab_doubles(s->d, (int)tail_m));
   if (slab_need > s->slab_cap) {
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     if (s->d.slab) SGD_HIP_TRY(hipFree(s->d.slab));
@@ -125,7 +142,8 @@ int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
     s->slab_cap = slab_need;
     drop_graph(s);
   }
-  const int64_t blocks = batch_gather_blocks(s->d, (int)batch);
+  int64_t blocks = batch_gather_blocks(s->d, (int)batch);
+  if (tail_m > 0) blocks = std::max<int64_t>(blocks, batch_gather_blocks(s->d, (int)tail_m));
   if (blocks > s->d0_parts_cap) {
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     if (s->d.d0_part) SGD_HIP_TRY(hipFree(s->d.d0_part));
@@ -160,6 +178,13 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
     const int64_t t0 = (int64_t)k * batch;
     const int64_t m = (draws - t0 < batch) ? draws - t0 : batch;
     const int tail = (m != batch) ? 1 : 0;
+    // the launch geometry must fit the scratch sized by set_batch_shape (a mismatch would
+    // write past d0_part / slab on the device)
+    if (batch_gather_blocks(s->d, (int)m) > s->d0_parts_cap ||
+        batch_gather_slab_doubles(s->d, (int)m) > s->slab_cap) {
+      set_error("internal: gather geometry of a %lld-draw batch exceeds its scratch", (long long)m);
+      return SGDNET_EINVAL;
+    }
     if (ev) {
       // dispatch-level start/stop timestamps of each kernel (no host gaps inside the interval)
       hipEvent_t e[4];
@@ -490,6 +515,15 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
   TRY(dev_alloc(s, &s->out_dev, 4, true));
   TRY(dev_alloc(s, &s->lam_dev, 1, true));
 #undef TRY
+  e = hipHostMalloc(reinterpret_cast<void**>(&s->lam_stage), sizeof(LamParams) * sgdnet_solver::kLamSlots,
+                    hipHostMallocDefault);
+  for (int i = 0; e == hipSuccess && i < sgdnet_solver::kLamSlots; ++i)
+    e = hipEventCreateWithFlags(&s->lam_ev[i], hipEventDisableTiming);
+  if (e != hipSuccess) {
+    set_error("solver initialisation failed: %s", hipGetErrorString(e));
+    sgdnet_solver_destroy(s);
+    return SGDNET_EHIP;
+  }
   e = hipMemsetAsync(d.claim, 0xFF, sizeof(int) * n, s->st);  // -1: never a batch id
   if (e == hipSuccess) e = hipStreamSynchronize(s->st);
   if (e != hipSuccess) {
@@ -511,6 +545,9 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   if (s->LS_dev) (void)hipFree(s->LS_dev);
   if (s->d.d0_part) (void)hipFree(s->d.d0_part);
   if (s->d.slab) (void)hipFree(s->d.slab);
+  if (s->lam_stage) (void)hipHostFree(s->lam_stage);
+  for (hipEvent_t ev : s->lam_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (s->stream_dev) (void)hipFree(s->stream_dev);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;

@@ -356,3 +356,19 @@ def test_lds_privatised_gather_matches_batched_oracle(sa, oracle, family, K, pen
     S.close()
     for k in STATE:
         assert relerr(got[k], st[k]) < TOL_BATCHED, k
+
+
+def test_lds_full_batches_with_a_global_atomic_tail(sa, oracle):
+    # full batches take the LDS-privatised gather (256 workgroups), the short tail batch takes
+    # the global-atomic gather with many more, smaller workgroups: scratch sizing must cover both
+    n, p, batch = 25000, 400, 12000
+    x, y = make_problem("binomial", 1, n, p, 0.015, seed=18)
+    S = sa.SagaSolver(x, y, family="binomial", n_classes=1)
+    assert S._L.sgdnet_solver_gather_form(S._h, batch) == 1
+    assert S._L.sgdnet_solver_gather_form(S._h, n - 2 * batch) == 0
+    S.close()
+    (ep, rc, st), (ep2, conv, got) = run_both(
+        sa, oracle, x, y, family="binomial", K=1, penalty="elasticnet", gamma=0.01, alpha=1e-3,
+        beta=1e-3, epochs=3, mode="batched", batch=batch)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_BATCHED, k
