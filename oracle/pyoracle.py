@@ -153,7 +153,7 @@ def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True
         if batch and batch > 1:
             ep = L.orc_saga_sparse_batched(
                 C.byref(P), C.c_int64(batch), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
-                idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(val), _dp(y), Ky,
+                idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(val), _dp(c), _dp(y), Ky,
                 _dp(state["intercept"]), _dp(state["w"]), _dp(state["g_memory"]),
                 _dp(state["g_sum"]), _dp(state["g_sum_intercept"]), C.byref(draws),
                 C.byref(rc), _dp(losses))

@@ -533,6 +533,7 @@ unsigned orc_saga_dense(const orc_saga_params* P,
 /*   D_j   = sum_i x_ij * gc_i           (first occurrence of a sample only) */
 /*   w_j  <- r^m w_j - gamma*LS_m*G_j - gamma*D_j ; prox(beta*gamma*LS_m)    */
 /*   G_j  <- G_j + D_j/n                                                     */
+/* With implicit centring (standardize): lp -= c.w and D_j -= c_j sum_i gc_i. */
 /* with r = 1 - alpha*gamma, LS_m = sum_{k<m} r^k  (the reference's          */
 /* lag_scaling[m], saga-sparse.h:229-240, in closed form).                   */
 /* ------------------------------------------------------------------------ */
@@ -550,6 +551,7 @@ void orc_batch_factors(double alpha, double gamma, int64_t m, double* r_m, doubl
 
 unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
                                  const int64_t* ptr, const int32_t* idx, const double* val,
+                                 const double* c,
                                  const double* y, int Ky,
                                  double* intercept, double* w,
                                  double* M, double* G, double* gb,
@@ -567,6 +569,8 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
   double* lp = (double*)calloc((size_t)K, sizeof(double));
   double* w_prev = (double*)malloc(sizeof(double) * (size_t)(K * p));
   int64_t* seen = (int64_t*)calloc((size_t)n, sizeof(int64_t)); /* batch stamp + 1 */
+  double* wc = (double*)calloc((size_t)K, sizeof(double));
+  const int centred = P->standardize && c != NULL;
   int64_t stamp = 0;
   unsigned it_outer = 0;
   int converged = 0;
@@ -581,11 +585,16 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
       double r_m, ls_m;
       orc_batch_factors(P->alpha, gamma, m, &r_m, &ls_m);
       ++stamp;
+      /* implicit centring (saga-sparse.h:276-277): (x_s - c).w = x_s.w - c.w, and c.w is one
+       * scalar per class for the whole batch because w is a snapshot */
+      if (centred) w_dot_center(K, p, w, c, wc);
       for (i = 0; i < m; ++i) {
         uint32_t s = next_draw(draws, (uint32_t)n);
         if (seen[s] == stamp) continue;       /* repeat within the batch: gc == 0 */
         seen[s] = stamp;
         lp_sparse_plain(K, ptr, idx, val, s, w, intercept, lp);
+        if (centred)
+          for (k = 0; k < K; ++k) lp[k] -= wc[k];
         family_gradient(P->family, K, lp, y, Ky, s, g);
         for (k = 0; k < K; ++k) {
           double gck = g[k] - M[k + (int64_t)s * K];
@@ -599,6 +608,9 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
         double* wj = w + j * K;
         double* gj = G + j * K;
         double* dj = D + j * K;
+        /* AddWeighted's dense term (saga-sparse.h:127-128): sum_i (x_ij - c_j) gc_i */
+        if (centred)
+          for (k = 0; k < K; ++k) dj[k] -= c[j] * d0[k];
         for (k = 0; k < K; ++k) wj[k] = r_m * wj[k] - gamma * ls_m * gj[k] - gamma * dj[k];
         if (P->penalty == ORC_ELASTICNET) {
           for (k = 0; k < K; ++k) wj[k] = soft_threshold(wj[k], beta * gamma * ls_m);
@@ -628,14 +640,14 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
     }
 
     if (P->debug && losses)
-      losses[it_outer] = total_loss_sparse(P, ptr, idx, val, NULL, y, Ky, w, intercept, 1);
+      losses[it_outer] = total_loss_sparse(P, ptr, idx, val, c, y, Ky, w, intercept, 1);
 
     converged = convergence_check(w, w_prev, K * p, P->tol);
     ++it_outer;
   } while (!converged && it_outer < P->max_iter);
 
   *return_code = (it_outer == P->max_iter) ? 1u : 0u;
-  free(D); free(d0); free(g); free(lp); free(w_prev); free(seen);
+  free(D); free(d0); free(g); free(lp); free(w_prev); free(seen); free(wc);
   return it_outer;
 }
 
@@ -1027,7 +1039,8 @@ static int fit_common(const orc_xmat* X,            /* feature-major, preprocess
     P.gamma = step_size(norm_max, alpha[li], ctl->fit_intercept, family_L_scaling(family), n);
     if (X->sparse) {
       if (ctl->batch > 1)
-        epochs = orc_saga_sparse_batched(&P, ctl->batch, sptr, sidx, sval, yt, Ky, intercept, w,
+        epochs = orc_saga_sparse_batched(&P, ctl->batch, sptr, sidx, sval, x_center_scaled, yt, Ky,
+                                         intercept, w,
                                          M, G, gb, draws, &rc, losses);
       else
         epochs = orc_saga_sparse(&P, sptr, sidx, sval, x_center_scaled, yt, Ky, intercept, w,

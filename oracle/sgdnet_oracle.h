@@ -91,9 +91,10 @@ unsigned orc_saga_dense(const orc_saga_params* P,
  * the CPU (DESIGN.md "Batched mode").  Not a reference function: it is the
  * reference iteration (saga-sparse.h:258-337) applied to `batch` consecutive
  * draws against one snapshot of (w, intercept); batch == 1 is mathematically
- * the reference iteration in unscaled coordinates.  standardize unsupported. */
+ * the reference iteration in unscaled coordinates. */
 unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
                                  const int64_t* ptr, const int32_t* idx, const double* val,
+                                 const double* x_center_scaled,
                                  const double* y, int Ky,
                                  double* intercept, double* w,
                                  double* g_memory, double* g_sum, double* g_sum_intercept,

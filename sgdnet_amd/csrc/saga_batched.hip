@@ -55,6 +55,26 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
                          __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Implicit centring of sparse x (standardize = TRUE; reference saga-sparse.h:127-128,
+// 276-277 does it with dense O(p) work per iteration).  Against a snapshot of w it folds into
+// two per-batch scalars per class: lp -= c.w and D_j -= c_j * sum_i gc_i.  c.w lives in two
+// sets of 16 accumulation slots: the sweep of batch B adds its blocks' partial sums of
+// c_j * w_new into set (B+1)&1 (zeroed by gather B), gather B+1 reads that set.
+constexpr int kCwSlots = 16;
+
+__device__ __forceinline__ double cw_sum(const SagaDev& d, int batch_id, int k) {
+  const double* set = d.cw + (size_t)(batch_id & 1) * kCwSlots * d.K;
+  double t = 0.0;
+#pragma unroll
+  for (int i = 0; i < kCwSlots; ++i) t += set[i * d.K + k];
+  return t;
+}
+
+__device__ __forceinline__ void cw_clear_next(const SagaDev& d, int batch_id) {
+  if (blockIdx.x == 0 && (int)threadIdx.x < kCwSlots * d.K)
+    d.cw[(size_t)((batch_id + 1) & 1) * kCwSlots * d.K + threadIdx.x] = 0.0;
+}
+
 }  // namespace
 
 // --------------------------------------------------------------------------
@@ -113,7 +133,8 @@ __device__ __forceinline__ void scatter_add(double* p, double v) {
 
 template <int KMAX, bool kLds>
 __device__ __forceinline__ void saga_draw(const SagaDev& d, const uint32_t s, const int gl,
-                                          const int batch_id, double* Dt, double (&gc)[KMAX]) {
+                                          const int batch_id, const double (&bk)[KMAX], double* Dt,
+                                          double (&gc)[KMAX]) {
   const int K = KMAX == 1 ? 1 : d.K;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;
@@ -161,7 +182,7 @@ __device__ __forceinline__ void saga_draw(const SagaDev& d, const uint32_t s, co
 
   double lp[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) lp[k] = group_sum(acc[k]) + ((k < K) ? d.b[k] : 0.0);
+  for (int k = 0; k < KMAX; ++k) lp[k] = group_sum(acc[k]) + bk[k];
 
   int first;
   if (KMAX == 1) {
@@ -267,11 +288,15 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
   const int i = (blockIdx.x * kBlock + threadIdx.x) / kGroup;
   const int64_t t0 = lamp->stream_base + t0_in_epoch;
   const int batch_id = lamp->batch_seq + batch_id_offset;
-  double gc[KMAX];
+  double gc[KMAX], bk[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;
-  if (i < m) saga_draw<KMAX, false>(d, d.stream[t0 + i], gl, batch_id, d.D, gc);
-  if (d.fit_intercept) store_d0_partial<KMAX, kBlock>(d, K, gc);
+  for (int k = 0; k < KMAX; ++k) {
+    gc[k] = 0.0;
+    bk[k] = k < K ? d.b[k] - (d.standardize ? cw_sum(d, batch_id, k) : 0.0) : 0.0;
+  }
+  if (d.standardize) cw_clear_next(d, batch_id);
+  if (i < m) saga_draw<KMAX, false>(d, d.stream[t0 + i], gl, batch_id, bk, d.D, gc);
+  if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kBlock>(d, K, gc);
 }
 
 // --------------------------------------------------------------------------
@@ -285,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
 template <int U>
 __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint32_t* sp, const int i,
                                                     const int hi, const int step, const int gl,
-                                                    double* Dl) {
+                                                    const double b0, double* Dl) {
   const int cap = d.rec_cap;
   uint32_t s[U];
   bool valid[U];
@@ -324,7 +349,6 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
       acc[u] += a;
     }
   }
-  const double b0 = d.b[0];
   double g0[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -384,18 +408,22 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   const int lo = blockIdx.x * draws_per_block;
   const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
 
-  double gct[KMAX];
+  double gct[KMAX], bk[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) gct[k] = 0.0;
+  for (int k = 0; k < KMAX; ++k) {
+    gct[k] = 0.0;
+    bk[k] = k < K ? d.b[k] - (d.standardize ? cw_sum(d, batch_id, k) : 0.0) : 0.0;
+  }
+  if (d.standardize) cw_clear_next(d, batch_id);
   constexpr int kGroups = kLdsBlock / kGroup;
   if (KMAX == 1) {
     constexpr int U = 4;
     for (int i = lo + group; i < hi; i += kGroups * U)
-      gct[0] += saga_draws_k1_lds<U>(d, d.stream + t0, i, hi, kGroups, gl, Dl);
+      gct[0] += saga_draws_k1_lds<U>(d, d.stream + t0, i, hi, kGroups, gl, bk[0], Dl);
   } else {
     for (int i = lo + group; i < hi; i += kGroups) {
       double gc[KMAX];
-      saga_draw<KMAX, true>(d, d.stream[t0 + i], gl, batch_id, Dl, gc);
+      saga_draw<KMAX, true>(d, d.stream[t0 + i], gl, batch_id, bk, Dl, gc);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) gct[k] += gc[k];
     }
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   // cap the flush at the ~1.3 TB/s atomic rate); the sweep sums the slabs in a fixed order
   double* slab = d.slab + (int64_t)blockIdx.x * KP;
   for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
-  if (d.fit_intercept) store_d0_partial<KMAX, kLdsBlock>(d, K, gct);
+  if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kLdsBlock>(d, K, gct);
 }
 
 // --------------------------------------------------------------------------
@@ -430,9 +458,9 @@ __device__ __forceinline__ SweepParams load_sweep_params(const SagaDev& d, const
   return q;
 }
 
-// dj: the K scatter sums of feature j (any address space)
+// dj: the K scatter sums of feature j (registers); wout receives the updated coefficients
 __device__ __forceinline__ void sweep_feature(const SagaDev& d, const SweepParams& q, int64_t j,
-                                              const double* dj) {
+                                              const double* dj, double* wout) {
   const int K = d.K;
   double* wj = d.w + j * K;
   double* gj = d.G + j * K;
@@ -441,17 +469,16 @@ __device__ __forceinline__ void sweep_feature(const SagaDev& d, const SweepParam
     double nrm = 0.0;
     for (int k = 0; k < K; ++k) {
       const double v = q.r_m * wj[k] - gls * gj[k] - q.gamma * dj[k];
-      wj[k] = v;
+      wout[k] = v;
       nrm += v * v;
     }
     nrm = sqrt(nrm);
     const double factor = q.beta * q.gamma * q.ls_m / nrm;
-    if (factor < 1.0) {
-      for (int k = 0; k < K; ++k) wj[k] *= 1.0 - factor;
-    } else {
-      for (int k = 0; k < K; ++k) wj[k] = 0.0;
+    for (int k = 0; k < K; ++k) {
+      wout[k] = factor < 1.0 ? wout[k] * (1.0 - factor) : 0.0;
+      wj[k] = wout[k];
+      gj[k] += dj[k] / q.n_d;
     }
-    for (int k = 0; k < K; ++k) gj[k] += dj[k] / q.n_d;
   } else {
     const double tau = q.beta * q.gamma * q.ls_m;
     for (int k = 0; k < K; ++k) {
@@ -459,15 +486,16 @@ __device__ __forceinline__ void sweep_feature(const SagaDev& d, const SweepParam
       double v = q.r_m * wj[k] - gls * gj[k] - q.gamma * dk;
       if (q.penalty == SGDNET_ELASTICNET) v = soft_threshold(v, tau);
       wj[k] = v;
+      wout[k] = v;
       if (dk != 0.0) gj[k] += dk / q.n_d;
     }
   }
 }
 
-// intercept: gb += d0/n ; b -= gamma (0.01 m gb + d0/n), d0 = sum of the gather kernel's
-// per-block partials in a fixed order.  Executed by one whole block.
+// d0[k] = sum of the gather kernel's per-block partials, in a fixed order, for every thread of
+// the block (result in sh_d0).  Called by whole blocks.
 template <int kThreads>
-__device__ __forceinline__ void sweep_intercept(const SagaDev& d, const SweepParams& q, int n_parts) {
+__device__ __forceinline__ void block_d0(const SagaDev& d, int n_parts, double* sh_d0) {
   __shared__ double red[kThreads / 64];
   const int K = d.K;
   for (int k = 0; k < K; ++k) {
@@ -479,26 +507,65 @@ __device__ __forceinline__ void sweep_intercept(const SagaDev& d, const SweepPar
     if (threadIdx.x == 0) {
       double tot = 0.0;
       for (int wv = 0; wv < kThreads / 64; ++wv) tot += red[wv];
-      const double dk = tot / q.n_d;
-      const double gbk = d.gb[k] + dk;
-      d.gb[k] = gbk;
-      d.b[k] -= q.gamma * (gbk * 0.01 * q.m_d + dk);
+      sh_d0[k] = tot;
     }
     __syncthreads();
   }
 }
 
+// intercept: gb += d0/n ; b -= gamma (0.01 m gb + d0/n)   (saga-sparse.h:300-304)
+__device__ __forceinline__ void sweep_intercept(const SagaDev& d, const SweepParams& q, const double* sh_d0) {
+  if ((int)threadIdx.x < d.K) {
+    const int k = threadIdx.x;
+    const double dk = sh_d0[k] / q.n_d;
+    const double gbk = d.gb[k] + dk;
+    d.gb[k] = gbk;
+    d.b[k] -= q.gamma * (gbk * 0.01 * q.m_d + dk);
+  }
+}
+
+// adds this block's sum of c_j * w_new_kj into the next batch's c.w slots
+template <int kThreads>
+__device__ __forceinline__ void cw_accumulate(const SagaDev& d, int batch_id, const double* cwp) {
+  __shared__ double red[kThreads / 64][16];
+  const int K = d.K;
+  for (int k = 0; k < K; ++k) {
+    const double t = wave_sum(cwp[k]);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = t;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < K) {
+    double tot = 0.0;
+    for (int wv = 0; wv < kThreads / 64; ++wv) tot += red[wv][threadIdx.x];
+    double* set = d.cw + (size_t)((batch_id + 1) & 1) * kCwSlots * K;
+    if (tot != 0.0) atomic_add_f64(set + (blockIdx.x % kCwSlots) * K + threadIdx.x, tot);
+  }
+}
+
 // D accumulated by global atomics (saga_batch_gather_kernel): one thread per feature.
 __global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
-                                                                  int n_parts) {
+                                                                  int n_parts, int batch_id_offset) {
+  __shared__ double sh_d0[16];
   const SweepParams q = load_sweep_params(d, lamp, tail);
+  const int K = d.K;
+  const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
+  if (need_d0) block_d0<kBlock>(d, n_parts, sh_d0);
+  double cwp[16];
+  for (int k = 0; k < K; ++k) cwp[k] = 0.0;
   const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (j < d.p) {
-    double* dj = d.D + j * d.K;
-    sweep_feature(d, q, j, dj);
-    for (int k = 0; k < d.K; ++k) dj[k] = 0.0;
+    double* dg = d.D + j * K;
+    double dj[16], wn[16];
+    const double cj = d.standardize ? d.c[j] : 0.0;
+    for (int k = 0; k < K; ++k) {
+      dj[k] = dg[k] - (d.standardize ? cj * sh_d0[k] : 0.0);
+      dg[k] = 0.0;
+    }
+    sweep_feature(d, q, j, dj, wn);
+    for (int k = 0; k < K; ++k) cwp[k] = cj * wn[k];
   }
-  if (blockIdx.x == 0 && d.fit_intercept) sweep_intercept<kBlock>(d, q, n_parts);
+  if (d.standardize) cw_accumulate<kBlock>(d, lamp->batch_seq + batch_id_offset, cwp);
+  if (blockIdx.x == 0 && d.fit_intercept) sweep_intercept(d, q, sh_d0);
 }
 
 // D held as per-workgroup slabs (saga_batch_gather_lds_kernel): a block owns F = 32/K
@@ -508,10 +575,13 @@ constexpr int kSlabElems = 32;
 constexpr int kSlabGroups = kBlock / kSlabElems;
 
 __global__ __launch_bounds__(kBlock) void saga_batch_sweep_slab_kernel(SagaDev d, LamParams* lamp, int tail,
-                                                                       int n_parts) {
+                                                                       int n_parts, int batch_id_offset) {
   __shared__ double part[kSlabGroups][kSlabElems];
+  __shared__ double sh_d0[16];
   const SweepParams q = load_sweep_params(d, lamp, tail);
   const int K = d.K;
+  const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
+  if (need_d0) block_d0<kBlock>(d, n_parts, sh_d0);
   const int F = kSlabElems / K;              // K <= 16
   const int E = F * K;
   const int64_t KP = (int64_t)K * d.p;
@@ -531,22 +601,46 @@ __global__ __launch_bounds__(kBlock) void saga_batch_sweep_slab_kernel(SagaDev d
   }
   part[g][e] = acc;
   __syncthreads();
-  if (threadIdx.x < F) {
+  double cwp[16];
+  for (int k = 0; k < K; ++k) cwp[k] = 0.0;
+  if ((int)threadIdx.x < F) {
     const int64_t j = (int64_t)blockIdx.x * F + threadIdx.x;
     if (j < d.p) {
-      double dj[16];
+      double dj[16], wn[16];
+      const double cj = d.standardize ? d.c[j] : 0.0;
       for (int k = 0; k < K; ++k) {
         const int ee = threadIdx.x * K + k;
         double t = 0.0;
         for (int gg = 0; gg < kSlabGroups; ++gg) t += part[gg][ee];
-        dj[k] = t;
+        dj[k] = t - (d.standardize ? cj * sh_d0[k] : 0.0);
       }
-      sweep_feature(d, q, j, dj);
+      sweep_feature(d, q, j, dj, wn);
+      for (int k = 0; k < K; ++k) cwp[k] = cj * wn[k];
     }
   }
-  if (blockIdx.x == 0 && d.fit_intercept) {
+  if (d.standardize) cw_accumulate<kBlock>(d, lamp->batch_seq + batch_id_offset, cwp);
+  if (blockIdx.x == 0 && d.fit_intercept) sweep_intercept(d, q, sh_d0);
+}
+
+// c.w of the current w into the slot set batch `batch_id` will read; clears the other set.
+__global__ __launch_bounds__(kBlock) void saga_cw_init_kernel(SagaDev d, const LamParams* lamp) {
+  __shared__ double red[kBlock / 64];
+  const int K = d.K;
+  const int batch_id = lamp->batch_seq;
+  for (int i = threadIdx.x; i < 2 * kCwSlots * K; i += kBlock) d.cw[i] = 0.0;
+  __syncthreads();
+  for (int k = 0; k < K; ++k) {
+    double acc = 0.0;
+    for (int64_t j = threadIdx.x; j < d.p; j += kBlock) acc += d.c[j] * d.w[k + j * K];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    sweep_intercept<kBlock>(d, q, n_parts);
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int wv = 0; wv < kBlock / 64; ++wv) tot += red[wv];
+      d.cw[(size_t)(batch_id & 1) * kCwSlots * K + k] = tot;
+    }
+    __syncthreads();
   }
 }
 
@@ -738,18 +832,24 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
   return SGDNET_OK;
 }
 
-int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0,
-                       hipEvent_t ev1) {
+int launch_cw_init(const SagaDev& d, const LamParams* lam, hipStream_t st) {
+  hipLaunchKernelGGL(saga_cw_init_kernel, dim3(1), dim3(kBlock), 0, st, d, lam);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, int batch_id_offset,
+                       hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const GatherPlan g = plan_gather(d, m);
   if (g.lds) {
     const int F = kSlabElems / d.K;
     const int grid = (int)((d.p + F - 1) / F);
     hipExtLaunchKernelGGL(saga_batch_sweep_slab_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
-                          ev1, 0, d, lam, tail, g.grid);
+                          ev1, 0, d, lam, tail, g.grid, batch_id_offset);
   } else {
     const int grid = (int)((d.p + kBlock - 1) / kBlock);
     hipExtLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0, ev1,
-                          0, d, lam, tail, g.grid);
+                          0, d, lam, tail, g.grid, batch_id_offset);
   }
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;

@@ -191,13 +191,13 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
       for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
       int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st, e[0], e[1]);
       if (rc) return rc;
-      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, s->st, e[2], e[3]);
+      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, k, s->st, e[2], e[3]);
       if (rc) return rc;
       for (auto x : e) ev->push_back(x);
     } else {
       int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
       if (rc) return rc;
-      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, s->st);
+      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, k, s->st);
       if (rc) return rc;
     }
   }
@@ -229,10 +229,6 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
 int check_batched_ok(const sgdnet_solver* s) {
   if (!s->sparse) {
     set_error("batched mode is implemented for sparse x only; dense x runs in exact mode");
-    return SGDNET_EUNSUPPORTED;
-  }
-  if (s->d.standardize) {
-    set_error("batched mode does not implement implicit centring (sparse standardize=TRUE)");
     return SGDNET_EUNSUPPORTED;
   }
   if (s->d.K > batched_max_classes()) {
@@ -486,7 +482,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
     d.ptr = ptr;
     d.idx = idx;
     d.val = val;
-    if (!pb->standardize) TRY(build_records(s, pb));   // batched mode needs no centring
+    TRY(build_records(s, pb));
   } else {
     double* xd;
     TRY(dev_upload(s, &xd, pb->x_dense, n * p));
@@ -511,6 +507,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
   TRY(dev_alloc(s, &d.lag, p, true));
   TRY(dev_alloc(s, &d.D, K * p, true));
   TRY(dev_alloc(s, &d.claim, n, false));
+  TRY(dev_alloc(s, &d.cw, 2 * 16 * K, true));
   TRY(dev_alloc(s, &s->ref, 2 * K * p + 2 * K, true));
   TRY(dev_alloc(s, &s->out_dev, 4, true));
   TRY(dev_alloc(s, &s->lam_dev, 1, true));
@@ -705,6 +702,10 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     s->lam.stream_base = stream_offset;
     rc = push_lam(s);
     if (rc) return rc;
+    if (s->d.standardize) {
+      rc = launch_cw_init(s->d, s->lam_dev, s->st);
+      if (rc) return rc;
+    }
     // ConvergenceCheck{w, tol}: w_prev starts as the warm-start w (saga-sparse.h:251)
     SGD_HIP_TRY(hipMemcpyAsync(s->d.w_prev, s->d.w, wbytes, hipMemcpyDeviceToDevice, s->st));
     rc = ensure_graph(s, batch, draws_per_epoch);
@@ -754,6 +755,10 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   s->lam.stream_base = stream_offset;
   rc = push_lam(s);
   if (rc) return rc;
+  if (s->d.standardize) {
+    rc = launch_cw_init(s->d, s->lam_dev, s->st);
+    if (rc) return rc;
+  }
   rc = ensure_graph(s, batch, draws_per_epoch);
   if (rc) return rc;
   const int nb = n_batches(batch, draws_per_epoch);
@@ -791,6 +796,10 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   s->lam.stream_base = stream_offset;
   rc = push_lam(s);
   if (rc) return rc;
+  if (s->d.standardize) {
+    rc = launch_cw_init(s->d, s->lam_dev, s->st);
+    if (rc) return rc;
+  }
   std::vector<hipEvent_t> ev;
   rc = enqueue_epoch_kernels(s, batch, draws_per_epoch, &ev);
   if (rc) return rc;

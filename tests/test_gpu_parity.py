@@ -372,3 +372,36 @@ def test_lds_full_batches_with_a_global_atomic_tail(sa, oracle):
         beta=1e-3, epochs=3, mode="batched", batch=batch)
     for k in STATE:
         assert relerr(got[k], st[k]) < TOL_BATCHED, k
+
+
+@pytest.mark.parametrize("family,K,penalty,batch,n,p", [
+    ("binomial", 1, "elasticnet", 64, 2500, 120), ("binomial", 1, "elasticnet", 15000, 30000, 40),
+    ("multinomial", 3, "elasticnet", 500, 2500, 120), ("mgaussian", 2, "grouplasso", 15000, 30000, 40),
+    ("gaussian", 1, "ridge", 2, 1500, 50)])
+def test_batched_implicit_centring_matches_batched_oracle(sa, oracle, family, K, penalty, batch, n, p):
+    # sparse standardize=TRUE in batched mode: lp -= c.w and D_j -= c_j * sum(gc), O(z) per draw
+    x, y = make_problem(family, K, n, p, 0.1, seed=19)
+    c = np.random.default_rng(2).normal(0.05, 0.1, p)
+    (ep, rc, st), (ep2, conv, got) = run_both(
+        sa, oracle, x, y, family=family, K=K, penalty=penalty, gamma=0.003, alpha=1e-3,
+        beta=0.0 if penalty == "ridge" else 2e-3, epochs=3, mode="batched", batch=batch, c=c)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_BATCHED, k
+
+
+def test_fit_batched_standardized_sparse_reaches_the_dense_optimum(sa, oracle):
+    # the package default standardize=TRUE on sparse x, batched mode, against the oracle's DENSE
+    # fit (explicit centring): same optimum.  (The reference's own sparse standardize path only
+    # agrees with its dense path to ~1e-3, tests/testthat/test-sparse.R.)
+    rng = np.random.default_rng(3)
+    n, p = 4000, 60
+    X = sp.random(n, p, density=0.1, format="csc", random_state=3,
+                  data_rvs=lambda k: rng.normal(1.0, 1.0, k))
+    bt = rng.normal(size=p) * (rng.random(p) < 0.3)
+    y = (rng.random(n) < 1 / (1 + np.exp(-(X @ bt - 1)))).astype(float)
+    kw = dict(family="binomial", alpha=0.5, lambda_=[0.002], thresh=1e-11, maxit=5000, standardize=True)
+    dense = oracle.fit(X.toarray(), y, seed=1, **kw)
+    fit = sa.sgdnet(X, y, seed=1, mode="batched", batch=64, **kw)
+    assert fit.return_codes[0] == 0
+    assert relerr(fit.beta[:, 0], dense["beta"][0, :, 0]) < 1e-8
+    assert abs(fit.a0[0] - dense["a0"][0, 0]) < 1e-8
