@@ -181,6 +181,14 @@ int sgdnet_solver_set_penalty(sgdnet_solver* s, int penalty, double gamma, doubl
 int sgdnet_solver_get_state(sgdnet_solver* s, int which, double* host);
 int sgdnet_solver_set_state(sgdnet_solver* s, int which, const double* host);
 
+/* Generate `count` sample indices floor(runif(0, n_samples)) ON THE DEVICE from the R-compatible
+ * Mersenne-Twister state `rng` (replaces any previous stream); `rng` is advanced exactly as
+ * sgdnet_rng_fill(rng, n_samples, out, count) would advance it. */
+int sgdnet_solver_generate_stream(sgdnet_solver* s, sgdnet_rng* rng, int64_t count);
+
+/* Copy `count` entries of the resident stream, starting at `offset`, back to the host. */
+int sgdnet_solver_get_stream(sgdnet_solver* s, uint32_t* host, int64_t offset, int64_t count);
+
 /* Make `count` sample indices resident on the device (replaces any previous stream). */
 int sgdnet_solver_upload_stream(sgdnet_solver* s, const uint32_t* host, int64_t count);
 

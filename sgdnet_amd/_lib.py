@@ -16,6 +16,7 @@ EXPORTS = [
     "sgdnet_rng_seed", "sgdnet_rng_unif", "sgdnet_rng_fill",
     "sgdnet_solver_create", "sgdnet_solver_destroy", "sgdnet_solver_set_penalty",
     "sgdnet_solver_get_state", "sgdnet_solver_set_state", "sgdnet_solver_upload_stream",
+    "sgdnet_solver_generate_stream", "sgdnet_solver_get_stream",
     "sgdnet_solver_run", "sgdnet_solver_enqueue_epochs", "sgdnet_solver_sync",
     "sgdnet_solver_profile_epoch", "sgdnet_solver_deviance", "sgdnet_solver_snapshot",
     "sgdnet_solver_export_delta", "sgdnet_solver_apply_merged", "sgdnet_solver_delta_len",
@@ -99,6 +100,8 @@ def load():
     L.sgdnet_solver_get_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.sgdnet_solver_set_state.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double)]
     L.sgdnet_solver_upload_stream.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64]
+    L.sgdnet_solver_generate_stream.argtypes = [C.c_void_p, C.POINTER(Rng), C.c_int64]
+    L.sgdnet_solver_get_stream.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.c_int64, C.c_int64]
     L.sgdnet_solver_run.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_uint,
                                     C.c_double, C.POINTER(C.c_uint), C.POINTER(C.c_int),
                                     C.POINTER(C.c_double)]

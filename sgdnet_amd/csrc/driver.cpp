@@ -195,6 +195,7 @@ struct DrawSource {
   sgdnet_rng rng;
   int64_t pos = 0;
   explicit DrawSource(const sgdnet_control* c) : ctl(c) { sgdnet_rng_seed(&rng, c->seed); }
+  bool internal() const { return !ctl->sample_stream && !ctl->unif; }
   int fill(uint32_t n, uint32_t* out, int64_t count) {
     if (ctl->sample_stream) {
       if (pos + count > ctl->sample_stream_len) {
@@ -422,9 +423,15 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // one epoch per launch: exactly the draws the reference would consume are taken
     // from the source (R's RNG state after the call matches, SURVEY.md 8b "RNG")
     while (epochs < ctl->max_iter && !converged) {
-      rc = draws.fill((uint32_t)n, chunk.data(), n);
-      if (rc) return rc;
-      rc = sgdnet_solver_upload_stream(S, chunk.data(), n);
+      if (draws.internal()) {
+        // built-in generator: the epoch's draws are produced in HBM (r_rng_device.hip)
+        rc = sgdnet_solver_generate_stream(S, &draws.rng, n);
+        draws.pos += n;
+      } else {
+        rc = draws.fill((uint32_t)n, chunk.data(), n);
+        if (rc) return rc;
+        rc = sgdnet_solver_upload_stream(S, chunk.data(), n);
+      }
       if (rc) return rc;
       unsigned ran = 0;
       rc = sgdnet_solver_run(S, mode, batch, 0, n, 1, ctl->tol, &ran, &converged,

@@ -56,6 +56,8 @@ struct sgdnet_solver {
   int* out_dev = nullptr;
   uint32_t* stream_dev = nullptr;
   int64_t stream_len = 0;
+  int64_t stream_cap = 0;
+  uint32_t* rng_dev = nullptr;  // 625 words: the device copy of a sgdnet_rng
   int64_t nnz = 0;
   bool penalty_set = false;
   // cached epoch graph
@@ -546,6 +548,7 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   for (hipEvent_t ev : s->lam_ev)
     if (ev) (void)hipEventDestroy(ev);
   if (s->stream_dev) (void)hipFree(s->stream_dev);
+  if (s->rng_dev) (void)hipFree(s->rng_dev);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
 }
@@ -604,23 +607,60 @@ int sgdnet_solver_set_state(sgdnet_solver* s, int which, const double* host) {
   return SGDNET_OK;
 }
 
+static int reserve_stream(sgdnet_solver* s, int64_t count) {
+  if (count > s->stream_cap || !s->stream_dev) {
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    if (s->stream_dev) SGD_HIP_TRY(hipFree(s->stream_dev));
+    s->stream_dev = nullptr;
+    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->stream_dev), sizeof(uint32_t) * (size_t)count));
+    s->stream_cap = count;
+    drop_graph(s);  // captured kernels hold the old pointer
+  }
+  s->stream_len = count;
+  s->d.stream = s->stream_dev;
+  return SGDNET_OK;
+}
+
 int sgdnet_solver_upload_stream(sgdnet_solver* s, const uint32_t* host, int64_t count) {
   if (!s || !host || count <= 0) {
     set_error("sgdnet_solver_upload_stream: invalid argument");
     return SGDNET_EINVAL;
   }
   SGD_HIP_TRY(hipSetDevice(s->device));
-  if (count > s->stream_len || !s->stream_dev) {
-    SGD_HIP_TRY(hipStreamSynchronize(s->st));
-    if (s->stream_dev) SGD_HIP_TRY(hipFree(s->stream_dev));
-    s->stream_dev = nullptr;
-    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->stream_dev), sizeof(uint32_t) * (size_t)count));
-    drop_graph(s);  // captured kernels hold the old pointer
-  }
-  s->stream_len = count;
-  s->d.stream = s->stream_dev;
+  int rc = reserve_stream(s, count);
+  if (rc) return rc;
   SGD_HIP_TRY(hipMemcpyAsync(s->stream_dev, host, sizeof(uint32_t) * (size_t)count, hipMemcpyHostToDevice,
                              s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_get_stream(sgdnet_solver* s, uint32_t* host, int64_t offset, int64_t count) {
+  if (!s || !host || offset < 0 || count <= 0 || offset + count > s->stream_len) {
+    set_error("sgdnet_solver_get_stream: range outside the resident stream");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipMemcpyAsync(host, s->stream_dev + offset, sizeof(uint32_t) * (size_t)count,
+                             hipMemcpyDeviceToHost, s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_generate_stream(sgdnet_solver* s, sgdnet_rng* rng, int64_t count) {
+  if (!s || !rng || count <= 0) {
+    set_error("sgdnet_solver_generate_stream: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = reserve_stream(s, count);
+  if (rc) return rc;
+  if (!s->rng_dev) SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rng_dev), sizeof(sgdnet_rng)));
+  static_assert(sizeof(sgdnet_rng) == 625 * sizeof(uint32_t), "sgdnet_rng is mti + 624 words");
+  SGD_HIP_TRY(hipMemcpyAsync(s->rng_dev, rng, sizeof(sgdnet_rng), hipMemcpyHostToDevice, s->st));
+  rc = launch_rng_fill(s->rng_dev, (uint32_t)s->d.n, s->stream_dev, count, s->st);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipMemcpyAsync(rng, s->rng_dev, sizeof(sgdnet_rng), hipMemcpyDeviceToHost, s->st));
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   return SGDNET_OK;
 }

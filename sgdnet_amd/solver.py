@@ -123,6 +123,19 @@ class SagaSolver:
             self._h, s.ctypes.data_as(C.POINTER(C.c_uint32)), s.size))
         self.stream_len = s.size
 
+    def generate_stream(self, rrng, count):
+        """`count` draws floor(runif(0, n)) generated on the device from the RRng state
+        (advanced exactly as rrng.stream(n, count) would advance it)."""
+        check(self._L.sgdnet_solver_generate_stream(self._h, C.byref(rrng.state), count))
+        self.stream_len = count
+
+    def get_stream(self, offset=0, count=None):
+        count = self.stream_len - offset if count is None else count
+        out = np.empty(count, dtype=np.uint32)
+        check(self._L.sgdnet_solver_get_stream(self._h, out.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               offset, count))
+        return out
+
     def run(self, *, mode="exact", batch=0, stream_offset=0, draws_per_epoch=None, max_epochs=1,
             tol=0.0, losses=False):
         """Saga() for the current penalty; returns (epochs, converged[, losses])."""

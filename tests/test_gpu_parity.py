@@ -405,3 +405,23 @@ def test_fit_batched_standardized_sparse_reaches_the_dense_optimum(sa, oracle):
     assert fit.return_codes[0] == 0
     assert relerr(fit.beta[:, 0], dense["beta"][0, :, 0]) < 1e-8
     assert abs(fit.a0[0] - dense["a0"][0, 0]) < 1e-8
+
+
+@pytest.mark.parametrize("seed,n,count,burn", [(1, 150, 1000, 0), (4, 1_000_000, 3_000_000, 0),
+                                               (123, 4177, 624 * 3, 0), (7, 1000, 5000, 317),
+                                               (42, 65536, 100_000, 1000)])
+def test_device_mersenne_twister_equals_host(sa, oracle, seed, n, count, burn):
+    # r_rng_device.hip reproduces floor(R::runif(0, n)) draw for draw, from any position
+    # inside a 624-word block, and leaves the generator state where the host would
+    S = sa.SagaSolver(sp.csc_matrix(np.ones((1, n))), np.zeros((1, n)), family="gaussian", n_classes=1)
+    host, dev = sa.RRng(seed), sa.RRng(seed)
+    if burn:
+        host.stream(n, burn)
+        dev.stream(n, burn)
+    want = host.stream(n, count)
+    S.generate_stream(dev, count)
+    assert np.array_equal(S.get_stream(), want)
+    # continuation: both generators are in the same state
+    assert np.array_equal(dev.stream(n, 2000), host.stream(n, 2000))
+    assert np.array_equal(want[:5], oracle.Rng(seed).stream(n, burn + 5)[burn:])
+    S.close()
