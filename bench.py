@@ -71,9 +71,11 @@ def main():
     if os.environ.get("SGDNET_BENCH_ONE_GPU") == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_merge = world == 1 and os.environ.get("SGDNET_BENCH_FORCE_MERGE") == "1"
+    if world > 1 or force_merge:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -130,9 +132,12 @@ def main():
     S.set_penalty("elasticnet", gamma, a_l2, b_l1)
     S.set("intercept", b0)
     S.upload_stream(stream)
+    # device-ordered merge (no host sync inside an epoch) unless SGDNET_BENCH_FUSED=0
+    fused = ((world > 1 or force_merge) and backend == "nccl"
+             and os.environ.get("SGDNET_BENCH_FUSED", "1") == "1")
     shard = HipShard(S, batch=batch, draws_per_epoch=n_local, device=torch.device("cuda", local_rank),
-                     stage_on_host=(backend != "nccl"))
-    job = ShardedSaga(shard, world)
+                     stage_on_host=(backend != "nccl"), fused=fused)
+    job = ShardedSaga(shard, world, force_merge=force_merge)
 
     def fence():
         S.sync()
@@ -186,7 +191,8 @@ def main():
                         f"alpha={mix}, lambda=1/n, intercept, standardize=FALSE",
             "mode": "batched", "batch": batch, "samples_per_gpu": n_local,
             "sample_order": f"R MT19937 set.seed({seed}+rank), with replacement",
-            "merge": "none" if world == 1 else "per-epoch RCCL all-reduce, w averaged",
+            "merge": "none" if world == 1 else ("per-epoch RCCL all-reduce, w averaged"
+                                                 + (", stream-ordered" if fused else "")),
             "gen_s": round(t_gen, 2),
         },
         "roofline": {
@@ -230,7 +236,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     S.close()
-    if world > 1:
+    if world > 1 or force_merge:
         dist.destroy_process_group()
 
 

@@ -229,6 +229,13 @@ int sgdnet_solver_export_delta(sgdnet_solver* s, void* device_buf);
 int sgdnet_solver_apply_merged(sgdnet_solver* s, const void* device_buf, double w_weight);
 int64_t sgdnet_solver_delta_len(const sgdnet_solver* s);
 
+/* The solver's HIP stream (a hipStream_t), so that a caller can order its own device work
+ * -- e.g. the RCCL all-reduce of the merge buffer -- after the solver's kernels without host
+ * synchronisation.  export_delta_async / apply_merged_async only enqueue. */
+void* sgdnet_solver_stream(sgdnet_solver* s);
+int sgdnet_solver_export_delta_async(sgdnet_solver* s, void* device_buf);
+int sgdnet_solver_apply_merged_async(sgdnet_solver* s, const void* device_buf, double w_weight);
+
 /* ConvergenceCheck on the current w against the previous call's w (device-side). */
 int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged);
 

@@ -21,7 +21,8 @@ EXPORTS = [
     "sgdnet_solver_profile_epoch", "sgdnet_solver_deviance", "sgdnet_solver_snapshot",
     "sgdnet_solver_export_delta", "sgdnet_solver_apply_merged", "sgdnet_solver_delta_len",
     "sgdnet_solver_convergence", "sgdnet_solver_last_change", "sgdnet_auto_batch",
-    "sgdnet_solver_gather_form",
+    "sgdnet_solver_gather_form", "sgdnet_solver_stream", "sgdnet_solver_export_delta_async",
+    "sgdnet_solver_apply_merged_async",
 ]
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
@@ -115,6 +116,10 @@ def load():
     L.sgdnet_solver_export_delta.argtypes = [C.c_void_p, C.c_void_p]
     L.sgdnet_solver_apply_merged.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     L.sgdnet_solver_delta_len.argtypes = [C.c_void_p]
+    L.sgdnet_solver_stream.argtypes = [C.c_void_p]
+    L.sgdnet_solver_stream.restype = C.c_void_p
+    L.sgdnet_solver_export_delta_async.argtypes = [C.c_void_p, C.c_void_p]
+    L.sgdnet_solver_apply_merged_async.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     L.sgdnet_solver_convergence.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int)]
     L.sgdnet_solver_last_change.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sgdnet_solver_gather_form.argtypes = [C.c_void_p, C.c_int64]

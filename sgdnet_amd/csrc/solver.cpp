@@ -895,19 +895,29 @@ int sgdnet_solver_snapshot(sgdnet_solver* s) {
   return SGDNET_OK;
 }
 
-int sgdnet_solver_export_delta(sgdnet_solver* s, void* device_buf) {
+void* sgdnet_solver_stream(sgdnet_solver* s) { return s ? static_cast<void*>(s->st) : nullptr; }
+
+int sgdnet_solver_export_delta_async(sgdnet_solver* s, void* device_buf) {
   if (!s || !device_buf) return SGDNET_EINVAL;
   SGD_HIP_TRY(hipSetDevice(s->device));
-  int rc = launch_delta_export(s->d, s->ref, static_cast<double*>(device_buf), s->st);
+  return launch_delta_export(s->d, s->ref, static_cast<double*>(device_buf), s->st);
+}
+
+int sgdnet_solver_apply_merged_async(sgdnet_solver* s, const void* device_buf, double w_weight) {
+  if (!s || !device_buf) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  return launch_delta_apply(s->d, s->ref, static_cast<const double*>(device_buf), w_weight, s->st);
+}
+
+int sgdnet_solver_export_delta(sgdnet_solver* s, void* device_buf) {
+  int rc = sgdnet_solver_export_delta_async(s, device_buf);
   if (rc) return rc;
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   return SGDNET_OK;
 }
 
 int sgdnet_solver_apply_merged(sgdnet_solver* s, const void* device_buf, double w_weight) {
-  if (!s || !device_buf) return SGDNET_EINVAL;
-  SGD_HIP_TRY(hipSetDevice(s->device));
-  int rc = launch_delta_apply(s->d, s->ref, static_cast<const double*>(device_buf), w_weight, s->st);
+  int rc = sgdnet_solver_apply_merged_async(s, device_buf, w_weight);
   if (rc) return rc;
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   return SGDNET_OK;

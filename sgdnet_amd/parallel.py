@@ -23,9 +23,15 @@ buffer), not compute.
 
 
 class HipShard:
-    """Adapter: SagaSolver (libsgdnet_hip.so) + a torch device buffer for the all-reduce."""
+    """Adapter: SagaSolver (libsgdnet_hip.so) + a torch device buffer for the all-reduce.
 
-    def __init__(self, solver, *, batch, draws_per_epoch, device, stage_on_host=False):
+    fused=True wraps the solver's HIP stream as a torch ExternalStream and issues the
+    all-reduce from it: snapshot, local epoch, delta export, RCCL all-reduce and merge are then
+    ordered on the device with no host synchronisation inside an epoch (at 8 GPUs a local
+    epoch is ~0.4 ms, so three host syncs per epoch would cost a quarter of it).
+    """
+
+    def __init__(self, solver, *, batch, draws_per_epoch, device, stage_on_host=False, fused=False):
         import torch
 
         self.solver = solver
@@ -35,6 +41,10 @@ class HipShard:
         # functional rehearsals with a CPU-only backend (gloo) reduce a host copy
         self.host = torch.zeros_like(self.buf, device="cpu") if stage_on_host else None
         self.offset = 0
+        self.ext = None
+        if fused and not stage_on_host:
+            torch.cuda.synchronize()          # buf's zero fill ran on torch's stream
+            self.ext = torch.cuda.ExternalStream(solver.stream_handle(), device=device)
 
     def snapshot(self):
         self.solver.snapshot()
@@ -45,6 +55,9 @@ class HipShard:
         self.offset += self.draws
 
     def export_delta(self):
+        if self.ext is not None:
+            self.solver.export_delta_async(self.buf.data_ptr())
+            return self.buf
         self.solver.export_delta(self.buf.data_ptr())   # synchronises the solver's stream
         if self.host is not None:
             self.host.copy_(self.buf)
@@ -54,6 +67,9 @@ class HipShard:
     def apply_merged(self, buf, w_weight):
         import torch
 
+        if self.ext is not None:
+            self.solver.apply_merged_async(self.buf.data_ptr(), w_weight)
+            return
         if self.host is not None:
             self.buf.copy_(buf)
         torch.cuda.synchronize()                        # all-reduce ran on torch's stream
@@ -63,15 +79,16 @@ class HipShard:
 class ShardedSaga:
     """Per-epoch driver of the sharded job; identical on every rank."""
 
-    def __init__(self, shard, world_size, w_weight=None, group=None):
+    def __init__(self, shard, world_size, w_weight=None, group=None, force_merge=False):
         self.shard = shard
         self.world = world_size
         self.w_weight = (1.0 / world_size) if w_weight is None else w_weight
         self.group = group
+        self.force_merge = force_merge        # rehearse the merge path with a single rank
 
     def epoch(self):
         sh = self.shard
-        if self.world == 1:
+        if self.world == 1 and not self.force_merge:
             sh.local_epoch()
             return
         import torch.distributed as dist
@@ -79,7 +96,13 @@ class ShardedSaga:
         sh.snapshot()
         sh.local_epoch()
         buf = sh.export_delta()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        ext = getattr(sh, "ext", None)
+        if ext is not None:
+            import torch
+            with torch.cuda.stream(ext):      # the collective is ordered on the solver's stream
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         sh.apply_merged(buf, self.w_weight)
 
 

@@ -196,3 +196,13 @@ class SagaSolver:
 
     def apply_merged(self, device_ptr, w_weight):
         check(self._L.sgdnet_solver_apply_merged(self._h, C.c_void_p(device_ptr), w_weight))
+
+    def stream_handle(self):
+        """The solver's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        return int(self._L.sgdnet_solver_stream(self._h) or 0)
+
+    def export_delta_async(self, device_ptr):
+        check(self._L.sgdnet_solver_export_delta_async(self._h, C.c_void_p(device_ptr)))
+
+    def apply_merged_async(self, device_ptr, w_weight):
+        check(self._L.sgdnet_solver_apply_merged_async(self._h, C.c_void_p(device_ptr), w_weight))
