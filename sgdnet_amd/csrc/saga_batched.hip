@@ -83,12 +83,12 @@ __device__ __forceinline__ void cw_clear_next(const SagaDev& d, int batch_id) {
 // whatever the record size up to 128 B), so a draw should touch as few 64-B
 // lines as possible and need no pointer hop:
 //
-//   record s at rec + s*stride (stride = 64-B multiple sized for the 90th
-//   percentile row):  [f64 y][i32 nnz][i32 ovf][i32 idx[cap]] pad8 [f64 val[cap]]
+//   record s at rec + s*stride (stride = 128-B multiple sized for the 90th
+//   percentile row; requests are served in 128-B units):  [f64 y][i32 nnz][i32 ovf][i32 idx[cap]] pad8 [f64 val[cap]]
 //   rows longer than cap continue in 256-B overflow records:
 //                     [i32 next][i32 cnt][i32 idx[20]][f64 val[20]]
 //
-// At z = 10 a draw is 3 line requests (was: 2 row pointers + y + idx + val ~ 6).
+// At z = 10 a draw is one 256-B record = 2 requests (was: 2 row pointers + y + idx + val ~ 6).
 // --------------------------------------------------------------------------
 constexpr int kOvfStride = 256;
 constexpr int kOvfCap = 20;
