@@ -6,18 +6,20 @@ import sgdnet_amd as sa
 from sgdnet_amd import data as D
 wl = sys.argv[1] if len(sys.argv) > 1 else "C4"
 batches = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else [20000, 65536]
-n, p, dens, seed = {"C4": (10_000_000, 10_000, 0.001, 4), "C3": (1_000_000, 1_000, 0.01, 3),
-                    "C4s": (2_000_000, 10_000, 0.001, 4)}[wl]
-t = time.time(); pr = D.make_sparse_glm(n, p, dens, family="binomial", seed=seed); X = D.as_scipy(pr)
+n, p, dens, seed, family, K = {"C4": (10_000_000, 10_000, 0.001, 4, "binomial", 1),
+                               "C3": (1_000_000, 1_000, 0.01, 3, "binomial", 1),
+                               "C4s": (2_000_000, 10_000, 0.001, 4, "binomial", 1),
+                               "C5s": (2_000_000, 100_000, 0.0001, 5, "multinomial", 10)}[wl]
+t = time.time(); pr = D.make_sparse_glm(n, p, dens, family=family, n_classes=K, seed=seed); X = D.as_scipy(pr)
 print(f"{wl}: gen {time.time()-t:.1f}s nnz={X.nnz}", flush=True)
 epochs = 2 + 3 * len(batches) + 1
 stream = sa.RRng(seed).stream(n, n * 4)
 row_sq = np.add.reduceat(pr["val"] ** 2, pr["ptr"][:-1])
-gamma = D.step_size(row_sq.max(), 0.5 / n, True, "binomial", n)
-S = sa.SagaSolver(X, pr["y"], family="binomial", n_classes=1)
+gamma = D.step_size(row_sq.max(), 0.5 / n, True, family, n)
+S = sa.SagaSolver(X, pr["y"], family=family, n_classes=K)
 S.set_penalty("elasticnet", gamma, 0.5 / n, 0.5 / n)
 S.upload_stream(stream)
-ab = D.algorithmic_bytes(S.row_nnz, stream[:n], 1)
+ab = D.algorithmic_bytes(S.row_nnz, stream[:n], K)
 for batch in batches:
     S.enqueue_epochs(1, batch=batch); S.sync()
     t = time.time(); S.enqueue_epochs(3, batch=batch, stream_offset=n); S.sync(); dt = (time.time() - t) / 3

@@ -11,7 +11,11 @@
 
 #include <cmath>
 
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "common.hpp"
@@ -19,6 +23,19 @@
 using namespace sgdnet;
 
 namespace {
+
+// SGDNET_TRACE=1: wall-clock of the driver's phases on stderr
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  PhaseTimer() : on(getenv("SGDNET_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[sgdnet] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 struct Features {
   bool sparse = false;
@@ -274,6 +291,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     set_error("no HIP device available: the SAGA backend has no CPU fallback");
     return SGDNET_ENODEVICE;
   }
+  PhaseTimer pt;
 
   std::vector<double> y(y_in, y_in + n * Ky);
   std::vector<double> yt((size_t)(n * Ky));
@@ -392,8 +410,10 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   pb.device = ctl->device;
 
   sgdnet_solver* S = nullptr;
+  pt.mark("response, path, step sizes");
   int rc = sgdnet_solver_create(&pb, &S);
   if (rc) return rc;
+  pt.mark("solver create (pack + H2D)");
   struct Guard {
     sgdnet_solver* s;
     ~Guard() { sgdnet_solver_destroy(s); }
@@ -489,6 +509,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       ao[k] = fit_intercept ? b[(size_t)k] * y_scale[(size_t)k] + y_center[(size_t)k] - xbb[(size_t)k]
                             : b[(size_t)k];
   }
+  pt.mark("lambda path (SAGA + deviance)");
   out->npasses = n_iter;
   out->draws_used = draws.pos;
   return SGDNET_OK;
@@ -555,6 +576,7 @@ int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols, const sg
         X.sval[(size_t)dst] = X.val[(size_t)q];
       }
   }
+  if (getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet] features: standardize + transpose done\n");
   return fit_common(X, y, y_cols, ctl, out);
 }
 
