@@ -57,7 +57,7 @@ struct SagaDev {
   unsigned* lag;
   // batched-mode scratch
   double* D;      // K x p scatter accumulator
-  double* d0_part;  // blocks x K  per-block partial sums of the intercept accumulator
+  double* d0_part;  // 2 x 256 x K  partial sums of the intercept accumulator (two parity sets)
   double* slab;     // blocks x K x p  per-workgroup copies of D (LDS-privatised gather) or nullptr
   double* cw;       // 2 x 16 x K  slots of c.w (implicit centring in batched mode)
   int* claim;     // n     first-occurrence claims (K > 1)
@@ -106,7 +106,7 @@ size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state);
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
                         int batch_id_offset, hipStream_t st, hipEvent_t ev0 = nullptr,
                         hipEvent_t ev1 = nullptr);
-int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, int batch_id_offset,
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, int m, int batch_id_offset,
                        hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int launch_cw_init(const SagaDev& d, const LamParams* lam, hipStream_t st);
 int batch_gather_blocks(const SagaDev& d, int m);

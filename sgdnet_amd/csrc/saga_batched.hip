@@ -62,6 +62,26 @@ __device__ __forceinline__ void atomic_max_bits(unsigned long long* p, double v)
 // c_j * w_new into set (B+1)&1 (zeroed by gather B), gather B+1 reads that set.
 constexpr int kCwSlots = 16;
 
+// Intercept accumulator d0[k] = sum_i gc_ik: two sets (batch parity) of kD0Slots slots.  A
+// gather with at most kD0Slots workgroups stores one partial per workgroup; a larger grid adds
+// atomically into slot (workgroup % kD0Slots) of a set the previous sweep left zeroed.  Either
+// way the sweep sums at most kD0Slots values per class (thousands of same-address atomics, or
+// thousands of partials summed by one block, would each cost tens of microseconds).
+constexpr int kD0Slots = 256;
+
+__device__ __forceinline__ double* d0_set(const SagaDev& d, int batch_id) {
+  return d.d0_part + (size_t)(batch_id & 1) * kD0Slots * d.K;
+}
+
+__device__ __forceinline__ void d0_publish(const SagaDev& d, int batch_id, int k, double tot) {
+  double* set = d0_set(d, batch_id);
+  if (gridDim.x <= (unsigned)kD0Slots)
+    set[(size_t)blockIdx.x * d.K + k] = tot;
+  else if (tot != 0.0)
+    __hip_atomic_fetch_add(set + (size_t)(blockIdx.x % kD0Slots) * d.K + k, tot, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ double cw_sum(const SagaDev& d, int batch_id, int k) {
   const double* set = d.cw + (size_t)(batch_id & 1) * kCwSlots * d.K;
   double t = 0.0;
@@ -254,7 +274,8 @@ __device__ __forceinline__ void saga_draw(const SagaDev& d, const uint32_t s, co
 // Intercept accumulator: one partial per block and class, summed by the sweep in a
 // fixed order (thousands of same-address atomics would serialise at ~12 ns each).
 template <int KMAX, int kThreads>
-__device__ __forceinline__ void store_d0_partial(const SagaDev& d, int K, const double (&gc)[KMAX]) {
+__device__ __forceinline__ void store_d0_partial(const SagaDev& d, int K, int batch_id,
+                                                 const double (&gc)[KMAX]) {
   __shared__ double part[kThreads / 64][KMAX];
   const int wave = threadIdx.x >> 6;
 #pragma unroll
@@ -269,7 +290,7 @@ __device__ __forceinline__ void store_d0_partial(const SagaDev& d, int K, const 
     double tot = 0.0;
 #pragma unroll
     for (int wv = 0; wv < kThreads / 64; ++wv) tot += part[wv][threadIdx.x];
-    d.d0_part[(int64_t)blockIdx.x * K + threadIdx.x] = tot;
+    d0_publish(d, batch_id, threadIdx.x, tot);
   }
 }
 
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
   }
   if (d.standardize) cw_clear_next(d, batch_id);
   if (i < m) saga_draw<KMAX, false>(d, d.stream[t0 + i], gl, batch_id, bk, d.D, gc);
-  if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kBlock>(d, K, gc);
+  if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kBlock>(d, K, batch_id, gc);
 }
 
 // --------------------------------------------------------------------------
@@ -434,7 +455,128 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   // cap the flush at the ~1.3 TB/s atomic rate); the sweep sums the slabs in a fixed order
   double* slab = d.slab + (int64_t)blockIdx.x * KP;
   for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
-  if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kLdsBlock>(d, K, gct);
+  if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kLdsBlock>(d, K, batch_id, gct);
+}
+
+// --------------------------------------------------------------------------
+// Class-lane form for 4 < K <= 16 (multinomial / mgaussian with many classes): inside a
+// 16-lane group lane l owns class l and the group walks the row's non-zeros together.  Every
+// access to the K-fastest arrays (w, D, g_memory) is then K contiguous doubles per group =
+// one or two 128-B requests, instead of K separate requests per non-zero, and x.w needs no
+// cross-lane reduction (only the softmax does).
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double group_max(double v) {
+  v = fmax(v, __shfl_xor(v, 8, kGroup));
+  v = fmax(v, __shfl_xor(v, 4, kGroup));
+  v = fmax(v, __shfl_xor(v, 2, kGroup));
+  v = fmax(v, __shfl_xor(v, 1, kGroup));
+  return v;
+}
+
+// every lane of the group visits every non-zero (uniform addresses: broadcast loads)
+template <class F>
+__device__ __forceinline__ void row_for_each_uniform(const SagaDev& d, const char* base, int nnz, int ovf,
+                                                     F f) {
+  const int cap = d.rec_cap;
+  const int cnt0 = nnz < cap ? nnz : cap;
+  const int* ridx = reinterpret_cast<const int*>(base + 16);
+  const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
+  for (int e = 0; e < cnt0; ++e) f((int64_t)ridx[e], rval[e]);
+  int rem = nnz - cnt0;
+  while (rem > 0) {
+    const char* ob = d.ovf + (size_t)ovf * kOvfStride;
+    const int next = reinterpret_cast<const int*>(ob)[0];
+    const int c = reinterpret_cast<const int*>(ob)[1];
+    const int* oi = reinterpret_cast<const int*>(ob + 8);
+    const double* ov = reinterpret_cast<const double*>(ob + 8 + 4 * kOvfCap);
+    for (int e = 0; e < c; ++e) f((int64_t)oi[e], ov[e]);
+    rem -= c;
+    ovf = next;
+  }
+}
+
+// returns the gradient change of this lane's class (0 on lanes >= K and on repeated draws)
+template <bool kLds>
+__device__ __forceinline__ double saga_draw_classlane(const SagaDev& d, const uint32_t s, const int gl,
+                                                      const int batch_id, const double bl, double* Dt) {
+  const int K = d.K;
+  const bool lane_on = gl < K;
+  const char* base = d.rec + (size_t)s * d.rec_stride;
+  int prev = batch_id;
+  if (gl == 0)
+    prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const double mold = lane_on ? d.M[gl + (int64_t)s * K] : 0.0;
+  const double y0 = *reinterpret_cast<const double*>(base);
+  const int nnz = *reinterpret_cast<const int*>(base + 8);
+  const int ovf = *reinterpret_cast<const int*>(base + 12);
+
+  double acc = 0.0;
+  row_for_each_uniform(d, base, nnz, ovf, [&](int64_t j, double v) {
+    if (lane_on) acc += v * d.w[j * K + gl];
+  });
+  const double lp = acc + bl;
+
+  double g;
+  if (d.family == SGDNET_MULTINOMIAL) {
+    const double mx = group_max(lane_on ? lp : -HUGE_VAL);
+    const double ssum = group_sum(lane_on ? exp(lp - mx) : 0.0);
+    const double lse = log(ssum) + mx;
+    g = exp(lp - lse);
+    if ((unsigned)gl == (unsigned)(y0 + 0.5)) g -= 1.0;
+  } else {
+    g = lp - (lane_on ? d.y[(int64_t)s * d.Ky + gl] : 0.0);   // mgaussian: Ky == K responses
+  }
+  const int first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
+  double gc = 0.0;
+  if (first && lane_on) {
+    gc = g - mold;
+    d.M[gl + (int64_t)s * K] = g;
+  }
+  if (first) {
+    row_for_each_uniform(d, base, nnz, ovf, [&](int64_t j, double v) {
+      if (lane_on && gc != 0.0) scatter_add<kLds>(Dt + j * K + gl, v * gc);
+    });
+  }
+  return gc;
+}
+
+template <bool kLds>
+__global__ __launch_bounds__(kLds ? 1024 : kBlock) void saga_batch_gather_cl_kernel(
+    SagaDev d, const LamParams* lamp, int64_t t0_in_epoch, int m, int batch_id_offset, int draws_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double Dl[];
+  __shared__ double d0s[16];
+  constexpr int kThreads = kLds ? 1024 : kBlock;
+  const int K = d.K;
+  const int64_t KP = (int64_t)K * d.p;
+  const int gl = threadIdx.x & (kGroup - 1);
+  const int group = threadIdx.x / kGroup;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  if (kLds)
+    for (int64_t i = threadIdx.x; i < KP; i += kThreads) Dl[i] = 0.0;
+  if (threadIdx.x < 16) d0s[threadIdx.x] = 0.0;
+  __syncthreads();
+  const double bl = gl < K ? d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0) : 0.0;
+  if (d.standardize) cw_clear_next(d, batch_id);
+
+  double gct = 0.0;
+  if (kLds) {
+    const int lo = blockIdx.x * draws_per_block;
+    const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
+    for (int i = lo + group; i < hi; i += kThreads / kGroup)
+      gct += saga_draw_classlane<true>(d, d.stream[t0 + i], gl, batch_id, bl, Dl);
+  } else {
+    const int i = blockIdx.x * (kThreads / kGroup) + group;
+    if (i < m) gct = saga_draw_classlane<false>(d, d.stream[t0 + i], gl, batch_id, bl, d.D);
+  }
+  if (gct != 0.0) __hip_atomic_fetch_add(&d0s[gl], gct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();
+  if (kLds) {
+    double* slab = d.slab + (int64_t)blockIdx.x * KP;
+    for (int64_t i = threadIdx.x; i < KP; i += kThreads) slab[i] = Dl[i];
+  }
+  if ((d.fit_intercept || d.standardize) && (int)threadIdx.x < K)
+    d0_publish(d, batch_id, threadIdx.x, d0s[threadIdx.x]);
 }
 
 // --------------------------------------------------------------------------
@@ -495,12 +637,13 @@ __device__ __forceinline__ void sweep_feature(const SagaDev& d, const SweepParam
 // d0[k] = sum of the gather kernel's per-block partials, in a fixed order, for every thread of
 // the block (result in sh_d0).  Called by whole blocks.
 template <int kThreads>
-__device__ __forceinline__ void block_d0(const SagaDev& d, int n_parts, double* sh_d0) {
+__device__ __forceinline__ void block_d0(const SagaDev& d, int n_parts, int batch_id, double* sh_d0) {
   __shared__ double red[kThreads / 64];
   const int K = d.K;
   for (int k = 0; k < K; ++k) {
     double acc = 0.0;
-    for (int i = threadIdx.x; i < n_parts; i += kThreads) acc += d.d0_part[(int64_t)i * K + k];
+    const double* set = d0_set(d, batch_id);
+    for (int i = threadIdx.x; i < n_parts; i += kThreads) acc += set[(int64_t)i * K + k];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -542,30 +685,53 @@ __device__ __forceinline__ void cw_accumulate(const SagaDev& d, int batch_id, co
   }
 }
 
-// D accumulated by global atomics (saga_batch_gather_kernel): one thread per feature.
+// D accumulated by global atomics (saga_batch_gather_kernel).  Ridge / ElasticNet act per
+// element: one thread per (class, feature) entry, fully coalesced over the K-fastest arrays.
+// GroupLasso needs the column norm: one thread per feature.
+template <bool kGrouped>
 __global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
                                                                   int n_parts, int batch_id_offset) {
   __shared__ double sh_d0[16];
   const SweepParams q = load_sweep_params(d, lamp, tail);
   const int K = d.K;
   const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
-  if (need_d0) block_d0<kBlock>(d, n_parts, sh_d0);
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  if (need_d0) block_d0<kBlock>(d, n_parts, batch_id, sh_d0);
   double cwp[16];
   for (int k = 0; k < K; ++k) cwp[k] = 0.0;
-  const int64_t j = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (j < d.p) {
-    double* dg = d.D + j * K;
-    double dj[16], wn[16];
-    const double cj = d.standardize ? d.c[j] : 0.0;
-    for (int k = 0; k < K; ++k) {
-      dj[k] = dg[k] - (d.standardize ? cj * sh_d0[k] : 0.0);
-      dg[k] = 0.0;
+  const int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (kGrouped) {
+    if (t < d.p) {
+      double* dg = d.D + t * K;
+      double dj[16], wn[16];
+      const double cj = d.standardize ? d.c[t] : 0.0;
+      for (int k = 0; k < K; ++k) {
+        dj[k] = dg[k] - (d.standardize ? cj * sh_d0[k] : 0.0);
+        dg[k] = 0.0;
+      }
+      sweep_feature(d, q, t, dj, wn);
+      for (int k = 0; k < K; ++k) cwp[k] = cj * wn[k];
     }
-    sweep_feature(d, q, j, dj, wn);
-    for (int k = 0; k < K; ++k) cwp[k] = cj * wn[k];
+  } else if (t < (int64_t)K * d.p) {
+    const int64_t j = t / K;
+    const int k = (int)(t - j * K);
+    const double cj = d.standardize ? d.c[j] : 0.0;
+    const double raw = d.D[t];
+    const double dk = raw - (d.standardize ? cj * sh_d0[k] : 0.0);
+    double v = q.r_m * d.w[t] - q.gamma * q.ls_m * d.G[t] - q.gamma * dk;
+    if (q.penalty == SGDNET_ELASTICNET) v = soft_threshold(v, q.beta * q.gamma * q.ls_m);
+    d.w[t] = v;
+    if (dk != 0.0) d.G[t] += dk / q.n_d;
+    if (raw != 0.0) d.D[t] = 0.0;
+    // every lane keeps its own class slot so that cw_accumulate's wave_sum stays per class
+    for (int kk = 0; kk < K; ++kk) cwp[kk] = kk == k ? cj * v : 0.0;
   }
-  if (d.standardize) cw_accumulate<kBlock>(d, lamp->batch_seq + batch_id_offset, cwp);
-  if (blockIdx.x == 0 && d.fit_intercept) sweep_intercept(d, q, sh_d0);
+  if (d.standardize) cw_accumulate<kBlock>(d, batch_id, cwp);
+  if (blockIdx.x == 0) {
+    if (d.fit_intercept) sweep_intercept(d, q, sh_d0);
+    double* nxt = d0_set(d, batch_id + 1);      // the next gather may add into it atomically
+    for (int i = threadIdx.x; i < kD0Slots * K; i += kBlock) nxt[i] = 0.0;
+  }
 }
 
 // D held as per-workgroup slabs (saga_batch_gather_lds_kernel): a block owns F = 32/K
@@ -581,7 +747,8 @@ __global__ __launch_bounds__(kBlock) void saga_batch_sweep_slab_kernel(SagaDev d
   const SweepParams q = load_sweep_params(d, lamp, tail);
   const int K = d.K;
   const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
-  if (need_d0) block_d0<kBlock>(d, n_parts, sh_d0);
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  if (need_d0) block_d0<kBlock>(d, n_parts, batch_id, sh_d0);
   const int F = kSlabElems / K;              // K <= 16
   const int E = F * K;
   const int64_t KP = (int64_t)K * d.p;
@@ -618,8 +785,12 @@ __global__ __launch_bounds__(kBlock) void saga_batch_sweep_slab_kernel(SagaDev d
       for (int k = 0; k < K; ++k) cwp[k] = cj * wn[k];
     }
   }
-  if (d.standardize) cw_accumulate<kBlock>(d, lamp->batch_seq + batch_id_offset, cwp);
-  if (blockIdx.x == 0 && d.fit_intercept) sweep_intercept(d, q, sh_d0);
+  if (d.standardize) cw_accumulate<kBlock>(d, batch_id, cwp);
+  if (blockIdx.x == 0) {
+    if (d.fit_intercept) sweep_intercept(d, q, sh_d0);
+    double* nxt = d0_set(d, batch_id + 1);      // the next gather may add into it atomically
+    for (int i = threadIdx.x; i < kD0Slots * K; i += kBlock) nxt[i] = 0.0;
+  }
 }
 
 // c.w of the current w into the slot set batch `batch_id` will read; clears the other set.
@@ -804,7 +975,7 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<4>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
-      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<16>),
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_cl_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
       attr_done = true;
     }
@@ -815,7 +986,7 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
       hipExtLaunchKernelGGL(saga_batch_gather_lds_kernel<4>, dim3(g.grid), dim3(kLdsBlock), g.lds_bytes, st,
                             ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
     else
-      hipExtLaunchKernelGGL(saga_batch_gather_lds_kernel<16>, dim3(g.grid), dim3(kLdsBlock), g.lds_bytes,
+      hipExtLaunchKernelGGL(saga_batch_gather_cl_kernel<true>, dim3(g.grid), dim3(kLdsBlock), g.lds_bytes,
                             st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
   } else {
     if (d.K == 1)
@@ -825,8 +996,8 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
       hipExtLaunchKernelGGL(saga_batch_gather_kernel<4>, dim3(g.grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
                             lam, t0_in_epoch, m, batch_id_offset);
     else
-      hipExtLaunchKernelGGL(saga_batch_gather_kernel<16>, dim3(g.grid), dim3(kBlock), 0, st, ev0, ev1, 0, d,
-                            lam, t0_in_epoch, m, batch_id_offset);
+      hipExtLaunchKernelGGL(saga_batch_gather_cl_kernel<false>, dim3(g.grid), dim3(kBlock), 0, st, ev0, ev1,
+                            0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
   }
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
@@ -838,18 +1009,23 @@ int launch_cw_init(const SagaDev& d, const LamParams* lam, hipStream_t st) {
   return SGDNET_OK;
 }
 
-int launch_batch_sweep(const SagaDev& d, LamParams* lam, int tail, int m, int batch_id_offset,
+int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, int m, int batch_id_offset,
                        hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   const GatherPlan g = plan_gather(d, m);
+  const int n_parts = g.grid < kD0Slots ? g.grid : kD0Slots;
   if (g.lds) {
     const int F = kSlabElems / d.K;
     const int grid = (int)((d.p + F - 1) / F);
     hipExtLaunchKernelGGL(saga_batch_sweep_slab_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
                           ev1, 0, d, lam, tail, g.grid, batch_id_offset);
-  } else {
+  } else if (penalty == SGDNET_GROUPLASSO) {
     const int grid = (int)((d.p + kBlock - 1) / kBlock);
-    hipExtLaunchKernelGGL(saga_batch_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0, ev1,
-                          0, d, lam, tail, g.grid, batch_id_offset);
+    hipExtLaunchKernelGGL(saga_batch_sweep_kernel<true>, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
+                          ev1, 0, d, lam, tail, n_parts, batch_id_offset);
+  } else {
+    const int grid = (int)(((int64_t)d.K * d.p + kBlock - 1) / kBlock);
+    hipExtLaunchKernelGGL(saga_batch_sweep_kernel<false>, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
+                          ev1, 0, d, lam, tail, n_parts, batch_id_offset);
   }
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;

@@ -66,7 +66,6 @@ struct sgdnet_solver {
   hipGraph_t graph = nullptr;
   int64_t g_batch = 0, g_draws = 0;
   bool w_prev_valid = false;
-  int64_t d0_parts_cap = 0;     // blocks the d0_part buffer can hold
   double last_change = 0.0, last_size = 0.0;
   int64_t slab_cap = 0;         // doubles the slab buffer can hold
 };
@@ -145,17 +144,6 @@ int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
     s->slab_cap = slab_need;
     drop_graph(s);
   }
-  int64_t blocks = batch_gather_blocks(s->d, (int)batch);
-  if (tail_m > 0) blocks = std::max<int64_t>(blocks, batch_gather_blocks(s->d, (int)tail_m));
-  if (blocks > s->d0_parts_cap) {
-    SGD_HIP_TRY(hipStreamSynchronize(s->st));
-    if (s->d.d0_part) SGD_HIP_TRY(hipFree(s->d.d0_part));
-    s->d.d0_part = nullptr;
-    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d.d0_part),
-                          sizeof(double) * (size_t)blocks * (size_t)s->d.K));
-    s->d0_parts_cap = blocks;
-    drop_graph(s);  // captured kernels hold the old pointer
-  }
   const int64_t full = draws / batch;
   const int64_t tail = draws - full * batch;
   s->lam.m_full = batch;
@@ -183,8 +171,7 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
     const int tail = (m != batch) ? 1 : 0;
     // the launch geometry must fit the scratch sized by set_batch_shape (a mismatch would
     // write past d0_part / slab on the device)
-    if (batch_gather_blocks(s->d, (int)m) > s->d0_parts_cap ||
-        batch_gather_slab_doubles(s->d, (int)m) > s->slab_cap) {
+    if (batch_gather_slab_doubles(s->d, (int)m) > s->slab_cap) {
       set_error("internal: gather geometry of a %lld-draw batch exceeds its scratch", (long long)m);
       return SGDNET_EINVAL;
     }
@@ -194,13 +181,13 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
       for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
       int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st, e[0], e[1]);
       if (rc) return rc;
-      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, k, s->st, e[2], e[3]);
+      rc = launch_batch_sweep(s->d, s->lam_dev, s->lam.penalty, tail, (int)m, k, s->st, e[2], e[3]);
       if (rc) return rc;
       for (auto x : e) ev->push_back(x);
     } else {
       int rc = launch_batch_gather(s->d, s->lam_dev, t0, (int)m, tail, k, s->st);
       if (rc) return rc;
-      rc = launch_batch_sweep(s->d, s->lam_dev, tail, (int)m, k, s->st);
+      rc = launch_batch_sweep(s->d, s->lam_dev, s->lam.penalty, tail, (int)m, k, s->st);
       if (rc) return rc;
     }
   }
@@ -513,6 +500,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
   TRY(dev_alloc(s, &d.lag, p, true));
   TRY(dev_alloc(s, &d.D, K * p, true));
   TRY(dev_alloc(s, &d.claim, n, false));
+  TRY(dev_alloc(s, &d.d0_part, 2 * 256 * K, true));   // two parity sets of 256 slots (saga_batched.hip)
   TRY(dev_alloc(s, &d.cw, 2 * 16 * K, true));
   TRY(dev_alloc(s, &s->ref, 2 * K * p + 2 * K, true));
   TRY(dev_alloc(s, &s->out_dev, 4, true));
@@ -546,7 +534,6 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   drop_graph(s);
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
-  if (s->d.d0_part) (void)hipFree(s->d.d0_part);
   if (s->d.slab) (void)hipFree(s->d.slab);
   if (s->lam_stage) (void)hipHostFree(s->lam_stage);
   for (hipEvent_t ev : s->lam_ev)
@@ -563,6 +550,7 @@ int sgdnet_solver_set_penalty(sgdnet_solver* s, int penalty, double gamma, doubl
     return SGDNET_EINVAL;
   }
   SGD_HIP_TRY(hipSetDevice(s->device));
+  if (penalty != s->lam.penalty) drop_graph(s);   // the captured sweep kernel depends on it
   s->lam.penalty = penalty;
   s->lam.gamma = gamma;
   s->lam.alpha = alpha;
