@@ -72,6 +72,9 @@ typedef struct sgdnet_csc {
  * src/saga-sparse.h:261). */
 typedef double (*sgdnet_unif_fn)(void* ctx);
 
+/* State of R's default generator (Mersenne-Twister): 625 words = mti + mt[624]. */
+typedef struct sgdnet_rng { uint32_t mti; uint32_t mt[624]; } sgdnet_rng;
+
 typedef struct sgdnet_control {
   /* ---- the control list of R/sgdnet.R:346-359, field for field ---- */
   int           debug;
@@ -96,6 +99,9 @@ typedef struct sgdnet_control {
   sgdnet_unif_fn  unif;               /* used when sample_stream == NULL and unif != NULL */
   void*           unif_ctx;
   uint32_t        seed;               /* else: built-in R-compatible Mersenne-Twister, set.seed(seed) */
+  struct sgdnet_rng* rng_state;       /* else-branch only: if non-NULL the generator starts from this
+                                         state (R's .Random.seed: mti + mt[624]) instead of `seed`
+                                         and the advanced state is written back */
 
   /* ---- backend extensions; zero-initialised == reference behaviour ---- */
   int           mode;                 /* SGDNET_MODE_* */
@@ -135,7 +141,6 @@ int sgdnet_fit_dense(const double* x, int64_t n_samples, int64_t n_features,
 /* Built-in R-compatible Mersenne-Twister (the generator behind R::runif at  */
 /* src/saga-sparse.h:261 under R's default RNGkind): 625 words = mti + mt[]. */
 /* ------------------------------------------------------------------------ */
-typedef struct sgdnet_rng { uint32_t mti; uint32_t mt[624]; } sgdnet_rng;
 void     sgdnet_rng_seed(sgdnet_rng* r, uint32_t seed);           /* set.seed(seed)        */
 double   sgdnet_rng_unif(sgdnet_rng* r);                          /* unif_rand()           */
 void     sgdnet_rng_fill(sgdnet_rng* r, uint32_t n_samples,       /* floor(runif(0, n))    */

@@ -38,6 +38,10 @@ class Csc(C.Structure):
                 ("values", C.POINTER(C.c_double))]
 
 
+class Rng(C.Structure):
+    _fields_ = [("mti", C.c_uint32), ("mt", C.c_uint32 * 624)]
+
+
 class Control(C.Structure):
     _fields_ = [("debug", C.c_int), ("elasticnet_mix", C.c_double), ("family", C.c_int),
                 ("intercept", C.c_int), ("is_sparse", C.c_int),
@@ -48,6 +52,7 @@ class Control(C.Structure):
                 ("type_multinomial", C.c_int),
                 ("sample_stream", C.POINTER(C.c_uint32)), ("sample_stream_len", C.c_int64),
                 ("unif", UNIF_FN), ("unif_ctx", C.c_void_p), ("seed", C.c_uint32),
+                ("rng_state", C.POINTER(Rng)),
                 ("mode", C.c_int), ("batch", C.c_int64), ("device", C.c_int)]
 
 
@@ -57,10 +62,6 @@ class Result(C.Structure):
                 ("return_codes", C.POINTER(C.c_double)), ("losses", C.POINTER(C.c_double)),
                 ("losses_len", C.POINTER(C.c_int32)), ("nulldev", C.c_double),
                 ("npasses", C.c_double), ("draws_used", C.c_int64)]
-
-
-class Rng(C.Structure):
-    _fields_ = [("mti", C.c_uint32), ("mt", C.c_uint32 * 624)]
 
 
 class Problem(C.Structure):

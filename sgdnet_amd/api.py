@@ -45,14 +45,15 @@ def _stop(msg):
 
 def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None, lambda_=None,
            maxit=1000, standardize=True, intercept=True, thresh=0.001,
-           standardize_response=False, *, debug=False, seed=0, sample_stream=None, unif=None,
-           mode="exact", batch=0, device=0):
+           standardize_response=False, *, debug=False, seed=0, rng=None, sample_stream=None,
+           unif=None, mode="exact", batch=0, device=0):
     """Fit an elastic-net GLM path with SAGA on one MI355X.
 
     Positional/keyword arguments up to `standardize_response` are those of the reference's
     sgdnet.default (lambda.min.ratio -> lambda_min_ratio, lambda -> lambda_).  Keyword-only
-    extensions: debug (options(sgdnet.debug)), seed (set.seed), sample_stream / unif (explicit
-    sample order), mode / batch / device (backend).
+    extensions: debug (options(sgdnet.debug)), seed (set.seed) or rng (an RRng whose state is
+    advanced like R's .Random.seed), sample_stream / unif (explicit sample order), mode /
+    batch / device (backend).
     """
     import scipy.sparse as sp
 
@@ -173,6 +174,8 @@ def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None,
         ctl.unif = cb
         keep.append(cb)
     ctl.seed = int(seed) & 0xFFFFFFFF
+    if rng is not None:
+        ctl.rng_state = C.pointer(rng.state)
     ctl.mode = MODES[mode]
     ctl.batch = int(batch)
     ctl.device = int(device)

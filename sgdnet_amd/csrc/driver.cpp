@@ -211,7 +211,13 @@ struct DrawSource {
   const sgdnet_control* ctl;
   sgdnet_rng rng;
   int64_t pos = 0;
-  explicit DrawSource(const sgdnet_control* c) : ctl(c) { sgdnet_rng_seed(&rng, c->seed); }
+  explicit DrawSource(const sgdnet_control* c) : ctl(c) {
+    if (c->rng_state) rng = *c->rng_state;
+    else sgdnet_rng_seed(&rng, c->seed);
+  }
+  void finish() const {
+    if (internal() && ctl->rng_state) *ctl->rng_state = rng;
+  }
   bool internal() const { return !ctl->sample_stream && !ctl->unif; }
   int fill(uint32_t n, uint32_t* out, int64_t count) {
     if (ctl->sample_stream) {
@@ -512,6 +518,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   pt.mark("lambda path (SAGA + deviance)");
   out->npasses = n_iter;
   out->draws_used = draws.pos;
+  draws.finish();
   return SGDNET_OK;
 }
 

@@ -77,6 +77,10 @@ static void fill_control(SEXP control, sgdnet_control* c) {
   c->type_multinomial =
       strcmp(CHAR(Rf_asChar(list_get(control, "type_multinomial"))), "grouped") == 0;
   c->unif = r_unif;                    /* R's RNG, whatever RNGkind() is active */
+  /* Optional fast path (not enabled here): with the default Mersenne-Twister, copy
+   * .Random.seed[2:626] into a sgdnet_rng, set c->unif = NULL and c->rng_state = &state, and
+   * write the state back to .Random.seed after the fit; the draws are then generated on the
+   * device, bit-identical to unif_rand() (INTEGRATION.md "Faster sample order"). */
   SEXP opt = Rf_GetOption1(Rf_install("sgdnet.mode"));
   if (opt != R_NilValue && strcmp(CHAR(Rf_asChar(opt)), "batched") == 0) c->mode = SGDNET_MODE_BATCHED;
   opt = Rf_GetOption1(Rf_install("sgdnet.batch"));

@@ -425,3 +425,25 @@ def test_device_mersenne_twister_equals_host(sa, oracle, seed, n, count, burn):
     assert np.array_equal(dev.stream(n, 2000), host.stream(n, 2000))
     assert np.array_equal(want[:5], oracle.Rng(seed).stream(n, burn + 5)[burn:])
     S.close()
+
+
+def test_rng_state_and_callback_paths(sa):
+    # three ways to hand over R's sample order give the same fit: set.seed(seed), the generator
+    # state itself (advanced in place like .Random.seed), and a unif_rand() callback
+    rng = np.random.default_rng(20)
+    n, p = 500, 6
+    x = rng.standard_normal((n, p))
+    y = x @ rng.uniform(-1, 1, p) + 0.1 * rng.standard_normal(n)
+    kw = dict(family="gaussian", nlambda=4, thresh=1e-4)
+    a = sa.sgdnet(x, y, seed=9, **kw)
+    st = sa.RRng(9)
+    b = sa.sgdnet(x, y, rng=st, **kw)
+    cb_rng = sa.RRng(9)
+    c = sa.sgdnet(x, y, unif=lambda: float(cb_rng.unif(1)[0]), **kw)
+    for other in (b, c):
+        assert other.npasses == a.npasses
+        assert np.array_equal(other.beta, a.beta) and np.array_equal(other.a0, a.a0)
+    # the state object was advanced by exactly the draws consumed
+    ref = sa.RRng(9)
+    ref.stream(n, int(a.draws_used))
+    assert np.array_equal(st.stream(n, 100), ref.stream(n, 100))
