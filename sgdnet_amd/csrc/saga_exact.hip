@@ -21,7 +21,20 @@ namespace {
 
 constexpr int kWave = 64;
 
-__device__ __forceinline__ void wave_sync() { __syncthreads(); }
+// The workgroup is ONE wavefront, whose LDS operations execute in program order: when all
+// shared state lives in LDS, ordering lanes against each other only needs the compiler to keep
+// program order and the LDS queue to drain -- NOT `s_waitcnt vmcnt(0)`, which __syncthreads()
+// would add and which would serialise the software-prefetched global loads of the next draws
+// into every phase.  With state in global memory the full barrier is kept.
+__device__ __forceinline__ void wave_sync(bool lds_only) {
+  if (lds_only) {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  } else {
+    __syncthreads();
+  }
+}
 
 // ConvergenceCheck (src/utils.h:240-262), executed by the whole wave.
 __device__ __forceinline__ int convergence_check(const double* w, double* w_prev, int64_t len,
@@ -42,6 +55,10 @@ __device__ __forceinline__ int convergence_check(const double* w, double* w_prev
 
 }  // namespace
 
+// LDS carve of the sparse kernel (doubles unless noted):
+//   [slp K][sgc K][sb K][sgb K][sval 64][LS cache kLsCache][sidx 64 int][w KP][G KP][lag p u32]
+constexpr int kLsCache = 2048;
+
 __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, const LamParams* lamp,
                                                                   ExactCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,15 +66,20 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
   const int K = d.K;
   const int64_t p = d.p;
   const int64_t KP = (int64_t)K * p;
+  const bool lds_only = ctl.use_lds != 0;
 
-  // LDS carve: [slp K][sgc K][w KP][G KP][lag p]
   double* slp = reinterpret_cast<double*>(smem);
   double* sgc = slp + K;
+  double* sb = sgc + K;          // intercept, kept on chip for the whole launch
+  double* sgb = sb + K;          // g_sum_intercept
+  double* sval = sgb + K;        // the drawn row, staged for the ascending-order dot product
+  double* sls = sval + kWave;    // first kLsCache entries of lag_scaling
+  int* sidx = reinterpret_cast<int*>(sls + kLsCache);
   double* w = d.w;
   double* G = d.G;
   unsigned* lag = d.lag;
   if (ctl.use_lds) {
-    w = sgc + K;
+    w = reinterpret_cast<double*>(sidx + kWave);
     G = w + KP;
     lag = reinterpret_cast<unsigned*>(G + KP);
     for (int64_t i = lane; i < KP; i += kWave) {
@@ -65,45 +87,107 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
       G[i] = d.G[i];
     }
   }
+  const unsigned nit = (unsigned)ctl.nit;
+  const double* LS = ctl.LS;
+  for (int i = lane; i < kLsCache && i <= (int64_t)nit; i += kWave) sls[i] = LS[i];
+  for (int k = lane; k < K; k += kWave) {
+    sb[k] = d.b[k];
+    sgb[k] = d.gb[k];
+  }
   for (int64_t j = lane; j < p; j += kWave) lag[j] = 0u;            // saga-sparse.h:225
   for (int64_t i = lane; i < KP; i += kWave) d.w_prev[i] = w[i];     // :251
-  wave_sync();
+  wave_sync(lds_only);
+
+  auto ls_at = [&](unsigned m) -> double { return m < (unsigned)kLsCache ? sls[m] : LS[m]; };
 
   const int penalty = lamp->penalty;
   const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
   const double wscale_update = 1.0 - alpha * gamma;                  // :234
   const double n_d = d.n_total;
-  const double* LS = ctl.LS;
-  const unsigned nit = (unsigned)ctl.nit;
   double wscale = 1.0;                                               // :227
 
   unsigned it_outer = 0;
   int converged = 0;
   int64_t t = ctl.stream_off;
+  const int64_t t_last = ctl.stream_off + (int64_t)ctl.max_epochs * nit - 1;
+  auto clampt = [&](int64_t x) { return x < t_last ? x : t_last; };
+
+  // Software pipeline over the known sample order: the stream entry is loaded three draws
+  // ahead, the row pointers two ahead, the row (first 64 entries per lane), y and the old
+  // gradient memory one ahead -- none of them depends on the solver state.
+  uint32_t s1 = d.stream[clampt(t)], s2 = d.stream[clampt(t + 1)], s3 = d.stream[clampt(t + 2)];
+  int64_t q0_1 = d.ptr[s1], q1_1 = d.ptr[s1 + 1];
+  int64_t q0_2 = d.ptr[s2], q1_2 = d.ptr[s2 + 1];
+  int idx_1 = 0;
+  double val_1 = 0.0;
+  if (q0_1 + lane < q1_1) {
+    idx_1 = d.idx[q0_1 + lane];
+    val_1 = d.val[q0_1 + lane];
+  }
+  // lane k carries class k (k < 64; further classes are re-read from memory)
+  double y_1 = lane < d.Ky ? d.y[(int64_t)s1 * d.Ky + lane] : 0.0;
+  double m_1 = lane < K ? d.M[lane + (int64_t)s1 * K] : 0.0;
+
   do {
     for (unsigned it = 0; it < nit; ++it, ++t) {
-      const uint32_t s = d.stream[t];                                // :261
-      const int64_t q0 = d.ptr[s], q1 = d.ptr[s + 1];
+      // ---- rotate the pipeline -------------------------------------------------------
+      const uint32_t s = s1;                                         // :261
+      const int64_t q0 = q0_1, q1 = q1_1;
+      const int idx_c = idx_1;
+      const double val_c = val_1;
+      const double y_c = y_1;
+      const double m_c = m_1;
+      s1 = s2;
+      s2 = s3;
+      s3 = d.stream[clampt(t + 3)];
+      q0_1 = q0_2;
+      q1_1 = q1_2;
+      q0_2 = d.ptr[s2];
+      q1_2 = d.ptr[s2 + 1];
+      idx_1 = 0;
+      val_1 = 0.0;
+      if (q0_1 + lane < q1_1) {
+        idx_1 = d.idx[q0_1 + lane];
+        val_1 = d.val[q0_1 + lane];
+      }
+      y_1 = lane < d.Ky ? d.y[(int64_t)s1 * d.Ky + lane] : 0.0;
+      m_1 = lane < K ? d.M[lane + (int64_t)s1 * K] : 0.0;
+
+      const bool mine = q0 + lane < q1;                              // this lane holds entry q0+lane
+      if (mine) {
+        sidx[lane] = idx_c;
+        sval[lane] = val_c;
+      }
 
       // LaggedUpdate(it_inner): catch-up of the sample's features  :263-272
-      for (int64_t q = q0 + lane; q < q1; q += kWave) {
-        const int64_t j = d.idx[q];
+      if (mine) {
+        const int64_t j = idx_c;
         const unsigned lagged = it - lag[j];
         if (lagged != 0) {
-          penalty_apply(penalty, K, w + j * K, G + j * K, wscale, LS[lagged], gamma, beta);
+          penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
           lag[j] = it;
         }
       }
-      wave_sync();
+      for (int64_t q = q0 + kWave + lane; q < q1; q += kWave) {
+        const int64_t j = d.idx[q];
+        const unsigned lagged = it - lag[j];
+        if (lagged != 0) {
+          penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
+          lag[j] = it;
+        }
+      }
+      wave_sync(lds_only);
 
       // linear predictor: lane k accumulates in ascending feature order  :274
+      const int head = (q1 - q0) < kWave ? (int)(q1 - q0) : kWave;
       for (int k = lane; k < K; k += kWave) {
         double acc = 0.0;
-        for (int64_t q = q0; q < q1; ++q) acc += d.val[q] * w[k + (int64_t)d.idx[q] * K];
-        slp[k] = acc * wscale + d.b[k];
+        for (int e = 0; e < head; ++e) acc += sval[e] * w[k + (int64_t)sidx[e] * K];
+        for (int64_t q = q0 + kWave; q < q1; ++q) acc += d.val[q] * w[k + (int64_t)d.idx[q] * K];
+        slp[k] = acc * wscale + sb[k];
       }
       if (d.standardize) {                                           // :276-277
-        wave_sync();
+        wave_sync(lds_only);
         for (int k = 0; k < K; ++k) {
           double part = 0.0;
           for (int64_t j = lane; j < p; j += kWave) part += w[k + j * K] * d.c[j];
@@ -111,23 +195,30 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
           if (lane == 0) slp[k] -= part * wscale;
         }
       }
-      wave_sync();
+      wave_sync(lds_only);
 
       // gradient, gradient memory  :279-282
+      const double y_first = __shfl(y_c, 0, kWave);   // single-response families: y of the draw
       for (int k = lane; k < K; k += kWave) {
-        const double g = family_gradient_k(d.family, K, k, slp, d.y + (int64_t)s * d.Ky);
+        const bool first = k < kWave;     // classes >= 64 are not register-carried
+        double g;
+        if (d.family == SGDNET_MGAUSSIAN)
+          g = slp[k] - (first ? y_c : d.y[(int64_t)s * d.Ky + k]);
+        else
+          g = family_gradient_k(d.family, K, k, slp, &y_first);
         const int64_t mi = k + (int64_t)s * K;
-        sgc[k] = g - d.M[mi];
+        sgc[k] = g - (first ? m_c : d.M[mi]);
         d.M[mi] = g;
+        if (first && s1 == s) m_1 = g;    // the next draw repeats this sample: forward its memory
       }
 
       // rescale + unlag whenever wscale becomes too small  :285-295
       if (wscale < kSmall) {
-        wave_sync();
+        wave_sync(lds_only);
         for (int64_t j = lane; j < p; j += kWave) {
           const unsigned lagged = it - lag[j];
           if (lagged != 0)
-            penalty_apply(penalty, K, w + j * K, G + j * K, wscale, LS[lagged], gamma, beta);
+            penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
           for (int k = 0; k < K; ++k) w[k + j * K] *= wscale;
           lag[j] = it;
         }
@@ -135,32 +226,36 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
       }
 
       wscale *= wscale_update;                                       // :297
-      wave_sync();
+      wave_sync(lds_only);
 
       if (d.fit_intercept) {                                         // :300-304
         for (int k = lane; k < K; k += kWave) {
           const double gck = sgc[k] / n_d;
-          const double gbk = d.gb[k] + gck;
-          d.gb[k] = gbk;
-          d.b[k] -= gamma * (gbk * 0.01 + gck);
+          const double gbk = sgb[k] + gck;
+          sgb[k] = gbk;
+          sb[k] -= gamma * (gbk * 0.01 + gck);
         }
       }
 
       // AddWeighted(w, ..., -gamma/wscale)  :306-313
       {
         const double scaling = -gamma / wscale;
-        for (int64_t q = q0 + lane; q < q1; q += kWave) {
+        if (mine) {
+          const int64_t j = idx_c;
+          for (int k = 0; k < K; ++k) w[k + j * K] += val_c * sgc[k] * scaling;
+        }
+        for (int64_t q = q0 + kWave + lane; q < q1; q += kWave) {
           const int64_t j = d.idx[q];
           const double v = d.val[q];
           for (int k = 0; k < K; ++k) w[k + j * K] += v * sgc[k] * scaling;
         }
         if (d.standardize) {
-          wave_sync();
+          wave_sync(lds_only);
           for (int64_t j = lane; j < p; j += kWave) {
             const double cj = d.c[j];
             for (int k = 0; k < K; ++k) w[k + j * K] -= cj * sgc[k] * scaling;
           }
-          wave_sync();
+          wave_sync(lds_only);
         }
       }
 
@@ -168,41 +263,50 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
       // then AddWeighted(g_sum, ..., 1/n)  :328-335 (same lane, same feature)
       {
         const double scaling = 1.0 / n_d;
-        for (int64_t q = q0 + lane; q < q1; q += kWave) {
+        if (mine) {
+          const int64_t j = idx_c;
+          const unsigned lagged = (it + 1) - lag[j];
+          if (lagged != 0) {
+            penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
+            lag[j] = it + 1;
+          }
+          for (int k = 0; k < K; ++k) G[k + j * K] += val_c * sgc[k] * scaling;
+        }
+        for (int64_t q = q0 + kWave + lane; q < q1; q += kWave) {
           const int64_t j = d.idx[q];
           const unsigned lagged = (it + 1) - lag[j];
           if (lagged != 0) {
-            penalty_apply(penalty, K, w + j * K, G + j * K, wscale, LS[lagged], gamma, beta);
+            penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
             lag[j] = it + 1;
           }
           const double v = d.val[q];
           for (int k = 0; k < K; ++k) G[k + j * K] += v * sgc[k] * scaling;
         }
         if (d.standardize) {
-          wave_sync();
+          wave_sync(lds_only);
           for (int64_t j = lane; j < p; j += kWave) {
             const double cj = d.c[j];
             for (int k = 0; k < K; ++k) G[k + j * K] -= cj * sgc[k] * scaling;
           }
         }
       }
-      wave_sync();
+      wave_sync(lds_only);
     }
 
     // Reset(n_samples): unlag and rescale  :340-348
     for (int64_t j = lane; j < p; j += kWave) {
       const unsigned lagged = nit - lag[j];
       if (lagged != 0)
-        penalty_apply(penalty, K, w + j * K, G + j * K, wscale, LS[lagged], gamma, beta);
+        penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
       for (int k = 0; k < K; ++k) w[k + j * K] *= wscale;
       lag[j] = 0u;
     }
     wscale = 1.0;
-    wave_sync();
+    wave_sync(lds_only);
 
     converged = convergence_check(w, d.w_prev, KP, ctl.tol, lane);   // :367
     ++it_outer;
-    wave_sync();
+    wave_sync(lds_only);
   } while (!converged && it_outer < ctl.max_epochs);                 // :371
 
   if (ctl.use_lds) {
@@ -210,6 +314,10 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
       d.w[i] = w[i];
       d.G[i] = G[i];
     }
+  }
+  for (int k = lane; k < K; k += kWave) {
+    d.b[k] = sb[k];
+    d.gb[k] = sgb[k];
   }
   if (lane == 0) {
     ctl.out[0] = (int)it_outer;
@@ -229,6 +337,7 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
   const int K = d.K;
   const int64_t p = d.p;
   const int64_t KP = (int64_t)K * p;
+  const bool lds_only = ctl.use_lds != 0;
 
   // LDS carve: [slp K][sgc K][xs p][w KP][G KP]
   double* slp = reinterpret_cast<double*>(smem);
@@ -245,7 +354,7 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
     }
   }
   for (int64_t i = lane; i < KP; i += kWave) d.w_prev[i] = w[i];     // saga-dense.h:142
-  wave_sync();
+  wave_sync(lds_only);
 
   const int penalty = lamp->penalty;
   const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
@@ -286,14 +395,14 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
           xn[c] = j < p ? d.xd[(int64_t)s1 * p + j] : 0.0;
         }
       }
-      wave_sync();
+      wave_sync(lds_only);
 
       for (int k = lane; k < K; k += kWave) {                        // :154
         double acc = 0.0;
         for (int64_t j = 0; j < p; ++j) acc += w[k + j * K] * xs[j];
         slp[k] = acc * wscale + d.b[k];
       }
-      wave_sync();
+      wave_sync(lds_only);
 
       for (int k = lane; k < K; k += kWave) {                        // :156-159
         const double g = family_gradient_k(d.family, K, k, slp, d.y + (int64_t)s * d.Ky);
@@ -307,7 +416,7 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
         wscale = 1.0;
       }
       wscale *= wscale_update;                                       // :168
-      wave_sync();
+      wave_sync(lds_only);
 
       if (d.fit_intercept) {                                         // :170-173
         for (int k = lane; k < K; k += kWave) {
@@ -329,16 +438,16 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
           for (int k = 0; k < K; ++k) gj[k] += sgc[k] * xj / n_d;    // :183
         }
       }
-      wave_sync();
+      wave_sync(lds_only);
     }
 
     for (int64_t i = lane; i < KP; i += kWave) w[i] *= wscale;       // :188-189
     wscale = 1.0;
-    wave_sync();
+    wave_sync(lds_only);
 
     converged = convergence_check(w, d.w_prev, KP, ctl.tol, lane);   // :208
     ++it_outer;
-    wave_sync();
+    wave_sync(lds_only);
   } while (!converged && it_outer < ctl.max_epochs);
 
   if (ctl.use_lds) {
@@ -354,7 +463,7 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
 }
 
 size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state) {
-  size_t b = sizeof(double) * 2 * (size_t)d.K;
+  size_t b = sizeof(double) * (4 * (size_t)d.K + kWave + kLsCache) + sizeof(int) * kWave;
   if (stage_state) b += sizeof(double) * 2 * (size_t)d.K * (size_t)d.p + sizeof(unsigned) * (size_t)d.p;
   return (b + 15) & ~size_t(15);
 }
