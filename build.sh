@@ -10,14 +10,14 @@ mkdir -p "$OUT" build
 # order without fused multiply-adds.
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -I$SRC -Wall -Wno-unused-function"
 pids=()
-for f in saga_exact.hip saga_batched.hip r_rng_device.hip solver.cpp driver.cpp r_rng.cpp; do
+for f in saga_exact.hip saga_batched.hip r_rng_device.hip setup_device.hip solver.cpp driver.cpp r_rng.cpp; do
   o=build/${f%.*}.o
-  if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ "$SRC/common.hpp" -nt "$o" ] || [ "$SRC/device_math.hpp" -nt "$o" ] || [ include/sgdnet_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ "$SRC/common.hpp" -nt "$o" ] || [ "$SRC/device_math.hpp" -nt "$o" ] || [ "$SRC/setup_device.hpp" -nt "$o" ] || [ include/sgdnet_hip.h -nt "$o" ]; then
     $HIPCC $FLAGS -x hip -c "$SRC/$f" -o "$o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgdnet_hip.so" build/saga_exact.o build/saga_batched.o build/r_rng_device.o build/solver.o build/driver.o build/r_rng.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgdnet_hip.so" build/saga_exact.o build/saga_batched.o build/r_rng_device.o build/setup_device.o build/solver.o build/driver.o build/r_rng.o
 make -s -C oracle liboracle.so
 echo "built $OUT/libsgdnet_hip.so"

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "setup_device.hpp"
 
 using namespace sgdnet;
 
@@ -51,6 +52,11 @@ struct Features {
   std::vector<double> sval;
   std::vector<double> xt;       // dense p x n
   std::vector<double> x_center, x_scale, x_center_scaled;
+  // device-side setup (sparse): the O(nnz) passes run in setup_device.hip and the vectors
+  // above other than x_center / x_scale stay empty
+  DeviceSetup* dev = nullptr;
+  hipStream_t st = nullptr;
+  double dev_max_mean_sq = 0.0;
 };
 
 // math.h:66-79 Mean / :114-130 StandardDeviation (population sd, 0 -> 1)
@@ -76,7 +82,8 @@ void standardize_cols(double* x, int64_t n, int64_t m, const double* mean, const
 }
 
 // x^T v for every feature column; v is n x cols column-major
-void xt_times(const Features& X, const double* v, int cols, double* out) {
+int xt_times(const Features& X, const double* v, int cols, double* out) {
+  if (X.dev) return device_xt_times(*X.dev, v, cols, out, X.st);
   for (int c = 0; c < cols; ++c) {
     const double* vc = v + (int64_t)c * X.n;
     for (int64_t j = 0; j < X.p; ++j) {
@@ -90,6 +97,7 @@ void xt_times(const Features& X, const double* v, int cols, double* out) {
       out[j + (int64_t)c * X.p] = s;
     }
   }
+  return SGDNET_OK;
 }
 
 double log_sum_exp_host(const double* x, int K) {
@@ -167,7 +175,7 @@ double lambda_max(int family, int K, const Features& X, const double* y, int Ky,
   double best = 0.0;
   if (family == SGDNET_GAUSSIAN) {
     std::vector<double> xty((size_t)p);
-    xt_times(X, y, 1, xty.data());
+    if (xt_times(X, y, 1, xty.data())) return NAN;
     for (int64_t j = 0; j < p; ++j) best = std::max(best, fabs(xty[(size_t)j]));
     return y_scale[0] * best / (double)n;
   }
@@ -176,7 +184,7 @@ double lambda_max(int family, int K, const Features& X, const double* y, int Ky,
     col_mean_sd(y, n, 1, &ybar, &ystd);
     std::vector<double> ymap((size_t)n), xty((size_t)p);
     for (int64_t i = 0; i < n; ++i) ymap[(size_t)i] = (y[i] - ybar) / ystd;
-    xt_times(X, ymap.data(), 1, xty.data());
+    if (xt_times(X, ymap.data(), 1, xty.data())) return NAN;
     for (int64_t j = 0; j < p; ++j) best = std::max(best, fabs(xty[(size_t)j]));
     return ystd * best / (double)n;
   }
@@ -185,7 +193,7 @@ double lambda_max(int family, int K, const Features& X, const double* y, int Ky,
     for (int64_t i = 0; i < n; ++i) ymap[(size_t)(i + (int64_t)(unsigned)(y[i] + 0.5) * n)] = 1.0;
     col_mean_sd(ymap.data(), n, K, ybar.data(), ystd.data());
     standardize_cols(ymap.data(), n, K, ybar.data(), ystd.data());
-    xt_times(X, ymap.data(), K, xty.data());
+    if (xt_times(X, ymap.data(), K, xty.data())) return NAN;
     for (int k = 0; k < K; ++k)
       for (int64_t j = 0; j < p; ++j)
         best = std::max(best, fabs(xty[(size_t)(j + (int64_t)k * p)] * ystd[(size_t)k]));
@@ -194,7 +202,7 @@ double lambda_max(int family, int K, const Features& X, const double* y, int Ky,
   std::vector<double> ymap(y, y + n * Ky), xty((size_t)(p * Ky)), ybar((size_t)Ky), ystd((size_t)Ky);
   col_mean_sd(y, n, Ky, ybar.data(), ystd.data());
   standardize_cols(ymap.data(), n, Ky, ybar.data(), ystd.data());
-  xt_times(X, ymap.data(), Ky, xty.data());
+  if (xt_times(X, ymap.data(), Ky, xty.data())) return NAN;
   for (int64_t j = 0; j < p; ++j) {
     double s = 0.0;
     for (int k = 0; k < Ky; ++k) {
@@ -324,6 +332,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   std::vector<double> lambda((size_t)n_lambda), alpha((size_t)n_lambda), beta((size_t)n_lambda);
   if (ctl->n_lambda_user == 0) {
     const double lmax = lambda_max(family, K, X, y.data(), Ky, y_scale.data()) / std::max(mix, 0.001);
+    if (std::isnan(lmax)) return SGDNET_EHIP;   // device pass failed (sgdnet_last_error says why)
     if (lmax != 0.0) {
       const double log_from = log(lmax);
       const double step = (log(lmax * ctl->lambda_min_ratio) - log_from) / (double)(n_lambda - 1);
@@ -344,8 +353,12 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   // ColNormsMax: utils.h:60-85
   double norm_max = 0.0;
-  if (X.sparse) {
-    double csq = 0.0;
+  if (X.dev) {
+    // transpose, row norms and record packing on the device; y rides inside the records
+    static const int align = [] { const char* e = getenv("SGDNET_REC_ALIGN"); return e ? atoi(e) : 128; }();
+    int rcd = device_setup_finish(*X.dev, yt.data(), Ky, ctl->standardize ? 1 : 0, align, X.st, &norm_max);
+    if (rcd) return rcd;
+  } else if (X.sparse) {    double csq = 0.0;
     if (ctl->standardize)
       for (int64_t j = 0; j < p; ++j) csq += X.x_center_scaled[(size_t)j] * X.x_center_scaled[(size_t)j];
     for (int64_t i = 0; i < n; ++i) {
@@ -389,7 +402,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       set_error("batched mode is implemented for sparse x only; dense x runs in exact mode");
       return SGDNET_EUNSUPPORTED;
     }
-    if (batch <= 0) batch = auto_batch(X, norm_max);
+    if (batch <= 0) batch = X.dev ? sgdnet_auto_batch(norm_max, X.dev_max_mean_sq) : auto_batch(X, norm_max);
   } else if (mode != SGDNET_MODE_EXACT) {
     set_error("unknown mode %d", mode);
     return SGDNET_EINVAL;
@@ -403,7 +416,9 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   pb.n_features = p;
   pb.fit_intercept = fit_intercept ? 1 : 0;
   pb.standardize = (X.sparse && ctl->standardize) ? 1 : 0;
-  if (X.sparse) {
+  if (X.dev) {
+    // matrix, centring vector and records are adopted from the device setup
+  } else if (X.sparse) {
     pb.rowptr = X.sptr.data();
     pb.colidx = X.sidx.data();
     pb.values = X.sval.data();
@@ -417,7 +432,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   sgdnet_solver* S = nullptr;
   pt.mark("response, path, step sizes");
-  int rc = sgdnet_solver_create(&pb, &S);
+  int rc = X.dev ? solver_create_adopting(&pb, *X.dev, &S) : sgdnet_solver_create(&pb, &S);
   if (rc) return rc;
   pt.mark("solver create (pack + H2D)");
   struct Guard {
@@ -541,6 +556,36 @@ int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols, const sg
   X.colptr = x->colptr;
   X.rowidx = x->rowidx;
   const int64_t n = X.n, p = X.p, nnz = x->colptr[p];
+  for (int64_t q = 0; q < nnz; ++q) {
+    const int32_t r = x->rowidx[q];
+    if (r < 0 || r >= n) {
+      set_error("row index %d out of range at position %lld", r, (long long)q);
+      return SGDNET_EINVAL;
+    }
+  }
+  if (!getenv("SGDNET_HOST_SETUP")) {
+    // default: the per-fit O(nnz) passes run on the device (setup_device.hip)
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      set_error("no HIP device available: the SAGA backend has no CPU fallback");
+      return SGDNET_ENODEVICE;
+    }
+    if (ctl->device < 0 || ctl->device >= ndev) {
+      set_error("device %d out of range (%d devices)", ctl->device, ndev);
+      return SGDNET_EINVAL;
+    }
+    SGD_HIP_TRY(hipSetDevice(ctl->device));
+    DeviceSetup dev;
+    hipStream_t st = nullptr;
+    SGD_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    X.dev = &dev;
+    X.st = st;
+    rc = device_setup_begin(dev, x, ctl->standardize ? 1 : 0, st, X.x_center, X.x_scale, &X.dev_max_mean_sq);
+    if (!rc) rc = fit_common(X, y, y_cols, ctl, out);
+    dev.release();
+    (void)hipStreamDestroy(st);
+    return rc;
+  }
   X.val.assign(x->values, x->values + nnz);
   X.x_center.assign((size_t)p, 0.0);
   X.x_scale.assign((size_t)p, 1.0);
@@ -563,14 +608,7 @@ int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols, const sg
   }
   // AdaptiveTranspose (utils.h:276-281): counting sort into sample-major order
   X.sptr.assign((size_t)n + 1, 0);
-  for (int64_t q = 0; q < nnz; ++q) {
-    const int32_t r = x->rowidx[q];
-    if (r < 0 || r >= n) {
-      set_error("row index %d out of range at position %lld", r, (long long)q);
-      return SGDNET_EINVAL;
-    }
-    X.sptr[(size_t)r + 1]++;
-  }
+  for (int64_t q = 0; q < nnz; ++q) X.sptr[(size_t)x->rowidx[q] + 1]++;
   for (int64_t i = 0; i < n; ++i) X.sptr[(size_t)i + 1] += X.sptr[(size_t)i];
   X.sidx.resize((size_t)nnz);
   X.sval.resize((size_t)nnz);

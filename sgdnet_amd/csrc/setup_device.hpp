@@ -1,0 +1,38 @@
+// Device-resident setup state of one sparse fit (setup_device.hip).
+#pragma once
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace sgdnet {
+
+struct DeviceSetup {
+  int64_t n = 0, p = 0, nnz = 0;
+  // feature-major copy of x (freed by device_setup_finish)
+  int32_t* colptr = nullptr;
+  int32_t* rowidx = nullptr;
+  double* val = nullptr;
+  // sample-major matrix, centring vector and packed records: adopted by the solver
+  int64_t* sptr = nullptr;
+  int32_t* sidx = nullptr;
+  double* sval = nullptr;
+  double* center_scaled = nullptr;
+  char* rec = nullptr;
+  char* ovf = nullptr;
+  int rec_stride = 0, rec_cap = 0, rec_val_off = 0;
+  float avg_nnz = 0.f;
+  void release();
+};
+
+int device_setup_begin(DeviceSetup& S, const sgdnet_csc* x, int standardize, hipStream_t st,
+                       std::vector<double>& x_center, std::vector<double>& x_scale, double* max_mean_sq);
+int device_xt_times(const DeviceSetup& S, const double* ymap_host, int cols, double* xty_host, hipStream_t st);
+int device_setup_finish(DeviceSetup& S, const double* y_host, int y_rows, int standardize, int rec_align,
+                        hipStream_t st, double* max_sqnorm);
+
+// solver.cpp: builds a solver around buffers that device_setup_* left on the device
+// (ownership moves to the solver).  pb carries the scalar fields and the HOST response.
+int solver_create_adopting(const sgdnet_problem* pb, DeviceSetup& S, sgdnet_solver** out);
+
+}  // namespace sgdnet

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "setup_device.hpp"
 
 namespace sgdnet {
 
@@ -404,14 +405,16 @@ int sgdnet_device_count(void) {
   return n;
 }
 
-int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
+extern "C" void sgdnet_solver_destroy(sgdnet_solver* s);
+
+static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdnet_solver** out) {
   if (!pb || !out) {
     set_error("sgdnet_solver_create: null argument");
     return SGDNET_EINVAL;
   }
   *out = nullptr;
   if (pb->n_samples <= 0 || pb->n_features <= 0 || pb->n_classes <= 0 || !pb->y || pb->y_rows <= 0 ||
-      (!pb->x_dense && !(pb->rowptr && pb->colidx && pb->values))) {
+      (!adopt && !pb->x_dense && !(pb->rowptr && pb->colidx && pb->values))) {
     set_error("sgdnet_solver_create: invalid problem description");
     return SGDNET_EINVAL;
   }
@@ -436,7 +439,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
 
   sgdnet_solver* s = new sgdnet_solver();
   s->device = pb->device;
-  s->sparse = pb->x_dense == nullptr;
+  s->sparse = adopt != nullptr || pb->x_dense == nullptr;
   hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
   if (e != hipSuccess) {
     set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -448,7 +451,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
   d.K = pb->n_classes;
   d.Ky = pb->y_rows;
   d.fit_intercept = pb->fit_intercept;
-  d.standardize = (s->sparse && pb->standardize && pb->x_center_scaled) ? 1 : 0;
+  d.standardize = (s->sparse && pb->standardize && (adopt || pb->x_center_scaled)) ? 1 : 0;
   d.n = pb->n_samples;
   d.p = pb->n_features;
   d.n_total = (double)(pb->n_total > 0 ? pb->n_total : pb->n_samples);
@@ -463,7 +466,31 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
       return rc;                   \
     }                              \
   } while (0)
-  if (s->sparse) {
+  if (adopt) {
+    // buffers produced on the device by setup_device.hip: take ownership
+    s->nnz = adopt->nnz;
+    d.avg_nnz = adopt->avg_nnz;
+    d.ptr = adopt->sptr;
+    d.idx = adopt->sidx;
+    d.val = adopt->sval;
+    d.rec = adopt->rec;
+    d.ovf = adopt->ovf;
+    d.rec_stride = adopt->rec_stride;
+    d.rec_cap = adopt->rec_cap;
+    d.rec_val_off = adopt->rec_val_off;
+    for (void* q : {(void*)adopt->sptr, (void*)adopt->sidx, (void*)adopt->sval, (void*)adopt->rec,
+                    (void*)adopt->ovf})
+      s->owned.push_back(q);
+    adopt->sptr = nullptr;
+    adopt->sidx = nullptr;
+    adopt->sval = nullptr;
+    adopt->rec = adopt->ovf = nullptr;
+    if (d.standardize) {
+      d.c = adopt->center_scaled;
+      s->owned.push_back(adopt->center_scaled);
+      adopt->center_scaled = nullptr;
+    }
+  } else if (s->sparse) {
     s->nnz = pb->rowptr[n];
     d.avg_nnz = (float)((double)s->nnz / (double)n);
     int64_t* ptr;
@@ -485,7 +512,7 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
     double* y;
     TRY(dev_upload(s, &y, pb->y, n * (size_t)d.Ky));
     d.y = y;
-    if (d.standardize) {
+    if (d.standardize && !adopt) {
       double* c;
       TRY(dev_upload(s, &c, pb->x_center_scaled, p));
       d.c = c;
@@ -525,6 +552,10 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
   memset(&s->lam, 0, sizeof(s->lam));
   *out = s;
   return SGDNET_OK;
+}
+
+int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
+  return solver_create_impl(pb, nullptr, out);
 }
 
 void sgdnet_solver_destroy(sgdnet_solver* s) {
@@ -936,3 +967,11 @@ int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged) {
 }
 
 }  // extern "C"
+
+namespace sgdnet {
+
+int solver_create_adopting(const sgdnet_problem* pb, DeviceSetup& S, sgdnet_solver** out) {
+  return solver_create_impl(pb, &S, out);
+}
+
+}  // namespace sgdnet
