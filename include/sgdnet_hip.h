@@ -56,7 +56,8 @@ extern "C" {
 
 /* execution mode of the SAGA loop */
 #define SGDNET_MODE_EXACT   0  /* the reference iteration, one draw at a time, in stream order */
-#define SGDNET_MODE_BATCHED 1  /* `batch` consecutive draws against one snapshot (sparse only) */
+#define SGDNET_MODE_BATCHED 1  /* `batch` consecutive draws against one snapshot; sgdnet_fit_* fall back
+                                  to the exact iteration for dense x and for more than 16 classes */
 
 /* x as R passes it to SgdnetSparse: the slots of a dgCMatrix (R/sgdnet.R:226). */
 typedef struct sgdnet_csc {

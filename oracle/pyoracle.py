@@ -18,6 +18,9 @@ PENALTIES = {"ridge": 0, "elasticnet": 1, "grouplasso": 2}
 
 
 def build(force=False):
+    if os.environ.get("SGDNET_ORACLE_ASAN") == "1":     # sanitizer run of the CPU test-suite
+        subprocess.check_call(["make", "-C", _HERE, "liboracle_asan.so"], stdout=subprocess.DEVNULL)
+        return os.path.join(_HERE, "liboracle_asan.so")
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "sgdnet_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

@@ -397,11 +397,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   int mode = ctl->mode;
   int64_t batch = ctl->batch;
+  // SGDNET_MODE_BATCHED means "batched where it is implemented": dense x and more than 16
+  // classes run the exact iteration instead (a global options(sgdnet.mode = "batched") in R
+  // must not make dense fits fail)
+  if (mode == SGDNET_MODE_BATCHED && (!X.sparse || K > 16)) mode = SGDNET_MODE_EXACT;
   if (mode == SGDNET_MODE_BATCHED) {
-    if (!X.sparse) {
-      set_error("batched mode is implemented for sparse x only; dense x runs in exact mode");
-      return SGDNET_EUNSUPPORTED;
-    }
     if (batch <= 0) batch = X.dev ? sgdnet_auto_batch(norm_max, X.dev_max_mean_sq) : auto_batch(X, norm_max);
   } else if (mode != SGDNET_MODE_EXACT) {
     set_error("unknown mode %d", mode);

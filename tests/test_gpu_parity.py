@@ -447,3 +447,32 @@ def test_rng_state_and_callback_paths(sa):
     ref = sa.RRng(9)
     ref.stream(n, int(a.draws_used))
     assert np.array_equal(st.stream(n, 100), ref.stream(n, 100))
+
+
+def test_fit_edge_cases(sa, oracle):
+    rng = np.random.default_rng(21)
+    # (a) one sparse feature, a column of zeros next to it, standardize on (sd of the zero
+    #     column is replaced by 1, math.h:108), tiny n
+    x = np.zeros((12, 3))
+    x[:, 0] = rng.standard_normal(12) * (rng.random(12) < 0.6)
+    x[3, 2] = 2.0
+    y = 0.5 * x[:, 0] + rng.standard_normal(12) * 0.1
+    for xx in (x, sp.csc_matrix(x)):
+        for mode in ("exact", "batched"):
+            fit = sa.sgdnet(xx, y, family="gaussian", nlambda=3, thresh=1e-7, seed=1, mode=mode)
+            ref = oracle.fit(xx, y, family="gaussian", nlambda=3, thresh=1e-7, seed=1)
+            assert np.all(np.isfinite(fit.beta)) and fit.beta.shape == (3, 3)
+            assert relerr(fit.lambda_, ref["lambda"]) < 1e-12
+            if mode == "exact" or not sp.issparse(xx):        # dense x always runs exact
+                assert fit.npasses == ref["npasses"] and relerr(fit.beta, ref["beta"][0]) < 1e-8
+    # (b) a single user lambda, maxit = 1: return code 1, one epoch, n draws
+    xs = sp.random(300, 20, density=0.2, format="csc", random_state=1)
+    yb = (rng.random(300) < 0.5).astype(float)
+    fit = sa.sgdnet(xs, yb, family="binomial", lambda_=[0.01], maxit=1, standardize=False, seed=2)
+    assert fit.npasses == 1 and fit.return_codes[0] == 1 and fit.draws_used == 300
+    # (c) batch larger than n, batched mode on a problem smaller than one workgroup
+    fit_b = sa.sgdnet(xs[:40], yb[:40], family="binomial", lambda_=[0.01], standardize=False, seed=2,
+                      mode="batched", batch=10**6, thresh=1e-9, maxit=3000)
+    ref_b = oracle.fit(xs[:40], yb[:40], family="binomial", lambda_=[0.01], standardize=False, seed=2,
+                       batch=40, thresh=1e-9, maxit=3000)
+    assert fit_b.npasses == ref_b["npasses"] and relerr(fit_b.beta[:, 0], ref_b["beta"][0, :, 0]) < 1e-8
