@@ -34,6 +34,7 @@ struct SagaDev {
   int64_t p;     // features
   double n_total;  // samples of the whole job (the 1/n of the gradient average)
   float avg_nnz;   // mean non-zeros per sample (sparse)
+  int ablate;      // SGDNET_ABLATE bit mask: timing-only builds of the gather (results are wrong)
   // data, sample-major (SURVEY.md 8a "x")
   const int64_t* ptr;
   const int32_t* idx;

@@ -340,6 +340,7 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
     const int iu = i + u * step;
     valid[u] = iu < hi;
     s[u] = sp[valid[u] ? iu : i];
+    if (d.ablate & 16) s[u] &= 1023u;           // timing only: records from a cache-resident set
   }
   const char* base[U];
   double y0[U], vf[U];
@@ -360,7 +361,7 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
     const int cnt0 = nnz[u] < cap ? nnz[u] : cap;
     in[u] = valid[u] && gl < cnt0 && gl < kGroup;
     tail[u] = valid[u] && (nnz[u] > cnt0 || cnt0 > kGroup);
-    acc[u] = in[u] ? vf[u] * d.w[jf[u]] : 0.0;
+    acc[u] = in[u] ? vf[u] * ((d.ablate & 8) ? 1.0 : d.w[jf[u]]) : 0.0;
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -381,16 +382,20 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
   for (int u = 0; u < U; ++u) {
     gcv[u] = 0.0;
     if (gl == 0 && valid[u]) {
-      const double old =
-          __hip_atomic_exchange(d.M + s[u], g0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      gcv[u] = g0[u] - old;
+      if (d.ablate & 1) {                      // timing only: no gradient-memory exchange
+        gcv[u] = g0[u];
+      } else {
+        const double old =
+            __hip_atomic_exchange(d.M + s[u], g0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gcv[u] = g0[u] - old;
+      }
     }
   }
   double tot = 0.0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const double gc = __shfl(gcv[u], 0, kGroup);
-    if (gc != 0.0) {
+    if (gc != 0.0 && !(d.ablate & 4)) {
       if (in[u]) scatter_add<true>(Dl + jf[u], vf[u] * gc);
       if (tail[u])
         row_tail_for_each(d, base[u], nnz[u], ovf[u], gl,
@@ -454,7 +459,8 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   // flush the private copy as this workgroup's slab: plain coalesced stores (atomics would
   // cap the flush at the ~1.3 TB/s atomic rate); the sweep sums the slabs in a fixed order
   double* slab = d.slab + (int64_t)blockIdx.x * KP;
-  for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
+  if (!(d.ablate & 2))
+    for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
   if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kLdsBlock>(d, K, batch_id, gct);
 }
 

@@ -455,6 +455,7 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
   d.n = pb->n_samples;
   d.p = pb->n_features;
   d.n_total = (double)(pb->n_total > 0 ? pb->n_total : pb->n_samples);
+  d.ablate = getenv("SGDNET_ABLATE") ? atoi(getenv("SGDNET_ABLATE")) : 0;
 
   const size_t n = (size_t)d.n, p = (size_t)d.p, K = (size_t)d.K;
   int rc = SGDNET_OK;
