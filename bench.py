@@ -46,6 +46,10 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="staleness window; 0 = automatic (sgdnet_auto_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-epochs", type=int, default=2)
+    ap.add_argument("--no-convergence", action="store_true",
+                    help="skip the epochs-to-tolerance leg (outside the timed region)")
+    ap.add_argument("--conv-thresh", type=float, default=1e-6)
+    ap.add_argument("--conv-max-epochs", type=int, default=400)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -207,6 +211,36 @@ def main():
     }
 
     note("profiled epoch done")
+
+    # Epochs-to-tolerance of the same job from a cold start (outside the timed region): epochs/s
+    # alone says nothing about a merge rule that trades statistical efficiency for throughput.
+    if not args.no_convergence:
+        S.set("w", np.zeros((K, p)))
+        S.set("g_sum", np.zeros((K, p)))
+        S.set("g_sum_intercept", np.zeros(K))
+        S.set("g_memory", np.zeros((K, n_local)))
+        S.set("intercept", b0)
+        crng = sa.RRng(seed + 1000 + rank)
+        S.convergence(args.conv_thresh)            # w_prev <- 0
+        fence()
+        tconv = time.perf_counter()
+        done, conv_ep = False, 0
+        while not done and conv_ep < args.conv_max_epochs:
+            S.generate_stream(crng, n_local)       # this epoch's draws, generated on the device
+            shard.offset = 0
+            job.epoch()
+            S.sync()
+            torch.cuda.synchronize()
+            done = S.convergence(args.conv_thresh)
+            conv_ep += 1
+        tconv = time.perf_counter() - tconv
+        out["convergence"] = {"thresh": args.conv_thresh, "epochs": conv_ep, "converged": bool(done),
+                              "seconds": tconv, "deviance": None,
+                              "note": "cold start, ConvergenceCheck on the merged coefficients every epoch; "
+                                      "includes per-epoch device RNG and host synchronisation"}
+        if world == 1:
+            out["convergence"]["deviance"] = S.deviance()
+        note(f"convergence leg: {conv_ep} epochs in {tconv:.3f}s")
     # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 cannot run inside
     # this process); attached only when workload, batch and kernel match that profile
     try:
