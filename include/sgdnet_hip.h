@@ -242,6 +242,21 @@ void* sgdnet_solver_stream(sgdnet_solver* s);
 int sgdnet_solver_export_delta_async(sgdnet_solver* s, void* device_buf);
 int sgdnet_solver_apply_merged_async(sgdnet_solver* s, const void* device_buf, double w_weight);
 
+/* ------------------------------------------------------------------------ */
+/* Synchronous sample-sharded batches: a global batch is split  */
+/* across the ranks; every rank gathers its share into the bound buffer       */
+/* [D (K*p) | intercept-accumulator slots (2*256*K)], the caller sums the     */
+/* buffer across ranks on sgdnet_solver_stream() (RCCL all-reduce), then      */
+/* every rank sweeps with the GLOBAL draw count.  The iterates are those of   */
+/* the single-GPU batched mode with batch = that global count.                */
+/* ------------------------------------------------------------------------ */
+int64_t sgdnet_solver_sync_buffer_len(const sgdnet_solver* s);            /* doubles */
+int sgdnet_solver_sync_bind(sgdnet_solver* s, void* device_buf);         /* NULL: unbind */
+int sgdnet_solver_sync_begin(sgdnet_solver* s, int64_t stream_offset, int64_t draws_local_per_epoch);
+int sgdnet_solver_sync_gather(sgdnet_solver* s, int64_t t0_local, int64_t m_local, int round);
+int sgdnet_solver_sync_sweep(sgdnet_solver* s, int64_t m_global, int64_t m_local, int round);
+int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds);
+
 /* ConvergenceCheck on the current w against the previous call's w (device-side). */
 int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged);
 

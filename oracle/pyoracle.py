@@ -247,3 +247,42 @@ def fit(x, y, *, family="gaussian", alpha=1.0, nlambda=100, lambda_min_ratio=Non
     if debug:
         out["losses"] = [losses[:llen[i], i].copy() for i in range(nlambda)]
     return out
+
+
+def _params(state, x, *, family, penalty, gamma, alpha, beta, fit_intercept, standardize, n_total):
+    K = state["w"].shape[0]
+    p, n = x.shape
+    return _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n, p, int(fit_intercept),
+                       int(standardize), gamma, alpha, beta, 1, 0.0, 0, n_total)
+
+
+def batch_gather(x, y, state, draws, D, d0, *, family, penalty, gamma, alpha, beta,
+                 fit_intercept=True, x_center_scaled=None, n_total=0):
+    """Gather half of one batch (orc_batch_gather): adds into D (K,p) F-order and d0 (K)."""
+    x = x.tocsc()
+    P = _params(state, x, family=family, penalty=penalty, gamma=gamma, alpha=alpha, beta=beta,
+                fit_intercept=fit_intercept, standardize=x_center_scaled is not None, n_total=n_total)
+    ptr = np.ascontiguousarray(x.indptr, dtype=np.int64)
+    idx = np.ascontiguousarray(x.indices, dtype=np.int32)
+    val = np.ascontiguousarray(x.data, dtype=np.float64)
+    y = np.asfortranarray(y, dtype=np.float64)
+    dr = np.ascontiguousarray(draws, dtype=np.uint32)
+    c = None if x_center_scaled is None else np.ascontiguousarray(x_center_scaled, dtype=np.float64)
+    lib().orc_batch_gather(C.byref(P), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                           idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(val),
+                           _dp(c) if c is not None else None, _dp(y), y.shape[0],
+                           _dp(state["intercept"]), _dp(state["w"]), _dp(state["g_memory"]),
+                           dr.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(dr.size), _dp(D), _dp(d0))
+
+
+def batch_sweep(x_shape, state, m_global, D, d0, *, family, penalty, gamma, alpha, beta,
+                fit_intercept=True, x_center_scaled=None, n_total=0):
+    """Sweep half of one batch (orc_batch_sweep): consumes and zeroes D, d0."""
+    K = state["w"].shape[0]
+    p, n = x_shape
+    P = _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n, p, int(fit_intercept),
+                    int(x_center_scaled is not None), gamma, alpha, beta, 1, 0.0, 0, n_total)
+    c = None if x_center_scaled is None else np.ascontiguousarray(x_center_scaled, dtype=np.float64)
+    lib().orc_batch_sweep(C.byref(P), C.c_int64(m_global), _dp(c) if c is not None else None, _dp(D),
+                          _dp(d0), _dp(state["intercept"]), _dp(state["w"]), _dp(state["g_sum"]),
+                          _dp(state["g_sum_intercept"]))

@@ -549,6 +549,91 @@ void orc_batch_factors(double alpha, double gamma, int64_t m, double* r_m, doubl
   }
 }
 
+/* The two halves of one batch, exposed separately so that the sample-sharded synchronous
+ * mode (every rank gathers its share of a global batch, D and d0 are summed across ranks, every
+ * rank sweeps) can be restated with exactly the code of the single-process loop below. */
+void orc_batch_gather(const orc_saga_params* P, const int64_t* ptr, const int32_t* idx,
+                      const double* val, const double* c, const double* y, int Ky,
+                      const double* intercept, const double* w, double* M,
+                      const uint32_t* draws, int64_t m, double* D, double* d0) {
+  const int K = P->n_classes;
+  const int64_t n = P->n_samples, p = P->n_features;
+  const int centred = P->standardize && c != NULL;
+  double* g = (double*)calloc((size_t)K, sizeof(double));
+  double* lp = (double*)calloc((size_t)K, sizeof(double));
+  double* wc = (double*)calloc((size_t)K, sizeof(double));
+  unsigned char* seen = (unsigned char*)calloc((size_t)n, 1);
+  int64_t i, q;
+  int k;
+  /* implicit centring (saga-sparse.h:276-277): (x_s - c).w = x_s.w - c.w, and c.w is one
+   * scalar per class for the whole batch because w is a snapshot */
+  if (centred) w_dot_center(K, p, w, c, wc);
+  for (i = 0; i < m; ++i) {
+    const uint32_t s = draws[i];
+    if (seen[s]) continue;                  /* repeat within the batch: gc == 0 */
+    seen[s] = 1;
+    lp_sparse_plain(K, ptr, idx, val, s, w, intercept, lp);
+    if (centred)
+      for (k = 0; k < K; ++k) lp[k] -= wc[k];
+    family_gradient(P->family, K, lp, y, Ky, s, g);
+    for (k = 0; k < K; ++k) {
+      const double gck = g[k] - M[k + (int64_t)s * K];
+      M[k + (int64_t)s * K] = g[k];
+      d0[k] += gck;
+      for (q = ptr[s]; q < ptr[s + 1]; ++q) D[k + (int64_t)idx[q] * K] += val[q] * gck;
+    }
+  }
+  for (i = 0; i < m; ++i) seen[draws[i]] = 0;
+  free(g); free(lp); free(wc); free(seen);
+}
+
+/* m is the number of draws of the WHOLE batch (all ranks); D and d0 are zeroed. */
+void orc_batch_sweep(const orc_saga_params* P, int64_t m, const double* c, double* D, double* d0,
+                     double* intercept, double* w, double* G, double* gb) {
+  const int K = P->n_classes;
+  const int64_t p = P->n_features;
+  const double gamma = P->gamma, beta = P->beta;
+  const double nt = (double)(P->n_total > 0 ? P->n_total : P->n_samples);
+  const int centred = P->standardize && c != NULL;
+  double r_m, ls_m;
+  int64_t j;
+  int k;
+  orc_batch_factors(P->alpha, gamma, m, &r_m, &ls_m);
+  for (j = 0; j < p; ++j) {
+    double* wj = w + j * K;
+    double* gj = G + j * K;
+    double* dj = D + j * K;
+    /* AddWeighted's dense term (saga-sparse.h:127-128): sum_i (x_ij - c_j) gc_i */
+    if (centred)
+      for (k = 0; k < K; ++k) dj[k] -= c[j] * d0[k];
+    for (k = 0; k < K; ++k) wj[k] = r_m * wj[k] - gamma * ls_m * gj[k] - gamma * dj[k];
+    if (P->penalty == ORC_ELASTICNET) {
+      for (k = 0; k < K; ++k) wj[k] = soft_threshold(wj[k], beta * gamma * ls_m);
+    } else if (P->penalty == ORC_GROUPLASSO) {
+      double nrm = 0.0, factor;
+      for (k = 0; k < K; ++k) nrm += wj[k] * wj[k];
+      nrm = sqrt(nrm);
+      factor = beta * gamma * ls_m / nrm;
+      if (factor < 1.0) {
+        for (k = 0; k < K; ++k) wj[k] *= 1.0 - factor;
+      } else {
+        for (k = 0; k < K; ++k) wj[k] = 0.0;
+      }
+    }
+    for (k = 0; k < K; ++k) {
+      gj[k] += dj[k] / nt;
+      dj[k] = 0.0;
+    }
+  }
+  if (P->fit_intercept) {
+    for (k = 0; k < K; ++k) {
+      gb[k] += d0[k] / nt;
+      intercept[k] -= gamma * (gb[k] * 0.01 * (double)m + d0[k] / nt);
+    }
+  }
+  for (k = 0; k < K; ++k) d0[k] = 0.0;
+}
+
 unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
                                  const int64_t* ptr, const int32_t* idx, const double* val,
                                  const double* c,
@@ -559,84 +644,26 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
                                  double* losses) {
   const int K = P->n_classes;
   const int64_t n = P->n_samples, p = P->n_features;
-  const double gamma = P->gamma, beta = P->beta;
-  const double nt = (double)(P->n_total > 0 ? P->n_total : P->n_samples);
-  int k;
-  int64_t j, q, i;
   double* D = (double*)calloc((size_t)(K * p), sizeof(double));
   double* d0 = (double*)calloc((size_t)K, sizeof(double));
-  double* g = (double*)calloc((size_t)K, sizeof(double));
-  double* lp = (double*)calloc((size_t)K, sizeof(double));
   double* w_prev = (double*)malloc(sizeof(double) * (size_t)(K * p));
-  int64_t* seen = (int64_t*)calloc((size_t)n, sizeof(int64_t)); /* batch stamp + 1 */
-  double* wc = (double*)calloc((size_t)K, sizeof(double));
-  const int centred = P->standardize && c != NULL;
-  int64_t stamp = 0;
+  uint32_t* buf;
   unsigned it_outer = 0;
   int converged = 0;
+  int64_t i;
   if (batch < 1) batch = 1;
+  if (batch > n) batch = n;
+  buf = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)batch);
 
   memcpy(w_prev, w, sizeof(double) * (size_t)(K * p));
 
   do {
     int64_t t0;
     for (t0 = 0; t0 < n; t0 += batch) {
-      int64_t m = (n - t0 < batch) ? n - t0 : batch;
-      double r_m, ls_m;
-      orc_batch_factors(P->alpha, gamma, m, &r_m, &ls_m);
-      ++stamp;
-      /* implicit centring (saga-sparse.h:276-277): (x_s - c).w = x_s.w - c.w, and c.w is one
-       * scalar per class for the whole batch because w is a snapshot */
-      if (centred) w_dot_center(K, p, w, c, wc);
-      for (i = 0; i < m; ++i) {
-        uint32_t s = next_draw(draws, (uint32_t)n);
-        if (seen[s] == stamp) continue;       /* repeat within the batch: gc == 0 */
-        seen[s] = stamp;
-        lp_sparse_plain(K, ptr, idx, val, s, w, intercept, lp);
-        if (centred)
-          for (k = 0; k < K; ++k) lp[k] -= wc[k];
-        family_gradient(P->family, K, lp, y, Ky, s, g);
-        for (k = 0; k < K; ++k) {
-          double gck = g[k] - M[k + (int64_t)s * K];
-          M[k + (int64_t)s * K] = g[k];
-          d0[k] += gck;
-          for (q = ptr[s]; q < ptr[s + 1]; ++q) D[k + (int64_t)idx[q] * K] += val[q] * gck;
-        }
-      }
-      /* feature sweep */
-      for (j = 0; j < p; ++j) {
-        double* wj = w + j * K;
-        double* gj = G + j * K;
-        double* dj = D + j * K;
-        /* AddWeighted's dense term (saga-sparse.h:127-128): sum_i (x_ij - c_j) gc_i */
-        if (centred)
-          for (k = 0; k < K; ++k) dj[k] -= c[j] * d0[k];
-        for (k = 0; k < K; ++k) wj[k] = r_m * wj[k] - gamma * ls_m * gj[k] - gamma * dj[k];
-        if (P->penalty == ORC_ELASTICNET) {
-          for (k = 0; k < K; ++k) wj[k] = soft_threshold(wj[k], beta * gamma * ls_m);
-        } else if (P->penalty == ORC_GROUPLASSO) {
-          double nrm = 0.0, factor;
-          for (k = 0; k < K; ++k) nrm += wj[k] * wj[k];
-          nrm = sqrt(nrm);
-          factor = beta * gamma * ls_m / nrm;
-          if (factor < 1.0) {
-            for (k = 0; k < K; ++k) wj[k] *= 1.0 - factor;
-          } else {
-            for (k = 0; k < K; ++k) wj[k] = 0.0;
-          }
-        }
-        for (k = 0; k < K; ++k) {
-          gj[k] += dj[k] / nt;
-          dj[k] = 0.0;
-        }
-      }
-      if (P->fit_intercept) {
-        for (k = 0; k < K; ++k) {
-          gb[k] += d0[k] / nt;
-          intercept[k] -= gamma * (gb[k] * 0.01 * (double)m + d0[k] / nt);
-        }
-      }
-      for (k = 0; k < K; ++k) d0[k] = 0.0;
+      const int64_t m = (n - t0 < batch) ? n - t0 : batch;
+      for (i = 0; i < m; ++i) buf[i] = next_draw(draws, (uint32_t)n);
+      orc_batch_gather(P, ptr, idx, val, c, y, Ky, intercept, w, M, buf, m, D, d0);
+      orc_batch_sweep(P, m, c, D, d0, intercept, w, G, gb);
     }
 
     if (P->debug && losses)
@@ -647,7 +674,7 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
   } while (!converged && it_outer < P->max_iter);
 
   *return_code = (it_outer == P->max_iter) ? 1u : 0u;
-  free(D); free(d0); free(g); free(lp); free(w_prev); free(seen); free(wc);
+  free(D); free(d0); free(w_prev); free(buf);
   return it_outer;
 }
 

@@ -101,6 +101,16 @@ unsigned orc_saga_sparse_batched(const orc_saga_params* P, int64_t batch,
                                  orc_draws* draws, unsigned* return_code,
                                  double* losses);
 
+/* The two halves of one batch of the batched mode (gather: draws -> D, d0, g_memory;
+ * sweep: D, d0 -> w, g_sum, intercept), for the sample-sharded synchronous restatement. */
+void orc_batch_gather(const orc_saga_params* P, const int64_t* ptr, const int32_t* idx,
+                      const double* val, const double* x_center_scaled, const double* y, int Ky,
+                      const double* intercept, const double* w, double* g_memory,
+                      const uint32_t* draws, int64_t m, double* D, double* d0);
+void orc_batch_sweep(const orc_saga_params* P, int64_t m_global, const double* x_center_scaled,
+                     double* D, double* d0, double* intercept, double* w, double* g_sum,
+                     double* g_sum_intercept);
+
 /* r^m and LS_m = sum_{k<m} r^k for r = 1 - alpha*gamma (closed form of the
  * reference's lag_scaling table, saga-sparse.h:229-240). */
 void orc_batch_factors(double alpha, double gamma, int64_t m, double* r_m, double* ls_m);

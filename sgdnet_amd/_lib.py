@@ -22,7 +22,9 @@ EXPORTS = [
     "sgdnet_solver_export_delta", "sgdnet_solver_apply_merged", "sgdnet_solver_delta_len",
     "sgdnet_solver_convergence", "sgdnet_solver_last_change", "sgdnet_auto_batch",
     "sgdnet_solver_gather_form", "sgdnet_solver_stream", "sgdnet_solver_export_delta_async",
-    "sgdnet_solver_apply_merged_async",
+    "sgdnet_solver_apply_merged_async", "sgdnet_solver_sync_buffer_len", "sgdnet_solver_sync_bind",
+    "sgdnet_solver_sync_begin", "sgdnet_solver_sync_gather", "sgdnet_solver_sync_sweep",
+    "sgdnet_solver_sync_end",
 ]
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
@@ -121,6 +123,13 @@ def load():
     L.sgdnet_solver_stream.restype = C.c_void_p
     L.sgdnet_solver_export_delta_async.argtypes = [C.c_void_p, C.c_void_p]
     L.sgdnet_solver_apply_merged_async.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+    L.sgdnet_solver_sync_buffer_len.argtypes = [C.c_void_p]
+    L.sgdnet_solver_sync_buffer_len.restype = C.c_int64
+    L.sgdnet_solver_sync_bind.argtypes = [C.c_void_p, C.c_void_p]
+    L.sgdnet_solver_sync_begin.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    L.sgdnet_solver_sync_gather.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+    L.sgdnet_solver_sync_sweep.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int]
+    L.sgdnet_solver_sync_end.argtypes = [C.c_void_p, C.c_int]
     L.sgdnet_solver_convergence.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int)]
     L.sgdnet_solver_last_change.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.sgdnet_solver_gather_form.argtypes = [C.c_void_p, C.c_int64]

@@ -34,6 +34,7 @@ struct SagaDev {
   int64_t p;     // features
   double n_total;  // samples of the whole job (the 1/n of the gradient average)
   float avg_nnz;   // mean non-zeros per sample (sparse)
+  int force_global;  // synchronous sharded mode: always the global-atomic gather (D must be one array)
   int ablate;      // SGDNET_ABLATE bit mask: timing-only builds of the gather (results are wrong)
   // data, sample-major (SURVEY.md 8a "x")
   const int64_t* ptr;
@@ -108,7 +109,8 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
                         int batch_id_offset, hipStream_t st, hipEvent_t ev0 = nullptr,
                         hipEvent_t ev1 = nullptr);
 int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, int m, int batch_id_offset,
-                       hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                       hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, double ov_r = 0.0,
+                       double ov_ls = 0.0, double ov_m = 0.0);
 int launch_cw_init(const SagaDev& d, const LamParams* lam, hipStream_t st);
 int batch_gather_blocks(const SagaDev& d, int m);
 int64_t batch_gather_slab_doubles(const SagaDev& d, int m);

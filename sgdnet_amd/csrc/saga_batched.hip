@@ -594,7 +594,14 @@ struct SweepParams {
   double gamma, beta, r_m, ls_m, m_d, n_d;
 };
 
-__device__ __forceinline__ SweepParams load_sweep_params(const SagaDev& d, const LamParams* lamp, int tail) {
+// Batch factors passed by value instead of read from LamParams (synchronous sharded mode: the
+// draw count of a global batch varies by a few draws from round to round).  m <= 0: unused.
+struct SweepOverride {
+  double r_m, ls_m, m;
+};
+
+__device__ __forceinline__ SweepParams load_sweep_params(const SagaDev& d, const LamParams* lamp, int tail,
+                                                         const SweepOverride& ov) {
   SweepParams q;
   q.penalty = lamp->penalty;
   q.gamma = lamp->gamma;
@@ -602,6 +609,11 @@ __device__ __forceinline__ SweepParams load_sweep_params(const SagaDev& d, const
   q.r_m = tail ? lamp->r_tail : lamp->r_full;
   q.ls_m = tail ? lamp->ls_tail : lamp->ls_full;
   q.m_d = (double)(tail ? lamp->m_tail : lamp->m_full);
+  if (ov.m > 0.0) {
+    q.r_m = ov.r_m;
+    q.ls_m = ov.ls_m;
+    q.m_d = ov.m;
+  }
   q.n_d = d.n_total;
   return q;
 }
@@ -696,9 +708,10 @@ __device__ __forceinline__ void cw_accumulate(const SagaDev& d, int batch_id, co
 // GroupLasso needs the column norm: one thread per feature.
 template <bool kGrouped>
 __global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
-                                                                  int n_parts, int batch_id_offset) {
+                                                                  int n_parts, int batch_id_offset,
+                                                                  SweepOverride ov) {
   __shared__ double sh_d0[16];
-  const SweepParams q = load_sweep_params(d, lamp, tail);
+  const SweepParams q = load_sweep_params(d, lamp, tail, ov);
   const int K = d.K;
   const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
   const int batch_id = lamp->batch_seq + batch_id_offset;
@@ -750,7 +763,7 @@ __global__ __launch_bounds__(kBlock) void saga_batch_sweep_slab_kernel(SagaDev d
                                                                        int n_parts, int batch_id_offset) {
   __shared__ double part[kSlabGroups][kSlabElems];
   __shared__ double sh_d0[16];
-  const SweepParams q = load_sweep_params(d, lamp, tail);
+  const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
   const int K = d.K;
   const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
   const int batch_id = lamp->batch_seq + batch_id_offset;
@@ -936,7 +949,7 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
   // worthwhile once the batch's non-zeros outnumber the table ~48x: below that the fixed
   // cost of writing and re-reading one table per workgroup exceeds the atomics it saves
   const bool pays = (double)m * (double)d.avg_nnz >= 48.0 * (double)d.K * (double)d.p;
-  g.lds = d.slab != nullptr && fits && force != 2 && (force == 1 || pays);
+  g.lds = d.slab != nullptr && !d.force_global && fits && force != 2 && (force == 1 || pays);
   if (g.lds) {
     int dpb = (m + target_grid - 1) / target_grid;
     const int per_round = kLdsBlock / kGroup;
@@ -1016,9 +1029,12 @@ int launch_cw_init(const SagaDev& d, const LamParams* lam, hipStream_t st) {
 }
 
 int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, int m, int batch_id_offset,
-                       hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+                       hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, double ov_r, double ov_ls, double ov_m) {
   const GatherPlan g = plan_gather(d, m);
-  const int n_parts = g.grid < kD0Slots ? g.grid : kD0Slots;
+  // synchronous sharded mode (ov_m > 0): the slots were summed across ranks whose gather grids
+  // may differ by one workgroup, so all of them are read (unused slots are zero)
+  const int n_parts = ov_m > 0.0 ? kD0Slots : (g.grid < kD0Slots ? g.grid : kD0Slots);
+  const SweepOverride ov{ov_r, ov_ls, ov_m};
   if (g.lds) {
     const int F = kSlabElems / d.K;
     const int grid = (int)((d.p + F - 1) / F);
@@ -1027,11 +1043,11 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
   } else if (penalty == SGDNET_GROUPLASSO) {
     const int grid = (int)((d.p + kBlock - 1) / kBlock);
     hipExtLaunchKernelGGL(saga_batch_sweep_kernel<true>, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
-                          ev1, 0, d, lam, tail, n_parts, batch_id_offset);
+                          ev1, 0, d, lam, tail, n_parts, batch_id_offset, ov);
   } else {
     const int grid = (int)(((int64_t)d.K * d.p + kBlock - 1) / kBlock);
     hipExtLaunchKernelGGL(saga_batch_sweep_kernel<false>, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
-                          ev1, 0, d, lam, tail, n_parts, batch_id_offset);
+                          ev1, 0, d, lam, tail, n_parts, batch_id_offset, ov);
   }
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;

@@ -69,6 +69,8 @@ struct sgdnet_solver {
   bool w_prev_valid = false;
   double last_change = 0.0, last_size = 0.0;
   int64_t slab_cap = 0;         // doubles the slab buffer can hold
+  double* own_D = nullptr;      // the solver's own D / d0 slots while a sync buffer is bound
+  double* own_d0 = nullptr;
 };
 
 namespace {
@@ -959,6 +961,80 @@ int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq) 
   const double b = 2.0 * max_sample_sqnorm / max_feature_mean_sq;
   if (!(b < 131072.0)) return 131072;
   return b < 64.0 ? 64 : (int64_t)b;
+}
+
+int64_t sgdnet_solver_sync_buffer_len(const sgdnet_solver* s) {
+  if (!s) return 0;
+  return (int64_t)s->d.K * s->d.p + 2 * 256 * (int64_t)s->d.K;
+}
+
+int sgdnet_solver_sync_bind(sgdnet_solver* s, void* device_buf) {
+  if (!s) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  drop_graph(s);
+  if (device_buf) {
+    int rc = check_batched_ok(s);
+    if (rc) return rc;
+    if (!s->own_D) {
+      s->own_D = s->d.D;
+      s->own_d0 = s->d.d0_part;
+    }
+    double* buf = static_cast<double*>(device_buf);
+    SGD_HIP_TRY(hipMemsetAsync(buf, 0, sizeof(double) * (size_t)sgdnet_solver_sync_buffer_len(s), s->st));
+    s->d.D = buf;
+    s->d.d0_part = buf + (int64_t)s->d.K * s->d.p;
+    s->d.force_global = 1;
+  } else if (s->own_D) {
+    s->d.D = s->own_D;
+    s->d.d0_part = s->own_d0;
+    s->own_D = s->own_d0 = nullptr;
+    s->d.force_global = 0;
+  }
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_sync_begin(sgdnet_solver* s, int64_t stream_offset, int64_t draws_local_per_epoch) {
+  if (!s || !s->penalty_set || !s->d.force_global || draws_local_per_epoch <= 0) {
+    set_error("sgdnet_solver_sync_begin: bind a sync buffer and set the penalty first");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = check_stream(s, stream_offset, draws_local_per_epoch);
+  if (rc) return rc;
+  s->lam.stream_base = stream_offset;
+  s->lam.draws_per_epoch = draws_local_per_epoch;
+  rc = push_lam(s);
+  if (rc) return rc;
+  if (s->d.standardize) rc = launch_cw_init(s->d, s->lam_dev, s->st);
+  return rc;
+}
+
+int sgdnet_solver_sync_gather(sgdnet_solver* s, int64_t t0_local, int64_t m_local, int round) {
+  if (!s || !s->d.force_global || t0_local < 0 || m_local < 0) return SGDNET_EINVAL;
+  if (m_local == 0) return SGDNET_OK;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  return launch_batch_gather(s->d, s->lam_dev, t0_local, (int)m_local, 0, round, s->st);
+}
+
+int sgdnet_solver_sync_sweep(sgdnet_solver* s, int64_t m_global, int64_t m_local, int round) {
+  if (!s || !s->d.force_global || m_global <= 0) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  double r_m, ls_m;
+  batch_factors(s->lam.alpha, s->lam.gamma, m_global, &r_m, &ls_m);
+  return launch_batch_sweep(s->d, s->lam_dev, s->lam.penalty, 0, (int)(m_local > 0 ? m_local : 1), round, s->st,
+                            nullptr, nullptr, r_m, ls_m, (double)m_global);
+}
+
+int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds) {
+  if (!s || rounds <= 0) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  int rc = launch_epoch_end(s->lam_dev, rounds, s->st);
+  if (rc) return rc;
+  s->lam.stream_base += s->lam.draws_per_epoch;   // mirrors saga_epoch_end_kernel
+  s->lam.batch_seq += rounds;
+  return SGDNET_OK;
 }
 
 int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged) {

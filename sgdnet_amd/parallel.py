@@ -1,5 +1,19 @@
 """Sample-sharded SAGA across the GPUs of one node (BASELINE north star).
 
+Two drivers share the sample sharding (shard_bounds):
+
+* SyncShardedSaga (default): every GLOBAL batch of B draws is split across the ranks, each
+  rank gathers its B/world draws against the replicated snapshot w into the scatter
+  accumulator, ONE all-reduce sums [D | intercept accumulator] (K*p + 1024*K doubles), and
+  every rank applies the identical feature sweep.  The iterates are exactly those of the
+  single-GPU batched mode with batch B over the interleaved sample order, so convergence is
+  that of one GPU; the cost is one collective per batch.
+* ShardedSaga (per-epoch merge, below): one all-reduce per epoch, averaged iterates.  Cheap,
+  but only safe when the problem is strongly regularised -- on the C4 shape (lambda = 1/n)
+  the averaged iteration oscillates (scripts/merge_rule_experiment.py).
+
+Per-epoch merge in detail:
+
 One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Rank r
 holds a contiguous shard of the samples and their gradient-memory rows; the model
 state (w, g_sum, intercept, g_sum_intercept) is replicated.  One job epoch =
@@ -104,6 +118,91 @@ class ShardedSaga:
         else:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
         sh.apply_merged(buf, self.w_weight)
+
+
+class HipSyncShard:
+    """Adapter for SyncShardedSaga: SagaSolver + the torch buffer its D / intercept slots live in."""
+
+    def __init__(self, solver, *, draws_per_epoch, device, stage_on_host=False):
+        import torch
+
+        self.solver = solver
+        self.draws = draws_per_epoch
+        self.buf = torch.zeros(solver.sync_buffer_len(), dtype=torch.float64, device=device)
+        torch.cuda.synchronize()
+        solver.sync_bind(self.buf.data_ptr())
+        self.host = torch.zeros_like(self.buf, device="cpu") if stage_on_host else None
+        self.ext = torch.cuda.ExternalStream(solver.stream_handle(), device=device)
+        self.offset = 0
+
+    def sync_begin(self):
+        self.solver.sync_begin(self.offset, self.draws)
+
+    def sync_gather(self, t0, m, rnd):
+        self.solver.sync_gather(t0, m, rnd)
+
+    def sync_reduce(self, group):
+        import torch
+        import torch.distributed as dist
+
+        if self.host is not None:             # CPU-only backend rehearsal (gloo)
+            self.solver.sync()
+            self.host.copy_(self.buf)
+            dist.all_reduce(self.host, op=dist.ReduceOp.SUM, group=group)
+            self.buf.copy_(self.host)
+            torch.cuda.synchronize()
+            return
+        with torch.cuda.stream(self.ext):     # ordered between gather and sweep on the solver's stream
+            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+
+    def sync_sweep(self, m_global, m_local, rnd):
+        self.solver.sync_sweep(m_global, m_local, rnd)
+
+    def sync_end(self, rounds):
+        self.solver.sync_end(rounds)
+        self.offset += self.draws
+
+    def close(self):
+        self.solver.sync_bind(0)
+
+
+def sync_rounds(n_total, batch_global):
+    """Number of global batches per job epoch."""
+    return max(1, -(-n_total // max(1, batch_global)))
+
+
+def round_share(n_local, rounds, k):
+    """Draws [lo, hi) of a rank's local epoch stream that belong to global batch k."""
+    return (k * n_local) // rounds, ((k + 1) * n_local) // rounds
+
+
+class SyncShardedSaga:
+    """Synchronous driver: global batches split across ranks, one all-reduce per batch."""
+
+    def __init__(self, shard, n_total, world_size, batch_global, group=None, force_reduce=False):
+        self.shard = shard
+        self.world = world_size
+        self.group = group
+        self.force_reduce = force_reduce      # rehearse the collective with a single rank
+        sizes = [hi - lo for lo, hi in (shard_bounds(n_total, world_size, r) for r in range(world_size))]
+        self.sizes = sizes
+        # every rank contributes at least one draw to every round
+        self.rounds = max(1, min(sync_rounds(n_total, batch_global), min(sizes)))
+        # global draw count of every round: identical on all ranks by construction
+        self.m_global = [sum(round_share(nr, self.rounds, k)[1] - round_share(nr, self.rounds, k)[0]
+                             for nr in sizes) for k in range(self.rounds)]
+
+    def epoch(self, rank):
+        sh, R = self.shard, self.rounds
+        n_local = self.sizes[rank]
+        sh.sync_begin()
+        for k in range(R):
+            lo, hi = round_share(n_local, R, k)
+            sh.sync_gather(lo, hi - lo, k)
+            if self.world > 1 or self.force_reduce:
+                sh.sync_reduce(self.group)
+            sh.sync_sweep(self.m_global[k], hi - lo, k)
+        sh.sync_end(R)
 
 
 def shard_bounds(n_total, world, rank):

@@ -197,6 +197,25 @@ class SagaSolver:
     def apply_merged(self, device_ptr, w_weight):
         check(self._L.sgdnet_solver_apply_merged(self._h, C.c_void_p(device_ptr), w_weight))
 
+    # ---- synchronous sample-sharded batches (sgdnet_amd/parallel.py: SyncShardedSaga) ----
+    def sync_buffer_len(self):
+        return int(self._L.sgdnet_solver_sync_buffer_len(self._h))
+
+    def sync_bind(self, device_ptr):
+        check(self._L.sgdnet_solver_sync_bind(self._h, C.c_void_p(device_ptr) if device_ptr else None))
+
+    def sync_begin(self, stream_offset, draws_local):
+        check(self._L.sgdnet_solver_sync_begin(self._h, stream_offset, draws_local))
+
+    def sync_gather(self, t0_local, m_local, rnd):
+        check(self._L.sgdnet_solver_sync_gather(self._h, t0_local, m_local, rnd))
+
+    def sync_sweep(self, m_global, m_local, rnd):
+        check(self._L.sgdnet_solver_sync_sweep(self._h, m_global, m_local, rnd))
+
+    def sync_end(self, rounds):
+        check(self._L.sgdnet_solver_sync_end(self._h, rounds))
+
     def stream_handle(self):
         """The solver's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
         return int(self._L.sgdnet_solver_stream(self._h) or 0)

@@ -114,3 +114,114 @@ def test_two_rank_gloo_matches_emulation_and_converges(tmp_path):
             alpha=A_L2, beta=B_L1, max_iter=400, tol=1e-12, rng=po.Rng(3))
     opt = np.r_[st["w"].ravel(), st["intercept"]]
     assert np.abs(w0 - opt).max() / np.abs(opt).max() < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------
+# Synchronous mode: global batches split across ranks, one all-reduce per batch
+# (sgdnet_amd/parallel.py: SyncShardedSaga).  Must reproduce the single-process batched
+# iteration over the interleaved sample order, not merely its fixed point.
+# ---------------------------------------------------------------------------------------------
+S_LAM = dict(gamma=0.08, alpha=2e-5, beta=1e-5)       # weakly regularised: the regime where the
+S_BATCH = 96                                           # per-epoch averaged merge oscillates
+
+
+class OracleSyncShard:
+    def __init__(self, rank, world, family="binomial", K=1):
+        import torch
+        from oracle import pyoracle as po
+        from sgdnet_amd import data as D
+        from sgdnet_amd.parallel import shard_bounds
+        self.po, self.torch, self.family, self.K = po, torch, family, K
+        self.lo, hi = shard_bounds(N, world, rank)
+        pr = D.make_sparse_glm(N, P, DENS, family=family, n_classes=K, seed=SEED, lo=self.lo, hi=hi)
+        self.X, self.y, self.n = D.as_scipy(pr), pr["y"], hi - self.lo
+        self.st = po.new_state(K, P, self.n)
+        self.rng = po.Rng(SEED + rank)
+        self.buf = np.zeros(K * P + K)
+        self.D = self.buf[:K * P].reshape((K, P), order="F")
+        self.d0 = self.buf[K * P:]
+        self.kw = dict(family=family, penalty="elasticnet", n_total=N, **S_LAM)
+        self.history = []
+
+    def sync_begin(self):
+        self.stream = self.rng.stream(self.n, self.n)
+        self.history.append(self.stream)
+
+    def sync_gather(self, t0, m, rnd):
+        self.po.batch_gather(self.X, self.y, self.st, self.stream[t0:t0 + m], self.D, self.d0, **self.kw)
+
+    def sync_reduce(self, group):
+        import torch.distributed as dist
+        dist.all_reduce(self.torch.from_numpy(self.buf), op=dist.ReduceOp.SUM, group=group)
+
+    def sync_sweep(self, m_global, m_local, rnd):
+        self.po.batch_sweep((P, self.n), self.st, m_global, self.D, self.d0, **self.kw)
+
+    def sync_end(self, rounds):
+        pass
+
+
+def _sync_worker(rank, world, port, epochs, outdir, family, K):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from sgdnet_amd.parallel import SyncShardedSaga
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                            world_size=world)
+    shard = OracleSyncShard(rank, world, family, K)
+    job = SyncShardedSaga(shard, N, world, S_BATCH)
+    for _ in range(epochs):
+        job.epoch(rank)
+    np.save(os.path.join(outdir, f"s{rank}.npy"),
+            np.r_[shard.st["w"].ravel("F"), shard.st["intercept"], shard.st["g_sum"].ravel("F")])
+    np.save(os.path.join(outdir, f"h{rank}.npy"), np.stack(shard.history))
+    dist.destroy_process_group()
+
+
+def _sync_single_process(world, epochs, histories, family, K):
+    """The same global batches on ONE process holding all samples."""
+    from oracle import pyoracle as po
+    from sgdnet_amd import data as D
+    from sgdnet_amd.parallel import SyncShardedSaga, round_share, shard_bounds
+    pr = D.make_sparse_glm(N, P, DENS, family=family, n_classes=K, seed=SEED)
+    X, y = D.as_scipy(pr), pr["y"]
+    st = po.new_state(K, P, N)
+    plan = SyncShardedSaga(None, N, world, S_BATCH)
+    Dm, d0 = np.zeros((K, P), order="F"), np.zeros(K)
+    kw = dict(family=family, penalty="elasticnet", n_total=N, **S_LAM)
+    for e in range(epochs):
+        for k in range(plan.rounds):
+            draws = []
+            for r in range(world):
+                lo_r = shard_bounds(N, world, r)[0]
+                a, b = round_share(plan.sizes[r], plan.rounds, k)
+                draws.append(histories[r][e][a:b].astype(np.int64) + lo_r)
+            draws = np.concatenate(draws).astype(np.uint32)
+            assert draws.size == plan.m_global[k]
+            po.batch_gather(X, y, st, draws, Dm, d0, **kw)
+            po.batch_sweep((P, N), st, draws.size, Dm, d0, **kw)
+    return np.r_[st["w"].ravel("F"), st["intercept"], st["g_sum"].ravel("F")], (X, y)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("family,K", [("binomial", 1), ("multinomial", 3)])
+def test_two_rank_sync_mode_is_the_single_process_batched_iteration(tmp_path, family, K):
+    import torch.multiprocessing as mp
+    epochs = 6
+    mp.spawn(_sync_worker, args=(2, _free_port(), epochs, str(tmp_path), family, K), nprocs=2, join=True)
+    s0, s1 = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy")
+    assert np.array_equal(s0, s1), "ranks must hold identical replicated state"
+    hist = [np.load(tmp_path / f"h{r}.npy") for r in range(2)]
+    one, _ = _sync_single_process(2, epochs, hist, family, K)
+    np.testing.assert_allclose(s0, one, rtol=0, atol=1e-12)
+
+
+def test_sync_round_plan_covers_every_draw_once():
+    from sgdnet_amd.parallel import SyncShardedSaga, round_share
+    for n_total, world, batch in [(1000, 3, 64), (17, 4, 1), (10_000_000, 8, 131072), (5, 2, 100)]:
+        plan = SyncShardedSaga(None, n_total, world, batch)
+        assert sum(plan.m_global) == n_total
+        assert min(plan.m_global) >= world              # every rank contributes to every round
+        for nr in plan.sizes:
+            cuts = [round_share(nr, plan.rounds, k) for k in range(plan.rounds)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == nr
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
