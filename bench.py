@@ -8,9 +8,14 @@ HIP path on synthetic data of BASELINE config 4 -- CSC 10M x 10k, 0.1 % nnz,
 family=binomial, alpha=0.5, lambda=1/n, intercept, standardize=FALSE -- with the
 sample order, the matrix, y and the solver state resident in HBM before the
 timed region.  For N > 1 the driver launches one process per GPU
-(torch.distributed.run); samples are sharded, and every epoch ends with one RCCL
-all-reduce of the packed state deltas (sgdnet_amd/parallel.py), so the total
-work is fixed as N grows ("strong" scaling).
+(torch.distributed.run) and the samples are sharded; the total work is fixed as N
+grows ("strong" scaling).  --merge selects the exchange (sgdnet_amd/parallel.py):
+  sync  (default) every global batch is split across the ranks and its scatter
+        accumulator is all-reduced (RCCL) before the sweep: the iterates are those of the
+        single-GPU run, so epochs-to-tolerance does not change with N;
+  epoch one all-reduce of the packed state deltas per epoch, w averaged (the scheme of
+        SURVEY.md 8e): cheap, but the `convergence` object shows it does not reach the
+        tolerance at this workload's lambda = 1/n.
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel
 (the batched gather kernel) by the algorithmic bytes of SURVEY.md 8d divided by
@@ -50,6 +55,9 @@ def main():
                     help="skip the epochs-to-tolerance leg (outside the timed region)")
     ap.add_argument("--conv-thresh", type=float, default=1e-6)
     ap.add_argument("--conv-max-epochs", type=int, default=400)
+    ap.add_argument("--merge", default="sync", choices=["sync", "epoch"],
+                    help="N > 1: per-batch all-reduce of the scatter accumulator (exact) or per-epoch "
+                         "averaged merge")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -64,7 +72,7 @@ def main():
     import torch
     import sgdnet_amd as sa
     from sgdnet_amd import data as D
-    from sgdnet_amd.parallel import HipShard, ShardedSaga, shard_bounds
+    from sgdnet_amd.parallel import HipShard, HipSyncShard, ShardedSaga, SyncShardedSaga, shard_bounds
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the SAGA backend has no CPU fallback")
@@ -125,7 +133,9 @@ def main():
     if world > 1:
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
     batch = args.batch if args.batch > 0 else sa.auto_batch(max_sq, float(cs.max()) / n)
-    batch = min(batch, n_local)
+    sync_mode = (world > 1 or force_merge) and args.merge == "sync"
+    if not sync_mode:
+        batch = min(batch, n_local)       # sync mode: `batch` is the GLOBAL staleness window
     note(f"gamma={gamma:.5g} batch={batch}")
     epochs_total = args.warmup + args.steps + 1                 # +1: the event-profiled epoch
     # sample order: R's Mersenne-Twister, set.seed(config id [+ rank])
@@ -139,9 +149,17 @@ def main():
     # device-ordered merge (no host sync inside an epoch) unless SGDNET_BENCH_FUSED=0
     fused = ((world > 1 or force_merge) and backend == "nccl"
              and os.environ.get("SGDNET_BENCH_FUSED", "1") == "1")
-    shard = HipShard(S, batch=batch, draws_per_epoch=n_local, device=torch.device("cuda", local_rank),
-                     stage_on_host=(backend != "nccl"), fused=fused)
-    job = ShardedSaga(shard, world, force_merge=force_merge)
+    dev = torch.device("cuda", local_rank)
+    if sync_mode:
+        shard = HipSyncShard(S, draws_per_epoch=n_local, device=dev, stage_on_host=(backend != "nccl"))
+        sjob = SyncShardedSaga(shard, n, world, batch, force_reduce=force_merge)
+
+        class job:                         # same call shape as ShardedSaga below
+            epoch = staticmethod(lambda: sjob.epoch(rank))
+    else:
+        shard = HipShard(S, batch=batch, draws_per_epoch=n_local, device=dev,
+                         stage_on_host=(backend != "nccl"), fused=fused)
+        job = ShardedSaga(shard, world, force_merge=force_merge)
 
     def fence():
         S.sync()
@@ -167,7 +185,10 @@ def main():
     note(f"timed region done: {elapsed:.4f}s")
     # dominant kernel, HIP events around every launch of one more epoch (same stream)
     off = shard.offset
-    prof = S.profile_epoch(batch=batch, stream_offset=off, draws_per_epoch=n_local)
+    # sync mode: this rank's share of a global batch, same (global-atomic) gather kernel as the
+    # timed region; the profiled epoch runs without the exchange, the state is reset below
+    local_batch = min(batch, n_local) if not sync_mode else max(1, -(-n_local // sjob.rounds))
+    prof = S.profile_epoch(batch=local_batch, stream_offset=off, draws_per_epoch=n_local)
     alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, stream[off:off + n_local], K)
     gather_s = prof["gather_ms"] * 1e-3
     achieved = alg_bytes_epoch / gather_s / 1e9
@@ -195,8 +216,10 @@ def main():
                         f"alpha={mix}, lambda=1/n, intercept, standardize=FALSE",
             "mode": "batched", "batch": batch, "samples_per_gpu": n_local,
             "sample_order": f"R MT19937 set.seed({seed}+rank), with replacement",
-            "merge": "none" if world == 1 else ("per-epoch RCCL all-reduce, w averaged"
-                                                 + (", stream-ordered" if fused else "")),
+            "merge": ("none" if world == 1 and not force_merge else
+                      f"sync: RCCL all-reduce of the scatter accumulator per global batch "
+                      f"({sjob.rounds} per epoch), stream-ordered" if sync_mode else
+                      "per-epoch RCCL all-reduce, w averaged" + (", stream-ordered" if fused else "")),
             "gen_s": round(t_gen, 2),
         },
         "roofline": {

@@ -5,6 +5,7 @@ CPU fallback: if the shared object is missing, loading raises.
 """
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsgdnet_hip.so")
@@ -83,13 +84,25 @@ class SgdnetError(RuntimeError):
 
 
 _lib = None
+# PyTorch-ROCm wheels bundle their own HIP/HSA runtime under the system's sonames.  Whichever of
+# torch and libsgdnet_hip.so is loaded first decides which runtime the process uses; loading the
+# library first and torch afterwards ends with two HSA runtimes and torch seeing no GPU.  Only the
+# multi-GPU plumbing (parallel.py) uses torch, and it checks this flag.
+loaded_before_torch = False
+
+
+def require_torch_first():
+    if loaded_before_torch:
+        raise RuntimeError("libsgdnet_hip.so was loaded before torch in this process: import torch "
+                           "before sgdnet_amd touches the device when using sgdnet_amd.parallel")
 
 
 def load():
     """Load libsgdnet_hip.so; raises if it has not been built (no fallback)."""
-    global _lib
+    global _lib, loaded_before_torch
     if _lib is not None:
         return _lib
+    loaded_before_torch = "torch" not in sys.modules
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} not found: run ./build.sh (or __graft_entry__.build()); "
                       "the SAGA backend has no CPU fallback")

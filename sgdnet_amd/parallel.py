@@ -48,6 +48,9 @@ class HipShard:
     def __init__(self, solver, *, batch, draws_per_epoch, device, stage_on_host=False, fused=False):
         import torch
 
+        from . import _lib
+        _lib.require_torch_first()
+
         self.solver = solver
         self.batch = batch
         self.draws = draws_per_epoch
@@ -125,6 +128,9 @@ class HipSyncShard:
 
     def __init__(self, solver, *, draws_per_epoch, device, stage_on_host=False):
         import torch
+
+        from . import _lib
+        _lib.require_torch_first()
 
         self.solver = solver
         self.draws = draws_per_epoch

@@ -21,6 +21,7 @@ TOL_EXACT, TOL_BATCHED = 1e-10, 1e-9
 
 @pytest.fixture(scope="module")
 def sa():
+    import torch  # noqa: F401  -- before libsgdnet_hip.so: one HIP runtime per process (sgdnet_amd/_lib.py)
     import sgdnet_amd
     if sgdnet_amd.load().sgdnet_device_count() < 1:
         pytest.fail("GPU tests need a HIP device; the backend has no CPU fallback")
@@ -476,3 +477,109 @@ def test_fit_edge_cases(sa, oracle):
     ref_b = oracle.fit(xs[:40], yb[:40], family="binomial", lambda_=[0.01], standardize=False, seed=2,
                        batch=40, thresh=1e-9, maxit=3000)
     assert fit_b.npasses == ref_b["npasses"] and relerr(fit_b.beta[:, 0], ref_b["beta"][0, :, 0]) < 1e-8
+
+
+# ---------------------------------------------------------------------------------------------
+# Synchronous sample-sharded mode (sgdnet_solver_sync_*, sgdnet_amd/parallel.py)
+# ---------------------------------------------------------------------------------------------
+def _oracle_sync_rounds(oracle, x, y, K, plan, histories, lows, kw, c=None):
+    """Single-process restatement: per global batch, gather over the ranks' draws, then sweep."""
+    from sgdnet_amd.parallel import round_share
+    p, n = x.shape
+    st = oracle.new_state(K, p, n)
+    Dm, d0 = np.zeros((K, p), order="F"), np.zeros(K)
+    for e in range(len(histories[0])):
+        for k in range(plan.rounds):
+            draws = np.concatenate([
+                histories[r][e][slice(*round_share(plan.sizes[r], plan.rounds, k))].astype(np.int64) + lows[r]
+                for r in range(len(histories))]).astype(np.uint32)
+            oracle.batch_gather(x, y, st, draws, Dm, d0, x_center_scaled=c, **kw)
+            oracle.batch_sweep((p, n), st, draws.size, Dm, d0, x_center_scaled=c, **kw)
+    return st
+
+
+@pytest.mark.parametrize("family,K,penalty,centre", [
+    ("binomial", 1, "elasticnet", False), ("multinomial", 3, "elasticnet", False),
+    ("mgaussian", 2, "grouplasso", False), ("binomial", 1, "elasticnet", True)])
+def test_sync_mode_single_rank_matches_oracle_rounds(sa, oracle, family, K, penalty, centre):
+    import torch
+    from sgdnet_amd.parallel import HipSyncShard, SyncShardedSaga
+    n, p, epochs, batch = 2500, 120, 3, 333        # 333 does not divide 2500: rounds of 312/313 draws
+    x, y = make_problem(family, K, n, p, 0.06, seed=23)
+    c = np.random.default_rng(2).normal(0.05, 0.1, p) if centre else None
+    kw = dict(family=family, penalty=penalty, gamma=0.004, alpha=1e-3, beta=2e-3, n_total=n)
+    stream = oracle.Rng(9).stream(n, n * epochs)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K, x_center_scaled=c)
+    S.set_penalty(penalty, 0.004, 1e-3, 2e-3)
+    S.upload_stream(stream)
+    shard = HipSyncShard(S, draws_per_epoch=n, device=torch.device("cuda", 0))
+    job = SyncShardedSaga(shard, n, 1, batch)
+    for _ in range(epochs):
+        job.epoch(0)
+    S.sync()
+    got = {k: S.get(k) for k in STATE}
+    st = _oracle_sync_rounds(oracle, x, y, K, job, [stream.reshape(epochs, n)], [0], kw, c)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_BATCHED, k
+    # unbinding restores the ordinary batched path on the same solver
+    shard.close()
+    S.set("w", np.zeros((K, p))); S.set("g_sum", np.zeros((K, p))); S.set("g_memory", np.zeros((K, n)))
+    S.set("intercept", np.zeros(K)); S.set("g_sum_intercept", np.zeros(K))
+    S.run(mode="batched", batch=batch, max_epochs=2, tol=0.0)
+    st2 = oracle.new_state(K, p, n)
+    oracle.saga(x, y, st2, family=family, penalty=penalty, gamma=0.004, alpha=1e-3, beta=2e-3,
+                standardize=centre, x_center_scaled=c, max_iter=2, tol=0.0, stream=stream, batch=batch)
+    for k in STATE:
+        assert relerr(S.get(k), st2[k]) < TOL_BATCHED, k
+    S.close()
+
+
+def _gpu_sync_worker(rank, world, port, epochs, outdir, n, p, batch):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch                      # before sgdnet_amd: one HIP runtime per process
+    import torch.distributed as dist
+    import sgdnet_amd as sa
+    from sgdnet_amd import data as D
+    from sgdnet_amd.parallel import HipSyncShard, SyncShardedSaga, shard_bounds
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lo, hi = shard_bounds(n, world, rank)
+    pr = D.make_sparse_glm(n, p, 0.05, family="binomial", seed=31, lo=lo, hi=hi)
+    nl = hi - lo
+    stream = sa.RRng(40 + rank).stream(nl, nl * epochs)
+    S = sa.SagaSolver(D.as_scipy(pr), pr["y"], family="binomial", n_classes=1, n_total=n)
+    S.set_penalty("elasticnet", 0.01, 1e-5, 1e-5)
+    S.upload_stream(stream)
+    shard = HipSyncShard(S, draws_per_epoch=nl, device=torch.device("cuda", 0), stage_on_host=True)
+    job = SyncShardedSaga(shard, n, world, batch)
+    for _ in range(epochs):
+        job.epoch(rank)
+    S.sync()
+    np.savez(os.path.join(outdir, f"r{rank}.npz"), stream=stream.reshape(epochs, nl),
+             **{k: S.get(k) for k in STATE})
+    S.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_sync_mode_two_ranks_on_one_gpu_equal_the_single_process_iteration(sa, oracle, tmp_path):
+    # two processes share cuda:0 and reduce through gloo (host staging); the replicated state must
+    # equal the single-process batched iteration over the interleaved sample order
+    import socket
+    import torch.multiprocessing as mp
+    from sgdnet_amd import data as D
+    from sgdnet_amd.parallel import SyncShardedSaga, shard_bounds
+    n, p, epochs, batch, world = 6001, 150, 3, 500, 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_gpu_sync_worker, args=(world, port, epochs, str(tmp_path), n, p, batch), nprocs=world, join=True)
+    out = [np.load(tmp_path / f"r{r}.npz") for r in range(world)]
+    pr = D.make_sparse_glm(n, p, 0.05, family="binomial", seed=31)
+    plan = SyncShardedSaga(None, n, world, batch)
+    lows = [shard_bounds(n, world, r)[0] for r in range(world)]
+    kw = dict(family="binomial", penalty="elasticnet", gamma=0.01, alpha=1e-5, beta=1e-5, n_total=n)
+    st = _oracle_sync_rounds(oracle, D.as_scipy(pr), pr["y"], 1, plan, [o["stream"] for o in out], lows, kw)
+    for k in ("w", "intercept", "g_sum", "g_sum_intercept"):
+        assert np.array_equal(out[0][k], out[1][k]), k
+        assert relerr(out[0][k], st[k]) < TOL_BATCHED, k
+    mem = np.concatenate([o["g_memory"] for o in out], axis=1)
+    assert relerr(mem, st["g_memory"]) < TOL_BATCHED
