@@ -217,9 +217,10 @@ def main():
             "mode": "batched", "batch": batch, "samples_per_gpu": n_local,
             "sample_order": f"R MT19937 set.seed({seed}+rank), with replacement",
             "merge": ("none" if world == 1 and not force_merge else
-                      f"sync: RCCL all-reduce of the scatter accumulator per global batch "
-                      f"({sjob.rounds} per epoch), stream-ordered" if sync_mode else
-                      "per-epoch RCCL all-reduce, w averaged" + (", stream-ordered" if fused else "")),
+                      f"sync: {backend} all-reduce of the scatter accumulator per global batch "
+                      f"({sjob.rounds} per epoch)" + (", stream-ordered" if backend == "nccl" else "")
+                      if sync_mode else
+                      f"per-epoch {backend} all-reduce, w averaged" + (", stream-ordered" if fused else "")),
             "gen_s": round(t_gen, 2),
         },
         "roofline": {

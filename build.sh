@@ -8,7 +8,7 @@ OUT=sgdnet_amd/lib
 mkdir -p "$OUT" build
 # -ffp-contract=off: the exact-order kernels follow the reference's arithmetic
 # order without fused multiply-adds.
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -I$SRC -Wall -Wno-unused-function"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -I$SRC -Wall -Wno-unused-function ${EXTRA_FLAGS:-}"
 pids=()
 for f in saga_exact.hip saga_batched.hip r_rng_device.hip setup_device.hip solver.cpp driver.cpp r_rng.cpp; do
   o=build/${f%.*}.o

@@ -34,6 +34,7 @@ struct SagaDev {
   int64_t p;     // features
   double n_total;  // samples of the whole job (the 1/n of the gradient average)
   float avg_nnz;   // mean non-zeros per sample (sparse)
+  unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
   int force_global;  // synchronous sharded mode: always the global-atomic gather (D must be one array)
   int ablate;      // SGDNET_ABLATE bit mask: timing-only builds of the gather (results are wrong)
   // data, sample-major (SURVEY.md 8a "x")

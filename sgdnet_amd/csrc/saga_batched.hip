@@ -328,11 +328,34 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
 // `cap` slots are always readable (zero padded), so the idx/val loads do not wait
 // for the header.
 // --------------------------------------------------------------------------
+#ifdef SGDNET_PHASE_TIMING
+// development aid (never in the product build): shader-clock stamps after all outstanding
+// memory operations of the wave have returned
+__device__ __forceinline__ unsigned long long phase_stamp() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define PHASE(slot)                                                                      \
+  do {                                                                                    \
+    if (d.dbg && threadIdx.x == 0) d.dbg[(size_t)blockIdx.x * 16 + (slot)] = phase_stamp(); \
+  } while (0)
+#define PHASE_FIRST(slot)                                                                 \
+  do {                                                                                    \
+    if (d.dbg && threadIdx.x == 0 && stamp) d.dbg[(size_t)blockIdx.x * 16 + (slot)] = phase_stamp(); \
+  } while (0)
+#else
+#define PHASE(slot) ((void)0)
+#define PHASE_FIRST(slot) ((void)0)
+#endif
+
 template <int U>
 __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint32_t* sp, const int i,
                                                     const int hi, const int step, const int gl,
-                                                    const double b0, double* Dl) {
+                                                    const int batch_id, const double b0, double* Dl,
+                                                    const double* wv, const bool stamp) {
   const int cap = d.rec_cap;
+  PHASE_FIRST(6);
   uint32_t s[U];
   bool valid[U];
 #pragma unroll
@@ -342,6 +365,7 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
     s[u] = sp[valid[u] ? iu : i];
     if (d.ablate & 16) s[u] &= 1023u;           // timing only: records from a cache-resident set
   }
+  PHASE_FIRST(7);
   const char* base[U];
   double y0[U], vf[U];
   int nnz[U], ovf[U], jf[U];
@@ -354,6 +378,22 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
     jf[u] = gl < cap ? reinterpret_cast<const int*>(base[u] + 16)[gl] : 0;
     vf[u] = gl < cap ? reinterpret_cast<const double*>(base[u] + d.rec_val_off)[gl] : 0.0;
   }
+  PHASE_FIRST(8);
+  // claim + old gradient memory: depend on the index only, but are issued AFTER the record loads
+  // because a wave's loads and returning atomics come back in issue order -- the atomic is the
+  // longest round trip of a draw (memory-side, ~4 us under load) and now overlaps the w gather
+  // instead of delaying the record
+  int prev[U];
+  double mold[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    prev[u] = batch_id;
+    mold[u] = 0.0;
+    if (gl == 0 && valid[u] && !(d.ablate & 1)) {
+      prev[u] = __hip_atomic_exchange(d.claim + s[u], batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mold[u] = d.M[s[u]];
+    }
+  }
   double acc[U];
   bool in[U], tail[U];
 #pragma unroll
@@ -361,16 +401,17 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
     const int cnt0 = nnz[u] < cap ? nnz[u] : cap;
     in[u] = valid[u] && gl < cnt0 && gl < kGroup;
     tail[u] = valid[u] && (nnz[u] > cnt0 || cnt0 > kGroup);
-    acc[u] = in[u] ? vf[u] * ((d.ablate & 8) ? 1.0 : d.w[jf[u]]) : 0.0;
+    acc[u] = in[u] ? vf[u] * ((d.ablate & 8) ? 1.0 : wv[jf[u]]) : 0.0;
   }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (tail[u]) {
       double a = 0.0;
-      row_tail_for_each(d, base[u], nnz[u], ovf[u], gl, [&](int64_t j, double v) { a += v * d.w[j]; });
+      row_tail_for_each(d, base[u], nnz[u], ovf[u], gl, [&](int64_t j, double v) { a += v * wv[j]; });
       acc[u] += a;
     }
   }
+  PHASE_FIRST(9);
   double g0[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -382,15 +423,15 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
   for (int u = 0; u < U; ++u) {
     gcv[u] = 0.0;
     if (gl == 0 && valid[u]) {
-      if (d.ablate & 1) {                      // timing only: no gradient-memory exchange
+      if (d.ablate & 1) {                      // timing only: no gradient-memory update
         gcv[u] = g0[u];
-      } else {
-        const double old =
-            __hip_atomic_exchange(d.M + s[u], g0[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        gcv[u] = g0[u] - old;
+      } else if (prev[u] != batch_id) {        // first draw of this sample in the batch
+        gcv[u] = g0[u] - mold[u];
+        d.M[s[u]] = g0[u];
       }
     }
   }
+  PHASE_FIRST(10);
   double tot = 0.0;
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -403,6 +444,7 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
     }
     tot += gcv[u];
   }
+  PHASE_FIRST(11);
   return tot;   // non-zero on lane 0 of the group only
 }
 
@@ -416,7 +458,10 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
 // --------------------------------------------------------------------------
 constexpr int kLdsBlock = 1024;
 
-template <int KMAX>
+// kWLds (K == 1, 2*p doubles fit the CU's LDS): the coefficient snapshot is staged next to the
+// accumulator, so the x.w gather -- 64 distinct addresses per wave instruction, which the
+// vector-memory address unit serves at about one lane per clock -- becomes ds_read_b64.
+template <int KMAX, bool kWLds = false>
 __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDev d, const LamParams* lamp,
                                                                           int64_t t0_in_epoch, int m,
                                                                           int batch_id_offset,
@@ -424,8 +469,12 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   const int K = KMAX == 1 ? 1 : d.K;
   const int64_t KP = (int64_t)K * d.p;
+  PHASE(0);
   for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) Dl[i] = 0.0;
+  if (kWLds)
+    for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) Dl[KP + i] = d.w[i];
   __syncthreads();
+  PHASE(1);
 
   const int gl = threadIdx.x & (kGroup - 1);
   const int group = threadIdx.x / kGroup;
@@ -443,9 +492,13 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   if (d.standardize) cw_clear_next(d, batch_id);
   constexpr int kGroups = kLdsBlock / kGroup;
   if (KMAX == 1) {
-    constexpr int U = 4;
+#ifndef SGDNET_PIPE
+#define SGDNET_PIPE 4
+#endif
+    constexpr int U = SGDNET_PIPE;
     for (int i = lo + group; i < hi; i += kGroups * U)
-      gct[0] += saga_draws_k1_lds<U>(d, d.stream + t0, i, hi, kGroups, gl, bk[0], Dl);
+      gct[0] += saga_draws_k1_lds<U>(d, d.stream + t0, i, hi, kGroups, gl, batch_id, bk[0], Dl,
+                                     kWLds ? Dl + KP : d.w, i == lo);
   } else {
     for (int i = lo + group; i < hi; i += kGroups) {
       double gc[KMAX];
@@ -454,14 +507,18 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
       for (int k = 0; k < KMAX; ++k) gct[k] += gc[k];
     }
   }
+  PHASE(2);
   __syncthreads();
+  PHASE(3);
 
   // flush the private copy as this workgroup's slab: plain coalesced stores (atomics would
   // cap the flush at the ~1.3 TB/s atomic rate); the sweep sums the slabs in a fixed order
   double* slab = d.slab + (int64_t)blockIdx.x * KP;
   if (!(d.ablate & 2))
     for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
+  PHASE(4);
   if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kLdsBlock>(d, K, batch_id, gct);
+  PHASE(5);
 }
 
 // --------------------------------------------------------------------------
@@ -929,10 +986,13 @@ int batched_max_classes() { return 16; }
 // draws per workgroup to amortise its flush.
 struct GatherPlan {
   bool lds;
+  bool w_lds;   // K == 1: the coefficient snapshot is staged in LDS as well
   int grid;
   int draws_per_block;
   size_t lds_bytes;
 };
+constexpr size_t kLdsPerCu = 160 * 1024;        // gfx950
+constexpr size_t kLdsStaticReserve = 2 * 1024;  // static __shared__ of the LDS gather kernels
 
 static GatherPlan plan_gather(const SagaDev& d, int m) {
   GatherPlan g{};
@@ -957,6 +1017,9 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     g.draws_per_block = dpb;
     g.grid = (m + dpb - 1) / dpb;
     g.lds_bytes = table;
+    static const bool w_lds_on = [] { const char* e = getenv("SGDNET_W_LDS"); return !e || atoi(e) != 0; }();
+    g.w_lds = d.K == 1 && w_lds_on && 2 * table + kLdsStaticReserve <= kLdsPerCu;
+    if (g.w_lds) g.lds_bytes = 2 * table;
   } else {
     g.draws_per_block = kBlock / kGroup;
     g.grid = (m + g.draws_per_block - 1) / g.draws_per_block;
@@ -990,6 +1053,9 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
     static bool attr_done = false;
     if (!attr_done) {
       const int cap = 96 * 1024;   // the dense table is limited to 80 KiB (plan_gather)
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      kLdsPerCu - kLdsStaticReserve));
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<4>),
@@ -998,7 +1064,10 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
       attr_done = true;
     }
-    if (d.K == 1)
+    if (d.K == 1 && g.w_lds)
+      hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<1, true>), dim3(g.grid), dim3(kLdsBlock), g.lds_bytes,
+                            st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    else if (d.K == 1)
       hipExtLaunchKernelGGL(saga_batch_gather_lds_kernel<1>, dim3(g.grid), dim3(kLdsBlock), g.lds_bytes, st,
                             ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
     else if (d.K <= 4)

@@ -458,6 +458,10 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
   d.p = pb->n_features;
   d.n_total = (double)(pb->n_total > 0 ? pb->n_total : pb->n_samples);
   d.ablate = getenv("SGDNET_ABLATE") ? atoi(getenv("SGDNET_ABLATE")) : 0;
+#ifdef SGDNET_PHASE_TIMING
+  if (hipMalloc(&d.dbg, sizeof(unsigned long long) * 16 * 4096) != hipSuccess) d.dbg = nullptr;
+  if (d.dbg) (void)hipMemset(d.dbg, 0, sizeof(unsigned long long) * 16 * 4096);
+#endif
 
   const size_t n = (size_t)d.n, p = (size_t)d.p, K = (size_t)d.K;
   int rc = SGDNET_OK;
@@ -883,6 +887,34 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
     ++ng;
   }
   for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+#ifdef SGDNET_PHASE_TIMING
+  if (s->d.dbg) {   // stamps of the epoch's last gather launch (the tail batch unless batch divides the epoch)
+    std::vector<unsigned long long> t(16 * 256);
+    SGD_HIP_TRY(hipMemcpy(t.data(), s->d.dbg, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
+    unsigned long long first = ~0ull, last = 0;
+    for (int b = 0; b < 256; ++b) {
+      if (t[b * 16] && t[b * 16] < first) first = t[b * 16];
+      if (t[b * 16 + 5] > last) last = t[b * 16 + 5];
+    }
+    static const char* nm[11] = {"lds zero+sync", "draw loop", "barrier", "slab flush", "d0 partial", "",
+                                 "stream idx", "record loads", "w gather", "M exchange", "scatter"};
+    fprintf(stderr, "[phase] kernel span %.2f us (memtime ticks at 100 MHz)\n", (double)(last - first) / 100.0);
+    double start_spread = 0;
+    for (int b = 0; b < 256; ++b) if (t[b * 16]) start_spread = std::max(start_spread, (double)(t[b * 16] - first));
+    fprintf(stderr, "[phase] workgroup start spread %.2f us\n", start_spread / 100.0);
+    for (int ph = 0; ph < 11; ++ph) {
+      if (ph == 5) continue;
+      const int a = ph < 5 ? ph : ph, bslot = a + 1;
+      double sum = 0, mx = 0; int cnt = 0;
+      for (int b = 0; b < 256; ++b) {
+        if (!t[b * 16 + a] || !t[b * 16 + bslot]) continue;
+        const double dt = (double)(t[b * 16 + bslot] - t[b * 16 + a]) / 100.0;
+        sum += dt; mx = std::max(mx, dt); ++cnt;
+      }
+      if (cnt) fprintf(stderr, "[phase] %-14s mean %6.2f us max %6.2f us\n", nm[ph], sum / cnt, mx);
+    }
+  }
+#endif
   if (gather_ms) *gather_ms = g;
   if (gather_launches) *gather_launches = ng;
   if (sweep_ms) *sweep_ms = w;

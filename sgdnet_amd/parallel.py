@@ -158,8 +158,16 @@ class HipSyncShard:
             self.buf.copy_(self.host)
             torch.cuda.synchronize()
             return
-        with torch.cuda.stream(self.ext):     # ordered between gather and sweep on the solver's stream
-            dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+        # the caller holds reduce_context(): the collective is issued on the solver's stream,
+        # ordered between this batch's gather and sweep with no host synchronisation
+        dist.all_reduce(self.buf, op=dist.ReduceOp.SUM, group=group)
+
+    def reduce_context(self):
+        import contextlib
+
+        import torch
+
+        return contextlib.nullcontext() if self.host is not None else torch.cuda.stream(self.ext)
 
     def sync_sweep(self, m_global, m_local, rnd):
         self.solver.sync_sweep(m_global, m_local, rnd)
@@ -201,13 +209,18 @@ class SyncShardedSaga:
     def epoch(self, rank):
         sh, R = self.shard, self.rounds
         n_local = self.sizes[rank]
+        import contextlib
+
+        reduce = self.world > 1 or self.force_reduce
+        ctx = getattr(sh, "reduce_context", None) if reduce else None
         sh.sync_begin()
-        for k in range(R):
-            lo, hi = round_share(n_local, R, k)
-            sh.sync_gather(lo, hi - lo, k)
-            if self.world > 1 or self.force_reduce:
-                sh.sync_reduce(self.group)
-            sh.sync_sweep(self.m_global[k], hi - lo, k)
+        with (ctx() if ctx else contextlib.nullcontext()):   # entered once per epoch, not per batch
+            for k in range(R):
+                lo, hi = round_share(n_local, R, k)
+                sh.sync_gather(lo, hi - lo, k)
+                if reduce:
+                    sh.sync_reduce(self.group)
+                sh.sync_sweep(self.m_global[k], hi - lo, k)
         sh.sync_end(R)
 
 
