@@ -9,6 +9,8 @@ mkdir -p "$OUT" build
 # -ffp-contract=off: the exact-order kernels follow the reference's arithmetic
 # order without fused multiply-adds.
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -I$SRC -Wall -Wno-unused-function ${EXTRA_FLAGS:-}"
+# objects are rebuilt when the flags change (e.g. EXTRA_FLAGS=-DSGDNET_PHASE_TIMING experiments)
+if [ ! -f build/.flags ] || [ "$(cat build/.flags)" != "$FLAGS" ]; then rm -f build/*.o; echo "$FLAGS" > build/.flags; fi
 pids=()
 for f in saga_exact.hip saga_batched.hip r_rng_device.hip setup_device.hip solver.cpp driver.cpp r_rng.cpp; do
   o=build/${f%.*}.o

@@ -321,10 +321,10 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
 }
 
 // --------------------------------------------------------------------------
-// K == 1 software pipeline for the LDS-privatised gather: a 16-lane group keeps U
-// draws in flight.  The source is ordered in phases (stream -> records -> w ->
+// K == 1 software pipeline for the LDS-privatised gather: a 16-lane group keeps 2*U
+// draws in flight.  The source is ordered in phases (stream -> records -> x.w ->
 // gradient -> gradient-memory exchange -> LDS scatter) with no atomic between the
-// loads of a phase, so the U round trips of every phase overlap.  A record's first
+// loads of a phase, so the round trips of every phase overlap.  A record's first
 // `cap` slots are always readable (zero padded), so the idx/val loads do not wait
 // for the header.
 // --------------------------------------------------------------------------
@@ -349,104 +349,93 @@ __device__ __forceinline__ unsigned long long phase_stamp() {
 #define PHASE_FIRST(slot) ((void)0)
 #endif
 
+// One pipeline stage set for U draws of a 16-lane group (K == 1).
 template <int U>
-__device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint32_t* sp, const int i,
-                                                    const int hi, const int step, const int gl,
-                                                    const int batch_id, const double b0, double* Dl,
-                                                    const double* wv, const bool stamp) {
-  const int cap = d.rec_cap;
-  PHASE_FIRST(6);
+struct K1Draws {
   uint32_t s[U];
+  int jf[U], nnz[U];
+  double vf[U], y0[U], gcv[U];
   bool valid[U];
+
+  // stream indices + record loads (nothing waits here)
+  // `safe` < hi: the draw whose (discarded) record stands in for positions past the end
+  __device__ __forceinline__ void load(const SagaDev& d, const uint32_t* sp, int i, int hi, int step, int gl,
+                                       int safe) {
+    const int cap = d.rec_cap;
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int iu = i + u * step;
-    valid[u] = iu < hi;
-    s[u] = sp[valid[u] ? iu : i];
-    if (d.ablate & 16) s[u] &= 1023u;           // timing only: records from a cache-resident set
-  }
-  PHASE_FIRST(7);
-  const char* base[U];
-  double y0[U], vf[U];
-  int nnz[U], ovf[U], jf[U];
+    for (int u = 0; u < U; ++u) {
+      const int iu = i + u * step;
+      valid[u] = iu < hi;
+      s[u] = sp[valid[u] ? iu : safe];
+      if (d.ablate & 16) s[u] &= 1023u;         // timing only: records from a cache-resident set
+    }
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    base[u] = d.rec + (size_t)s[u] * d.rec_stride;
-    y0[u] = *reinterpret_cast<const double*>(base[u]);
-    nnz[u] = *reinterpret_cast<const int*>(base[u] + 8);
-    ovf[u] = *reinterpret_cast<const int*>(base[u] + 12);
-    jf[u] = gl < cap ? reinterpret_cast<const int*>(base[u] + 16)[gl] : 0;
-    vf[u] = gl < cap ? reinterpret_cast<const double*>(base[u] + d.rec_val_off)[gl] : 0.0;
-  }
-  PHASE_FIRST(8);
-  // claim + old gradient memory: depend on the index only, but are issued AFTER the record loads
-  // because a wave's loads and returning atomics come back in issue order -- the atomic is the
-  // longest round trip of a draw (memory-side, ~4 us under load) and now overlaps the w gather
-  // instead of delaying the record
-  int prev[U];
-  double mold[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    prev[u] = batch_id;
-    mold[u] = 0.0;
-    if (gl == 0 && valid[u] && !(d.ablate & 1)) {
-      prev[u] = __hip_atomic_exchange(d.claim + s[u], batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      mold[u] = d.M[s[u]];
+    for (int u = 0; u < U; ++u) {
+      const char* base = d.rec + (size_t)s[u] * d.rec_stride;
+      y0[u] = *reinterpret_cast<const double*>(base);
+      nnz[u] = *reinterpret_cast<const int*>(base + 8);
+      jf[u] = gl < cap ? reinterpret_cast<const int*>(base + 16)[gl] : 0;
+      vf[u] = gl < cap ? reinterpret_cast<const double*>(base + d.rec_val_off)[gl] : 0.0;
     }
   }
-  double acc[U];
-  bool in[U], tail[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int cnt0 = nnz[u] < cap ? nnz[u] : cap;
-    in[u] = valid[u] && gl < cnt0 && gl < kGroup;
-    tail[u] = valid[u] && (nnz[u] > cnt0 || cnt0 > kGroup);
-    acc[u] = in[u] ? vf[u] * ((d.ablate & 8) ? 1.0 : wv[jf[u]]) : 0.0;
+  __device__ __forceinline__ bool in(const SagaDev& d, int u, int gl) const {
+    const int cnt0 = nnz[u] < d.rec_cap ? nnz[u] : d.rec_cap;
+    return valid[u] && gl < cnt0 && gl < kGroup;
   }
+  __device__ __forceinline__ bool tail(const SagaDev& d, int u) const {
+    const int cnt0 = nnz[u] < d.rec_cap ? nnz[u] : d.rec_cap;
+    return valid[u] && (nnz[u] > cnt0 || cnt0 > kGroup);
+  }
+  template <class F>
+  __device__ __forceinline__ void tail_for_each(const SagaDev& d, int u, int gl, F f) const {
+    const char* base = d.rec + (size_t)s[u] * d.rec_stride;
+    row_tail_for_each(d, base, nnz[u], *reinterpret_cast<const int*>(base + 12), gl, f);
+  }
+  // x.w, gradient, and the gradient-memory exchange (issued, not waited for)
+  __device__ __forceinline__ void gradient(const SagaDev& d, int gl, double b0, const double* wv) {
+    double acc[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    if (tail[u]) {
-      double a = 0.0;
-      row_tail_for_each(d, base[u], nnz[u], ovf[u], gl, [&](int64_t j, double v) { a += v * wv[j]; });
-      acc[u] += a;
+    for (int u = 0; u < U; ++u) acc[u] = in(d, u, gl) ? vf[u] * ((d.ablate & 8) ? 1.0 : wv[jf[u]]) : 0.0;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (tail(d, u)) {
+        double a = 0.0;
+        tail_for_each(d, u, gl, [&](int64_t j, double v) { a += v * wv[j]; });
+        acc[u] += a;
+      }
     }
-  }
-  PHASE_FIRST(9);
-  double g0[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const double lp = group_sum(acc[u]) + b0;
-    g0[u] = d.family == SGDNET_BINOMIAL ? 1.0 - y0[u] - 1.0 / (1.0 + exp(lp)) : lp - y0[u];
-  }
-  double gcv[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    gcv[u] = 0.0;
-    if (gl == 0 && valid[u]) {
-      if (d.ablate & 1) {                      // timing only: no gradient-memory update
-        gcv[u] = g0[u];
-      } else if (prev[u] != batch_id) {        // first draw of this sample in the batch
-        gcv[u] = g0[u] - mold[u];
-        d.M[s[u]] = g0[u];
+    for (int u = 0; u < U; ++u) {
+      const double lp = group_sum(acc[u]) + b0;
+      const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y0[u] - 1.0 / (1.0 + exp(lp)) : lp - y0[u];
+      gcv[u] = 0.0;
+      if (gl == 0 && valid[u]) {
+        if (d.ablate & 1) {                      // timing only: no gradient-memory exchange
+          gcv[u] = g0;
+        } else {
+          // claim, read and update in ONE returning atomic: a repeated draw of the batch reads
+          // back the value just stored (same snapshot, same g0), so its gc is exactly 0
+          const double old = __hip_atomic_exchange(d.M + s[u], g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          gcv[u] = g0 - old;
+        }
       }
     }
   }
-  PHASE_FIRST(10);
-  double tot = 0.0;
+  // LDS scatter of x * gc; returns the sum of gc (lane 0 of the group only)
+  __device__ __forceinline__ double scatter(const SagaDev& d, int gl, double* Dl) const {
+    double tot = 0.0;
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const double gc = __shfl(gcv[u], 0, kGroup);
-    if (gc != 0.0 && !(d.ablate & 4)) {
-      if (in[u]) scatter_add<true>(Dl + jf[u], vf[u] * gc);
-      if (tail[u])
-        row_tail_for_each(d, base[u], nnz[u], ovf[u], gl,
-                          [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
+    for (int u = 0; u < U; ++u) {
+      const double gc = __shfl(gcv[u], 0, kGroup);
+      if (gc != 0.0 && !(d.ablate & 4)) {
+        if (in(d, u, gl)) scatter_add<true>(Dl + jf[u], vf[u] * gc);
+        if (tail(d, u)) tail_for_each(d, u, gl, [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
+      }
+      tot += gcv[u];
     }
-    tot += gcv[u];
+    return tot;
   }
-  PHASE_FIRST(11);
-  return tot;   // non-zero on lane 0 of the group only
-}
+};
 
 // --------------------------------------------------------------------------
 // gather, LDS-privatised scatter ("LDS staging of the gradient-average slice"):
@@ -456,7 +445,10 @@ __device__ __forceinline__ double saga_draws_k1_lds(const SagaDev& d, const uint
 // wave hit one 64-B line, so a workgroup issues at most K*p/8 atomic requests
 // instead of one per non-zero.
 // --------------------------------------------------------------------------
-constexpr int kLdsBlock = 1024;
+#ifndef SGDNET_LDS_BLOCK
+#define SGDNET_LDS_BLOCK 1024
+#endif
+constexpr int kLdsBlock = SGDNET_LDS_BLOCK;
 
 // kWLds (K == 1, 2*p doubles fit the CU's LDS): the coefficient snapshot is staged next to the
 // accumulator, so the x.w gather -- 64 distinct addresses per wave instruction, which the
@@ -471,8 +463,24 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   const int64_t KP = (int64_t)K * d.p;
   PHASE(0);
   for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) Dl[i] = 0.0;
-  if (kWLds)
-    for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) Dl[KP + i] = d.w[i];
+  if (kWLds) {
+    // all loads of a thread in flight before the first LDS store (a plain copy loop waits
+    // for every load in turn: 2.4 us instead of 0.5 us for 80 KB)
+    constexpr int kStage = 4;
+    for (int64_t i0 = threadIdx.x; i0 < KP; i0 += (int64_t)kLdsBlock * kStage) {
+      double t[kStage];
+#pragma unroll
+      for (int r = 0; r < kStage; ++r) {
+        const int64_t i = i0 + (int64_t)r * kLdsBlock;
+        t[r] = i < KP ? d.w[i] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < kStage; ++r) {
+        const int64_t i = i0 + (int64_t)r * kLdsBlock;
+        if (i < KP) Dl[KP + i] = t[r];
+      }
+    }
+  }
   __syncthreads();
   PHASE(1);
 
@@ -492,13 +500,27 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   if (d.standardize) cw_clear_next(d, batch_id);
   constexpr int kGroups = kLdsBlock / kGroup;
   if (KMAX == 1) {
+    // Two half-passes of U draws per group, software-pipelined: a wave's loads and returning
+    // atomics come back in issue order, so the order below keeps the second half's records
+    // and the first half's exchanges in flight together (chip-wide, every phase of this
+    // kernel is a burst on one resource -- HBM for the records, the memory-side atomic units
+    // for the exchange -- and the bursts of the two halves now overlap instead of queueing):
+    //   load A, load B | gradient A (+exchange A) | gradient B (+exchange B) | scatter A | scatter B
 #ifndef SGDNET_PIPE
-#define SGDNET_PIPE 4
+#define SGDNET_PIPE 2
 #endif
     constexpr int U = SGDNET_PIPE;
-    for (int i = lo + group; i < hi; i += kGroups * U)
-      gct[0] += saga_draws_k1_lds<U>(d, d.stream + t0, i, hi, kGroups, gl, batch_id, bk[0], Dl,
-                                     kWLds ? Dl + KP : d.w, i == lo);
+    const double* wv = kWLds ? Dl + KP : d.w;
+    const uint32_t* sp = d.stream + t0;
+    for (int i = lo + group; i < hi; i += 2 * kGroups * U) {
+      K1Draws<U> A, B;
+      A.load(d, sp, i, hi, kGroups, gl, i);
+      B.load(d, sp, i + kGroups * U, hi, kGroups, gl, i);
+      A.gradient(d, gl, bk[0], wv);
+      B.gradient(d, gl, bk[0], wv);
+      gct[0] += A.scatter(d, gl, Dl);
+      gct[0] += B.scatter(d, gl, Dl);
+    }
   } else {
     for (int i = lo + group; i < hi; i += kGroups) {
       double gc[KMAX];
@@ -604,11 +626,11 @@ __device__ __forceinline__ double saga_draw_classlane(const SagaDev& d, const ui
 }
 
 template <bool kLds>
-__global__ __launch_bounds__(kLds ? 1024 : kBlock) void saga_batch_gather_cl_kernel(
+__global__ __launch_bounds__(kLds ? kLdsBlock : kBlock) void saga_batch_gather_cl_kernel(
     SagaDev d, const LamParams* lamp, int64_t t0_in_epoch, int m, int batch_id_offset, int draws_per_block) {
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   __shared__ double d0s[16];
-  constexpr int kThreads = kLds ? 1024 : kBlock;
+  constexpr int kThreads = kLds ? kLdsBlock : kBlock;
   const int K = d.K;
   const int64_t KP = (int64_t)K * d.p;
   const int gl = threadIdx.x & (kGroup - 1);
