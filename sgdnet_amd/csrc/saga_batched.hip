@@ -99,9 +99,10 @@ __device__ __forceinline__ void cw_clear_next(const SagaDev& d, int batch_id) {
 
 // --------------------------------------------------------------------------
 // Packed sample records (built once per solver, solver.cpp: build_records).
-// HBM random access on MI355X is request-rate bound (~20 G line requests/s
-// whatever the record size up to 128 B), so a draw should touch as few 64-B
-// lines as possible and need no pointer hop:
+// Random full 128-B lines stream at the HBM rate on MI355X (26 G random 256-B records/s,
+// scripts/microbench/gather_rate.hip), partial lines waste it, and every dependent hop is a
+// 1-2.5 us round trip, so a draw should touch as few lines as possible, whole, with no
+// pointer hop:
 //
 //   record s at rec + s*stride (stride = 128-B multiple sized for the 90th
 //   percentile row; requests are served in 128-B units):  [f64 y][i32 nnz][i32 ovf][i32 idx[cap]] pad8 [f64 val[cap]]
@@ -298,7 +299,7 @@ __device__ __forceinline__ void store_d0_partial(const SagaDev& d, int K, int ba
 // gather, global-scatter form: one draw per 16-lane group, every draw of the
 // batch in flight at once (the kernel is a chain of dependent loads stream ->
 // record -> w, so parallelism, not per-thread work, hides the HBM latency).
-// Scattered fp64 atomics run at ~20 G requests/s chip-wide: 10 per draw at z = 10.
+// Scattered fp64 atomics run at ~23 G requests/s chip-wide: 10 per draw at z = 10.
 // --------------------------------------------------------------------------
 template <int KMAX>
 __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, const LamParams* lamp,
