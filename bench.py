@@ -55,6 +55,8 @@ def main():
                     help="skip the epochs-to-tolerance leg (outside the timed region)")
     ap.add_argument("--conv-thresh", type=float, default=1e-6)
     ap.add_argument("--conv-max-epochs", type=int, default=400)
+    ap.add_argument("--no-alt-merge", action="store_true",
+                    help="N > 1: do not also measure the exchange scheme that --merge did not select")
     ap.add_argument("--merge", default="sync", choices=["sync", "epoch"],
                     help="N > 1: per-batch all-reduce of the scatter accumulator (exact) or per-epoch "
                          "averaged merge")
@@ -150,16 +152,23 @@ def main():
     fused = ((world > 1 or force_merge) and backend == "nccl"
              and os.environ.get("SGDNET_BENCH_FUSED", "1") == "1")
     dev = torch.device("cuda", local_rank)
-    if sync_mode:
-        shard = HipSyncShard(S, draws_per_epoch=n_local, device=dev, stage_on_host=(backend != "nccl"))
-        sjob = SyncShardedSaga(shard, n, world, batch, force_reduce=force_merge)
 
-        class job:                         # same call shape as ShardedSaga below
-            epoch = staticmethod(lambda: sjob.epoch(rank))
-    else:
-        shard = HipShard(S, batch=batch, draws_per_epoch=n_local, device=dev,
-                         stage_on_host=(backend != "nccl"), fused=fused)
-        job = ShardedSaga(shard, world, force_merge=force_merge)
+    def make_job(mode):
+        """mode 'sync' | 'epoch' | 'none' -> (epoch callable, shard, description)."""
+        if mode == "sync":
+            sh = HipSyncShard(S, draws_per_epoch=n_local, device=dev, stage_on_host=(backend != "nccl"))
+            sj = SyncShardedSaga(sh, n, world, batch, force_reduce=force_merge)
+            desc = (f"sync: {backend} all-reduce of the scatter accumulator per global batch "
+                    f"({sj.rounds} per epoch)" + (", stream-ordered" if backend == "nccl" else ""))
+            return (lambda: sj.epoch(rank)), sh, desc, sj.rounds
+        sh = HipShard(S, batch=min(batch, n_local), draws_per_epoch=n_local, device=dev,
+                      stage_on_host=(backend != "nccl"), fused=fused)
+        sj = ShardedSaga(sh, world, force_merge=force_merge)
+        desc = ("none" if world == 1 and not force_merge else
+                f"per-epoch {backend} all-reduce, w averaged" + (", stream-ordered" if fused else ""))
+        return sj.epoch, sh, desc, 0
+
+    run_epoch, shard, merge_desc, sync_rounds = make_job("sync" if sync_mode else "epoch")
 
     def fence():
         S.sync()
@@ -168,26 +177,29 @@ def main():
         torch.cuda.synchronize()
 
     note("solver resident, stream uploaded")
-    for _ in range(args.warmup):
-        job.epoch()
-    fence()
-    note("warmup done")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        job.epoch()
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
+    def timed_epochs(epoch_fn):
+        for _ in range(args.warmup):
+            epoch_fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            epoch_fn()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return dt
+
+    elapsed = timed_epochs(run_epoch)
 
     note(f"timed region done: {elapsed:.4f}s")
     # dominant kernel, HIP events around every launch of one more epoch (same stream)
     off = shard.offset
     # sync mode: this rank's share of a global batch, same (global-atomic) gather kernel as the
     # timed region; the profiled epoch runs without the exchange, the state is reset below
-    local_batch = min(batch, n_local) if not sync_mode else max(1, -(-n_local // sjob.rounds))
+    local_batch = min(batch, n_local) if not sync_mode else max(1, -(-n_local // sync_rounds))
     prof = S.profile_epoch(batch=local_batch, stream_offset=off, draws_per_epoch=n_local)
     alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, stream[off:off + n_local], K)
     gather_s = prof["gather_ms"] * 1e-3
@@ -216,11 +228,7 @@ def main():
                         f"alpha={mix}, lambda=1/n, intercept, standardize=FALSE",
             "mode": "batched", "batch": batch, "samples_per_gpu": n_local,
             "sample_order": f"R MT19937 set.seed({seed}+rank), with replacement",
-            "merge": ("none" if world == 1 and not force_merge else
-                      f"sync: {backend} all-reduce of the scatter accumulator per global batch "
-                      f"({sjob.rounds} per epoch)" + (", stream-ordered" if backend == "nccl" else "")
-                      if sync_mode else
-                      f"per-epoch {backend} all-reduce, w averaged" + (", stream-ordered" if fused else "")),
+            "merge": merge_desc,
             "gen_s": round(t_gen, 2),
         },
         "roofline": {
@@ -238,33 +246,55 @@ def main():
 
     # Epochs-to-tolerance of the same job from a cold start (outside the timed region): epochs/s
     # alone says nothing about a merge rule that trades statistical efficiency for throughput.
-    if not args.no_convergence:
+    def cold_start():
         S.set("w", np.zeros((K, p)))
         S.set("g_sum", np.zeros((K, p)))
         S.set("g_sum_intercept", np.zeros(K))
         S.set("g_memory", np.zeros((K, n_local)))
         S.set("intercept", b0)
+
+    def convergence_leg(epoch_fn, sh, max_epochs):
+        cold_start()
         crng = sa.RRng(seed + 1000 + rank)
         S.convergence(args.conv_thresh)            # w_prev <- 0
         fence()
         tconv = time.perf_counter()
         done, conv_ep = False, 0
-        while not done and conv_ep < args.conv_max_epochs:
+        while not done and conv_ep < max_epochs:
             S.generate_stream(crng, n_local)       # this epoch's draws, generated on the device
-            shard.offset = 0
-            job.epoch()
+            sh.offset = 0
+            epoch_fn()
             S.sync()
             torch.cuda.synchronize()
             done = S.convergence(args.conv_thresh)
             conv_ep += 1
         tconv = time.perf_counter() - tconv
-        out["convergence"] = {"thresh": args.conv_thresh, "epochs": conv_ep, "converged": bool(done),
-                              "seconds": tconv, "deviance": None,
-                              "note": "cold start, ConvergenceCheck on the merged coefficients every epoch; "
-                                      "includes per-epoch device RNG and host synchronisation"}
-        if world == 1:
-            out["convergence"]["deviance"] = S.deviance()
-        note(f"convergence leg: {conv_ep} epochs in {tconv:.3f}s")
+        return {"thresh": args.conv_thresh, "epochs": conv_ep, "converged": bool(done), "seconds": tconv,
+                "deviance": S.deviance() if world == 1 else None,
+                "note": "cold start, ConvergenceCheck on the merged coefficients every epoch; "
+                        "includes per-epoch device RNG and host synchronisation"}
+
+    if not args.no_convergence:
+        out["convergence"] = convergence_leg(run_epoch, shard, args.conv_max_epochs)
+        note(f"convergence leg: {out['convergence']['epochs']} epochs in {out['convergence']['seconds']:.3f}s")
+
+    # N > 1: the other exchange scheme on the same resident problem, reported beside the headline
+    # (`sync` is exact but pays a collective per batch; `epoch` is the scheme of the
+    # north star, fast per epoch, and does not reach the tolerance at this lambda)
+    if (world > 1 or force_merge) and not args.no_alt_merge:
+        alt = "epoch" if sync_mode else "sync"
+        if sync_mode:
+            shard.close()                           # unbind the sync buffer
+        cold_start()
+        S.upload_stream(stream)
+        alt_epoch, alt_shard, alt_desc, _ = make_job(alt)
+        alt_dt = timed_epochs(alt_epoch)
+        out["alt_merge"] = {"merge": alt_desc, "value": args.steps / alt_dt, "unit": "epochs/s",
+                            "ms_per_step": 1e3 * alt_dt / args.steps}
+        if not args.no_convergence:
+            out["alt_merge"]["convergence"] = convergence_leg(alt_epoch, alt_shard,
+                                                              min(args.conv_max_epochs, 150))
+        note(f"alt merge {alt}: {out['alt_merge']['value']:.1f} epochs/s")
     # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 cannot run inside
     # this process); attached only when workload, batch and kernel match that profile
     try:
