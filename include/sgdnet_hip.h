@@ -57,7 +57,10 @@ extern "C" {
 /* execution mode of the SAGA loop */
 #define SGDNET_MODE_EXACT   0  /* the reference iteration, one draw at a time, in stream order */
 #define SGDNET_MODE_BATCHED 1  /* `batch` consecutive draws against one snapshot; sgdnet_fit_* fall back
-                                  to the exact iteration for dense x and for more than 16 classes */
+                                  to the exact iteration for more than 16 classes and for dense x with
+                                  n_classes * n_features > 10240 */
+#define SGDNET_MODE_AUTO    2  /* sgdnet_fit_* only: batched wherever it is implemented (see above), exact otherwise.  Same optimum, not the reference's
+                                  iteration order; SGDNET_MODE_EXACT stays the default. */
 
 /* x as R passes it to SgdnetSparse: the slots of a dgCMatrix (R/sgdnet.R:226). */
 typedef struct sgdnet_csc {

@@ -30,7 +30,7 @@ EXPORTS = [
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
 PENALTIES = {"ridge": 0, "elasticnet": 1, "grouplasso": 2}
-MODES = {"exact": 0, "batched": 1}
+MODES = {"exact": 0, "batched": 1, "auto": 2}
 
 UNIF_FN = C.CFUNCTYPE(C.c_double, C.c_void_p)
 

@@ -257,7 +257,12 @@ int64_t auto_batch(const Features& X, double max_sample_sqnorm) {
   double diag = 0.0;
   for (int64_t j = 0; j < X.p; ++j) {
     double s = 0.0;
-    for (int64_t q = X.colptr[j]; q < X.colptr[j + 1]; ++q) s += X.val[(size_t)q] * X.val[(size_t)q];
+    if (X.sparse) {
+      for (int64_t q = X.colptr[j]; q < X.colptr[j + 1]; ++q) s += X.val[(size_t)q] * X.val[(size_t)q];
+    } else {
+      const double* col = X.xd.data() + (size_t)j * (size_t)X.n;
+      for (int64_t i = 0; i < X.n; ++i) s += col[i] * col[i];
+    }
     diag = std::max(diag, s / (double)X.n);
   }
   return sgdnet_auto_batch(max_sample_sqnorm, diag);
@@ -397,10 +402,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   int mode = ctl->mode;
   int64_t batch = ctl->batch;
-  // SGDNET_MODE_BATCHED means "batched where it is implemented": dense x and more than 16
-  // classes run the exact iteration instead (a global options(sgdnet.mode = "batched") in R
+  // SGDNET_MODE_BATCHED means "batched where it is implemented": more than 16 classes, and dense
+  // x whose K x p accumulator does not fit a workgroup's LDS, run the exact iteration instead (a global options(sgdnet.mode = "batched") in R
   // must not make dense fits fail)
-  if (mode == SGDNET_MODE_BATCHED && (!X.sparse || K > 16)) mode = SGDNET_MODE_EXACT;
+  if (mode == SGDNET_MODE_AUTO) mode = SGDNET_MODE_BATCHED;
+  if (mode == SGDNET_MODE_BATCHED && (K > 16 || (!X.sparse && (int64_t)K * p > 10240))) mode = SGDNET_MODE_EXACT;
   if (mode == SGDNET_MODE_BATCHED) {
     if (batch <= 0) batch = X.dev ? sgdnet_auto_batch(norm_max, X.dev_max_mean_sq) : auto_batch(X, norm_max);
   } else if (mode != SGDNET_MODE_EXACT) {

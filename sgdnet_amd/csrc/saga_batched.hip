@@ -545,6 +545,126 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
 }
 
 // --------------------------------------------------------------------------
+// Dense x (src/saga-dense.h) in batched mode: one wavefront per draw.  A sample is p
+// contiguous doubles, so the row streams through coalesced 512-byte wave loads; x.w is a
+// wave reduction; x*gc goes into the workgroup's LDS copy of D with conflict-free ds_add_f64
+// (lane l owns features l, l+64, ...), and the copy leaves as the workgroup's slab exactly as
+// in the sparse LDS form, so the sweep kernels are shared.  The second pass over the row (the
+// scatter) re-reads it from L1/L2.  Algorithmic bytes per draw: 8p (row) + 8Ky + 16K.
+// --------------------------------------------------------------------------
+constexpr int kDenseBlock = 256;
+
+template <int KMAX>
+__global__ __launch_bounds__(kDenseBlock) void saga_batch_gather_dense_kernel(SagaDev d, const LamParams* lamp,
+                                                                              int64_t t0_in_epoch, int m,
+                                                                              int batch_id_offset,
+                                                                              int draws_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double Dl[];
+  const int K = KMAX == 1 ? 1 : d.K;
+  const int64_t p = d.p, KP = (int64_t)K * p;
+  for (int64_t i = threadIdx.x; i < KP; i += kDenseBlock) Dl[i] = 0.0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  const int lo = blockIdx.x * draws_per_block;
+  const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
+  double bk[KMAX], gct[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    bk[k] = k < K ? d.b[k] : 0.0;
+    gct[k] = 0.0;
+  }
+  for (int i = lo + wave; i < hi; i += kDenseBlock / 64) {
+    const uint32_t s = d.stream[t0 + i];
+    const double* xs = d.xd + (int64_t)s * p;
+    int prev = batch_id;
+    double mold[KMAX];
+    if (KMAX > 1) {   // claim + old gradient memory: independent of the row
+      if (lane == 0)
+        prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) mold[k] = k < K ? d.M[k + (int64_t)s * K] : 0.0;
+    }
+    double acc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
+    for (int64_t j = lane; j < p; j += 64) {
+      const double xv = xs[j];
+      const double* wj = d.w + j * K;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) acc[k] += xv * wj[k];
+    }
+    double lp[KMAX], g[KMAX], gc[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      lp[k] = wave_sum(acc[k]) + bk[k];
+      gc[k] = 0.0;
+    }
+    bool first;
+    if (KMAX == 1) {
+      const double y0 = d.y[(int64_t)s * d.Ky];
+      g[0] = d.family == SGDNET_BINOMIAL ? 1.0 - y0 - 1.0 / (1.0 + exp(lp[0])) : lp[0] - y0;
+      double gcv = 0.0;
+      if (lane == 0) {
+        const double old = __hip_atomic_exchange(d.M + s, g[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gcv = g[0] - old;
+      }
+      gc[0] = __shfl(gcv, 0, 64);
+      first = gc[0] != 0.0;
+    } else {
+      first = __shfl(prev != batch_id ? 1 : 0, 0, 64) != 0;
+      if (first) {
+        if (d.family == SGDNET_MULTINOMIAL) {
+          const double lse = log_sum_exp(lp, K);
+          const unsigned cls = (unsigned)(d.y[(int64_t)s * d.Ky] + 0.5);
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            g[k] = 0.0;
+            if (k < K) {
+              g[k] = exp(lp[k] - lse);
+              if ((unsigned)k == cls) g[k] -= 1.0;
+            }
+          }
+        } else if (d.family == SGDNET_MGAUSSIAN) {
+          const double* ys = d.y + (int64_t)s * d.Ky;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) g[k] = k < K ? lp[k] - ys[k] : 0.0;
+        } else {   // not reached: single-response families have K == 1
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) g[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+          if (k < K) {
+            gc[k] = g[k] - mold[k];
+            if (lane == k) d.M[k + (int64_t)s * K] = g[k];
+          }
+        }
+      }
+    }
+    if (first) {
+      for (int64_t j = lane; j < p; j += 64) {
+        const double xv = xs[j];
+        double* dj = Dl + j * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K && gc[k] != 0.0) scatter_add<true>(dj + k, xv * gc[k]);
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) gct[k] += gc[k];
+      }
+    }
+  }
+  __syncthreads();
+  double* slab = d.slab + (int64_t)blockIdx.x * KP;
+  for (int64_t i = threadIdx.x; i < KP; i += kDenseBlock) slab[i] = Dl[i];
+  if (d.fit_intercept) store_d0_partial<KMAX, kDenseBlock>(d, K, batch_id, gct);
+}
+
+// --------------------------------------------------------------------------
 // Class-lane form for 4 < K <= 16 (multinomial / mgaussian with many classes): inside a
 // 16-lane group lane l owns class l and the group walks the row's non-zeros together.  Every
 // access to the K-fastest arrays (w, D, g_memory) is then K contiguous doubles per group =
@@ -1008,7 +1128,8 @@ int batched_max_classes() { return 16; }
 // needs the dense K*p table in LDS twice per CU (2 workgroups per CU) and enough
 // draws per workgroup to amortise its flush.
 struct GatherPlan {
-  bool lds;
+  bool lds;     // per-workgroup LDS copies of D flushed as slabs (sparse LDS form and dense form)
+  bool dense;   // dense x: saga_batch_gather_dense_kernel
   bool w_lds;   // K == 1: the coefficient snapshot is staged in LDS as well
   int grid;
   int draws_per_block;
@@ -1029,6 +1150,19 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     return e ? atoi(e) : 256;
   }();
   const bool fits = table <= 80 * 1024;
+  if (d.xd) {   // dense x: wave per draw, slab form only (solver.cpp: check_batched_ok)
+    g.dense = true;
+    g.lds = d.slab != nullptr && fits;
+    const int waves = kDenseBlock / 64;
+    int dpb = (m + target_grid - 1) / target_grid;
+    dpb = (dpb + waves - 1) / waves * waves;
+    if (dpb < waves) dpb = waves;
+    g.draws_per_block = dpb;
+    g.grid = (m + dpb - 1) / dpb;
+    if (g.grid < 1) g.grid = 1;
+    g.lds_bytes = table;
+    return g;
+  }
   // worthwhile once the batch's non-zeros outnumber the table ~48x: below that the fixed
   // cost of writing and re-reading one table per workgroup exceeds the atomics it saves
   const bool pays = (double)m * (double)d.avg_nnz >= 48.0 * (double)d.K * (double)d.p;
@@ -1072,6 +1206,34 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
     return SGDNET_EUNSUPPORTED;
   }
   const GatherPlan g = plan_gather(d, m);
+  if (g.dense) {
+    if (!g.lds) {
+      set_error("batched mode on dense x needs n_classes * n_features <= 10240 (LDS copy of the accumulator)");
+      return SGDNET_EUNSUPPORTED;
+    }
+    static bool dense_attr_done = false;
+    if (!dense_attr_done) {
+      const int cap = 96 * 1024;
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<1>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<4>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+      dense_attr_done = true;
+    }
+    if (d.K == 1)
+      hipExtLaunchKernelGGL(saga_batch_gather_dense_kernel<1>, dim3(g.grid), dim3(kDenseBlock), g.lds_bytes, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    else if (d.K <= 4)
+      hipExtLaunchKernelGGL(saga_batch_gather_dense_kernel<4>, dim3(g.grid), dim3(kDenseBlock), g.lds_bytes, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    else
+      hipExtLaunchKernelGGL(saga_batch_gather_dense_kernel<16>, dim3(g.grid), dim3(kDenseBlock), g.lds_bytes, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
+  }
   if (g.lds) {
     static bool attr_done = false;
     if (!attr_done) {

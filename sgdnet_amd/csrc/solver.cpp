@@ -220,13 +220,18 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
 }
 
 int check_batched_ok(const sgdnet_solver* s) {
-  if (!s->sparse) {
-    set_error("batched mode is implemented for sparse x only; dense x runs in exact mode");
-    return SGDNET_EUNSUPPORTED;
-  }
   if (s->d.K > batched_max_classes()) {
     set_error("batched mode supports n_classes <= %d (got %d)", batched_max_classes(), s->d.K);
     return SGDNET_EUNSUPPORTED;
+  }
+  if (!s->sparse) {
+    // dense x: one LDS copy of the K x p accumulator per workgroup (saga_batch_gather_dense_kernel)
+    if ((int64_t)s->d.K * s->d.p > 10240) {
+      set_error("batched mode on dense x needs n_classes * n_features <= 10240 (got %lld); use exact mode",
+                (long long)((int64_t)s->d.K * s->d.p));
+      return SGDNET_EUNSUPPORTED;
+    }
+    return SGDNET_OK;
   }
   if (!s->d.rec) {
     set_error("batched mode: packed sample records were not built");
@@ -1008,6 +1013,10 @@ int sgdnet_solver_sync_bind(sgdnet_solver* s, void* device_buf) {
   if (device_buf) {
     int rc = check_batched_ok(s);
     if (rc) return rc;
+    if (!s->sparse) {
+      set_error("the synchronous sharded mode is implemented for sparse x");
+      return SGDNET_EUNSUPPORTED;
+    }
     if (!s->own_D) {
       s->own_D = s->d.D;
       s->own_d0 = s->d.d0_part;

@@ -28,7 +28,7 @@
  *     (src/sgdnet.cpp:275-284);
  *   - inputs are borrowed read-only; failures become R errors after cleanup.
  * Backend extensions are read from R options so that the R code needs no change:
- *   options(sgdnet.mode = "exact" | "batched", sgdnet.batch = <int>, sgdnet.device = <int>)
+ *   options(sgdnet.mode = "exact" | "batched" | "auto", sgdnet.batch = <int>, sgdnet.device = <int>)
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -83,6 +83,7 @@ static void fill_control(SEXP control, sgdnet_control* c) {
    * device, bit-identical to unif_rand() (INTEGRATION.md "Faster sample order"). */
   SEXP opt = Rf_GetOption1(Rf_install("sgdnet.mode"));
   if (opt != R_NilValue && strcmp(CHAR(Rf_asChar(opt)), "batched") == 0) c->mode = SGDNET_MODE_BATCHED;
+  if (opt != R_NilValue && strcmp(CHAR(Rf_asChar(opt)), "auto") == 0) c->mode = SGDNET_MODE_AUTO;
   opt = Rf_GetOption1(Rf_install("sgdnet.batch"));
   if (opt != R_NilValue) c->batch = (int64_t)Rf_asReal(opt);
   opt = Rf_GetOption1(Rf_install("sgdnet.device"));

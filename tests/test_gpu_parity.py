@@ -123,6 +123,42 @@ def test_sparse_batched_matches_batched_oracle(sa, oracle, family, K, penalty, b
         assert relerr(got[k], st[k]) < TOL_BATCHED, k
 
 
+@pytest.mark.parametrize("family,K,penalty,p", [
+    ("gaussian", 1, "elasticnet", 37), ("binomial", 1, "ridge", 130), ("multinomial", 3, "elasticnet", 37),
+    ("mgaussian", 2, "grouplasso", 70), ("multinomial", 10, "ridge", 8), ("binomial", 1, "elasticnet", 700)])
+@pytest.mark.parametrize("batch", [7, 64, 1000])
+def test_dense_batched_matches_batched_oracle(sa, oracle, family, K, penalty, p, batch):
+    # dense x in batched mode (wave per draw); the oracle restates the same batched iteration on
+    # the CSC form of the same matrix (every entry stored)
+    n = 1500
+    x, y = make_problem(family, K, n, p, None, seed=11, dense=True)
+    stream = oracle.Rng(5).stream(n, n * 3)
+    kw = dict(family=family, penalty=penalty, gamma=0.4 / p, alpha=1e-3, beta=0.0 if penalty == "ridge" else 2e-3)
+    st = oracle.new_state(K, p, n)
+    oracle.saga(sp.csc_matrix(x), y, st, max_iter=3, tol=0.0, stream=stream, batch=batch, **kw)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K)
+    S.set_penalty(penalty, kw["gamma"], kw["alpha"], kw["beta"])
+    S.upload_stream(stream)
+    ep, _ = S.run(mode="batched", batch=batch, max_epochs=3, tol=0.0)
+    assert ep == 3
+    for k in STATE:
+        assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
+    S.close()
+
+
+def test_dense_fit_batched_reaches_the_exact_optimum(sa, oracle):
+    rng = np.random.default_rng(3)
+    n, p = 4000, 12
+    X = rng.standard_normal((n, p)) * rng.uniform(0.5, 2.0, p)
+    y = X @ rng.standard_normal(p) + 0.3 * rng.standard_normal(n) + 1.5
+    kw = dict(family="gaussian", alpha=0.6, lambda_=[0.02], thresh=1e-11, maxit=3000)
+    ref = oracle.fit(X, y, seed=8, **kw)
+    fit = sa.sgdnet(X, y, seed=8, mode="batched", **kw)      # automatic batch (about 2p draws)
+    assert fit.return_codes[0] == 0
+    assert relerr(fit.beta[:, 0], ref["beta"][0, :, 0]) < 1e-8
+    assert abs(fit.a0[0] - ref["a0"][0, 0]) < 1e-8
+
+
 def test_batched_handles_repeats_and_empty_rows(sa, oracle):
     # a stream that draws the same few samples over and over inside one batch, on a
     # matrix with empty samples and one long row (several 16-lane chunks)
@@ -274,6 +310,26 @@ def test_fit_batched_mode_reaches_the_exact_optimum(sa, oracle):
     assert abs(fit.a0[0] - ref["a0"][0, 0]) < 1e-8
 
 
+def test_fit_auto_mode_is_batched_where_implemented(sa, oracle):
+    from sgdnet_amd import data as D
+    n, p = 5000, 60
+    pr = D.make_sparse_glm(n, p, 0.1, family="gaussian", seed=21)
+    X = D.as_scipy(pr).T.tocsc()
+    y = pr["y"][0]
+    kw = dict(family="gaussian", alpha=0.7, lambda_=[0.05], standardize=False, thresh=1e-10, maxit=500)
+    a = sa.sgdnet(X, y, seed=2, mode="auto", **kw)           # sparse: automatic batch
+    b = sa.sgdnet(X, y, seed=2, mode="batched", **kw)
+    # same path taken (scatter sums are order-dependent in the last bits, so not bitwise)
+    assert relerr(a.beta[:, 0], b.beta[:, 0]) < 1e-9 and a.npasses == b.npasses
+    e = sa.sgdnet(X, y, seed=2, mode="exact", **kw)
+    assert relerr(a.beta[:, 0], e.beta[:, 0]) < 1e-7        # same optimum, different trajectory
+    Xd = np.asarray(X.todense())
+    c = sa.sgdnet(Xd, y, seed=2, mode="auto", **kw)         # dense: batched as well (K*p fits the LDS)
+    d = sa.sgdnet(Xd, y, seed=2, mode="batched", **kw)
+    assert relerr(c.beta[:, 0], d.beta[:, 0]) < 1e-9 and c.npasses == d.npasses
+    assert relerr(c.beta[:, 0], e.beta[:, 0]) < 1e-7
+
+
 def test_unsupported_and_stream_errors(sa):
     from sgdnet_amd import SgdnetError
     x, y = make_problem("gaussian", 1, 200, 5, None, seed=1, dense=True)
@@ -283,9 +339,14 @@ def test_unsupported_and_stream_errors(sa):
     with pytest.raises(SgdnetError) as e:
         S.run(mode="exact", max_epochs=1)          # 200 draws needed, 100 resident
     assert e.value.code == -6
-    S.upload_stream(np.zeros(200, dtype=np.uint32))
+    S.close()
+    # dense x whose K x p accumulator exceeds a workgroup's LDS copy has no batched path
+    x, y = make_problem("gaussian", 1, 64, 10300, None, seed=1, dense=True)
+    S = sa.SagaSolver(x, y, family="gaussian", n_classes=1)
+    S.set_penalty("ridge", 1e-5, 1e-3, 0.0)
+    S.upload_stream(np.zeros(64, dtype=np.uint32))
     with pytest.raises(SgdnetError) as e:
-        S.run(mode="batched", batch=8, max_epochs=1)   # dense x has no batched path
+        S.run(mode="batched", batch=8, max_epochs=1)
     assert e.value.code == -5
     S.close()
 
@@ -464,8 +525,10 @@ def test_fit_edge_cases(sa, oracle):
             ref = oracle.fit(xx, y, family="gaussian", nlambda=3, thresh=1e-7, seed=1)
             assert np.all(np.isfinite(fit.beta)) and fit.beta.shape == (3, 3)
             assert relerr(fit.lambda_, ref["lambda"]) < 1e-12
-            if mode == "exact" or not sp.issparse(xx):        # dense x always runs exact
+            if mode == "exact":
                 assert fit.npasses == ref["npasses"] and relerr(fit.beta, ref["beta"][0]) < 1e-8
+            else:                                             # same optimum within the tolerance
+                assert np.abs(fit.beta - ref["beta"][0]).max() < 1e-4
     # (b) a single user lambda, maxit = 1: return code 1, one epoch, n draws
     xs = sp.random(300, 20, density=0.2, format="csc", random_state=1)
     yb = (rng.random(300) < 0.5).astype(float)
