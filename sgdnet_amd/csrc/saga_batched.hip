@@ -589,12 +589,26 @@ __global__ __launch_bounds__(kDenseBlock) void saga_batch_gather_dense_kernel(Sa
     double acc[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
-    for (int64_t j = lane; j < p; j += 64) {
-      const double xv = xs[j];
-      const double* wj = d.w + j * K;
+    // kRowU row chunks per lane requested before the first use (a plain strided loop waits for
+    // every load in turn: the trip count is a run-time value)
+    constexpr int kRowU = KMAX == 1 ? 8 : 4;
+    for (int64_t j0 = lane; j0 < p; j0 += 64 * kRowU) {
+      double xv[kRowU];
 #pragma unroll
-      for (int k = 0; k < KMAX; ++k)
-        if (k < K) acc[k] += xv * wj[k];
+      for (int r = 0; r < kRowU; ++r) {
+        const int64_t j = j0 + 64 * r;
+        xv[r] = j < p ? xs[j] : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < kRowU; ++r) {
+        const int64_t j = j0 + 64 * r;
+        if (j < p) {
+          const double* wj = d.w + j * K;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (k < K) acc[k] += xv[r] * wj[k];
+        }
+      }
     }
     double lp[KMAX], g[KMAX], gc[KMAX];
 #pragma unroll
@@ -645,12 +659,23 @@ __global__ __launch_bounds__(kDenseBlock) void saga_batch_gather_dense_kernel(Sa
       }
     }
     if (first) {
-      for (int64_t j = lane; j < p; j += 64) {
-        const double xv = xs[j];
-        double* dj = Dl + j * K;
+      for (int64_t j0 = lane; j0 < p; j0 += 64 * kRowU) {
+        double xv[kRowU];
 #pragma unroll
-        for (int k = 0; k < KMAX; ++k)
-          if (k < K && gc[k] != 0.0) scatter_add<true>(dj + k, xv * gc[k]);
+        for (int r = 0; r < kRowU; ++r) {
+          const int64_t j = j0 + 64 * r;
+          xv[r] = j < p ? xs[j] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < kRowU; ++r) {
+          const int64_t j = j0 + 64 * r;
+          if (j < p) {
+            double* dj = Dl + j * K;
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+              if (k < K && gc[k] != 0.0) scatter_add<true>(dj + k, xv[r] * gc[k]);
+          }
+        }
       }
       if (lane == 0) {
 #pragma unroll
