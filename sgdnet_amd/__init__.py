@@ -6,6 +6,10 @@ R front-end for the fit path plus benchmark/multi-GPU plumbing.
 """
 from ._lib import LIB_PATH, SgdnetError, load  # noqa: F401
 from .api import SgdnetFit, sgdnet  # noqa: F401
+from .cv import CvSgdnet, cv_sgdnet  # noqa: F401
+from .predict import coef, predict  # noqa: F401
+from .score import score  # noqa: F401
 from .solver import RRng, SagaSolver, auto_batch  # noqa: F401
 
-__all__ = ["sgdnet", "SgdnetFit", "SagaSolver", "RRng", "auto_batch", "SgdnetError", "load", "LIB_PATH"]
+__all__ = ["sgdnet", "SgdnetFit", "SagaSolver", "RRng", "auto_batch", "SgdnetError", "load", "LIB_PATH",
+           "cv_sgdnet", "CvSgdnet", "predict", "coef", "score"]

@@ -29,6 +29,38 @@ class RRng:
                                 out.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(count))
         return out
 
+    # ---- R's sample() (R >= 3.6.0, sample.kind = "Rejection"; src/main/RNG.c R_unif_index and
+    #      src/main/random.c do_sample of R itself), used by cv_sgdnet for the fold ids ----
+    def _rbits(self, bits):
+        v = 0
+        for _ in range(0, bits + 1, 16):
+            v = 65536 * v + int(np.floor(self.unif()[0] * 65536))
+        return v & ((1 << bits) - 1) if bits < 64 else v
+
+    def unif_index(self, dn):
+        if dn <= 0:
+            return 0
+        bits = int(np.ceil(np.log2(dn)))
+        while True:
+            dv = self._rbits(bits)
+            if dv < dn:
+                return dv
+
+    def sample(self, n, size=None):
+        """sample(n, size) without replacement: a 1-based permutation prefix, as R returns it."""
+        k = n if size is None else size
+        if k < 2:
+            return np.array([self.unif_index(n) + 1 for _ in range(k)], dtype=np.int64)
+        x = list(range(n))
+        out = np.empty(k, dtype=np.int64)
+        m = n
+        for i in range(k):
+            j = self.unif_index(m)
+            out[i] = x[j] + 1
+            m -= 1
+            x[j] = x[m]
+        return out
+
 
 def auto_batch(max_sample_sqnorm, max_feature_mean_sq):
     """Default staleness window of the batched mode (sgdnet_auto_batch of the C ABI)."""

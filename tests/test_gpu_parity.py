@@ -646,3 +646,32 @@ def test_sync_mode_two_ranks_on_one_gpu_equal_the_single_process_iteration(sa, o
         assert relerr(out[0][k], st[k]) < TOL_BATCHED, k
     mem = np.concatenate([o["g_memory"] for o in out], axis=1)
     assert relerr(mem, st["g_memory"]) < TOL_BATCHED
+
+
+# ---------------------------------------------------------------------------------------------
+# cv_sgdnet fan-out: independent fits through the same C-ABI entry point
+# ---------------------------------------------------------------------------------------------
+def test_cv_sgdnet_runs_the_reference_protocol(sa, oracle):
+    from sgdnet_amd import data as D
+    n, p = 600, 12
+    pr = D.make_sparse_glm(n, p, 0.4, family="binomial", seed=5)
+    X = np.asarray(D.as_scipy(pr).T.todense())
+    y = pr["y"][0]
+    cv = sa.cv_sgdnet(X, y, alpha=[0.5, 1.0], nfolds=3, family="binomial", type_measure="deviance",
+                      seed=3, nlambda=8, thresh=1e-6)
+    assert cv.name == "Binomial Deviance" and len(cv.cv_raw) == 2 and cv.cv_raw[0].shape == (3, 8)
+    assert np.all(np.isfinite(cv.cv_summary)) and cv.cv_summary.shape == (16, 6)
+    assert cv.alpha_min in (0.5, 1.0) and cv.lambda_1se >= cv.lambda_min
+    assert sorted(np.unique(cv.foldid).tolist()) == [1, 2, 3]
+    # the fold fits are the oracle's fits of the same sub-problems: fold 2 of alpha = 1, scored by hand
+    train = cv.foldid == 2
+    ref = oracle.fit(X[train], y[train], family="binomial", alpha=1.0, lambda_=cv.lambda_[1], thresh=1e-6, seed=9)
+    lp = X[~train] @ ref["beta"][0] + ref["a0"][0]
+    prob = np.clip(1 / (1 + np.exp(-lp)), 1e-5, 1 - 1e-5)
+    t = y[~train][:, None]
+    want = (-2 * (t * np.log(prob) + (1 - t) * np.log(1 - prob))).mean(axis=0)
+    assert np.allclose(cv.cv_raw[1][1], want, rtol=2e-3)          # different sample order, same optimum
+    # fan-out path (per-fit seeds, thread pool) gives the same table within the fit tolerance
+    cv2 = sa.cv_sgdnet(X, y, alpha=[0.5, 1.0], nfolds=3, family="binomial", foldid=cv.foldid, devices=[0, 0],
+                       nlambda=8, thresh=1e-6)
+    assert np.allclose(cv2.cv_summary[:, 2], cv.cv_summary[:, 2], rtol=5e-3)
