@@ -267,6 +267,10 @@ def main():
             S.sync()
             torch.cuda.synchronize()
             done = S.convergence(args.conv_thresh)
+            if world > 1:                          # one decision for all ranks (they hold the same w)
+                flag = torch.tensor([1.0 if done else 0.0], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                done = bool(flag[0] > 0.5)
             conv_ep += 1
         tconv = time.perf_counter() - tconv
         return {"thresh": args.conv_thresh, "epochs": conv_ep, "converged": bool(done), "seconds": tconv,
