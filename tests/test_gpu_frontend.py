@@ -1,0 +1,118 @@
+"""The reference's front-end tests that reach the fit path through predict / score / cv_sgdnet
+(tests/testthat/test-assertions.R, test-cross-validation.R, test-multinomial.R,
+test-predictions.R), restated against the host mirrors with the HIP backend doing the fits.
+Data sets that are base-R objects in the reference (trees, mtcars) are replaced by the
+committed abalone / iris fixtures and seeded synthetic data."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import torch  # noqa: F401  -- before libsgdnet_hip.so (sgdnet_amd/_lib.py)
+    import sgdnet_amd
+    if sgdnet_amd.load().sgdnet_device_count() < 1:
+        pytest.fail("GPU tests need a HIP device; the backend has no CPU fallback")
+    return sgdnet_amd
+
+
+def _random_data(rng, n, p, family):
+    """tests/testthat/setup.R random_data(): dense design, family-appropriate response."""
+    x = rng.standard_normal((n, p))
+    if family == "gaussian":
+        return x, x @ rng.standard_normal(p) + rng.standard_normal(n)
+    if family == "binomial":
+        return x, (rng.random(n) < 1 / (1 + np.exp(-x @ rng.standard_normal(p)))).astype(int)
+    if family == "multinomial":
+        return x, np.argmax(x @ rng.standard_normal((p, 3)) + rng.gumbel(size=(n, 3)), axis=1)
+    return x, x @ rng.standard_normal((p, 2)) + rng.standard_normal((n, 2))
+
+
+def test_assertions_in_predict(sa):
+    # test-assertions.R:3-17
+    ab = np.load(os.path.join(GOLD, "abalone.npz"))
+    x, y = ab["x"][:300, 1:4], ab["y"][:300]
+    fit = sa.sgdnet(x, y, nlambda=5)
+    for bad in (dict(), dict(newx=x, type=1), dict(newx=x, s=-3), dict(newx=x, type="class")):
+        with pytest.raises(ValueError):
+            sa.predict(fit, **bad)
+    ir = np.load(os.path.join(GOLD, "iris.npz"))
+    fit = sa.sgdnet(ir["x"], ir["y"], family="multinomial", nlambda=5)
+    with pytest.raises(ValueError):
+        sa.predict(fit, ir["x"], s=-3, type="class")
+    with pytest.raises(ValueError):
+        sa.predict(fit)
+
+
+def test_assertions_in_cv_sgdnet(sa):
+    # test-assertions.R:54-63
+    rng = np.random.default_rng(1)
+    n = 100
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    for bad in (dict(nfolds=n + 1), dict(nfolds=1), dict(alpha=[]), dict(foldid=np.arange(n - 1))):
+        with pytest.raises(ValueError):
+            sa.cv_sgdnet(x, y, **bad)
+
+
+@pytest.mark.parametrize("family", ["gaussian", "binomial", "multinomial", "mgaussian"])
+def test_cross_validation_works_for_every_family_and_measure(sa, family):
+    # test-cross-validation.R:3-36
+    from sgdnet_amd.score import _MEASURES
+    rng = np.random.default_rng(2)
+    x, y = _random_data(rng, 500, 2, family)
+    for alpha in (0, 1, [0.2, 0.5]):
+        for measure in _MEASURES[family]:
+            cv = sa.cv_sgdnet(x, y, family=family, alpha=alpha, nlambda=5, maxit=10, thresh=1e-2,
+                              type_measure=measure, seed=2)
+            assert isinstance(cv, sa.CvSgdnet) and np.all(np.isfinite(cv.cv_summary[:, 2]))
+            pred = sa.predict(cv.fit, x, s=cv.lambda_1se)          # predict.cv_sgdnet
+            assert pred.shape[0] == 500 and np.all(np.isfinite(pred))
+
+
+def test_various_cross_validation_arguments(sa):
+    # test-cross-validation.R:38-46: leave-one-out and user fold ids
+    rng = np.random.default_rng(3)
+    n = 100
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    cv = sa.cv_sgdnet(x, y, nfolds=n, nlambda=4, seed=1)
+    assert cv.cv_raw[0].shape == (n, 4)
+    folds = sa.RRng(1).sample(n) % 10 + 1                          # sample(rep(1:10, 10))
+    cv = sa.cv_sgdnet(x, y, foldid=folds, nlambda=4)
+    assert cv.cv_raw[0].shape == (10, 4)
+
+
+def test_multinomial_predicted_responses_sum_to_one(sa):
+    # test-multinomial.R:8-13
+    ir = np.load(os.path.join(GOLD, "iris.npz"))
+    fit = sa.sgdnet(ir["x"], ir["y"], alpha=0, family="multinomial", nlambda=10)
+    pr = sa.predict(fit, ir["x"], type="response")
+    assert pr.shape == (150, 3, 10) and np.allclose(pr.sum(axis=1), 1.0, atol=1e-12)
+
+
+def test_linear_interpolation_succeeds(sa):
+    # test-predictions.R:75-92
+    ab = np.load(os.path.join(GOLD, "abalone.npz"))
+    x, y = ab["x"][:, 1:4], ab["y"]
+    fit = sa.sgdnet(x, y, thresh=1e-7)
+    s = float(np.sqrt(fit.lambda_[20] * fit.lambda_[21]))           # between two path points
+    old = sa.predict(fit, x, s=s, type="coefficients")
+    new = sa.predict(sa.sgdnet(x, y, lambda_=[s], thresh=1e-7), type="coefficients")
+    assert np.abs(old - new).mean() / np.abs(new).mean() < 0.01    # expect_equivalent(tolerance = 0.01)
+    lo = sa.predict(fit, x, s=fit.lambda_[21], type="coefficients")
+    hi = sa.predict(fit, x, s=fit.lambda_[20], type="coefficients")
+    assert np.all(np.minimum(lo, hi) - 1e-12 <= old) and np.all(old <= np.maximum(lo, hi) + 1e-12)
+
+
+def test_nas_in_new_data_propagate(sa):
+    # test-predictions.R:109-125
+    rng = np.random.default_rng(5)
+    x, y = _random_data(rng, 60, 2, "mgaussian")
+    fit = sa.sgdnet(x, y, family="mgaussian", nlambda=5)
+    x[10, :] = np.nan
+    out = sa.predict(fit, x)
+    assert np.all(np.isnan(out[10])) and np.all(np.isfinite(np.delete(out, 10, axis=0)))
