@@ -10,7 +10,8 @@ n, p, dens, seed, family, K = {"C4": (10_000_000, 10_000, 0.001, 4, "binomial", 
                                "C3": (1_000_000, 1_000, 0.01, 3, "binomial", 1),
                                "C4s": (2_000_000, 10_000, 0.001, 4, "binomial", 1),
                                "C4z6": (10_000_000, 10_000, 0.0006, 4, "binomial", 1),
-                               "C5s": (2_000_000, 100_000, 0.0001, 5, "multinomial", 10)}[wl]
+                               "C5s": (2_000_000, 100_000, 0.0001, 5, "multinomial", 10),
+                               "C5": (50_000_000, 100_000, 0.0001, 5, "multinomial", 10)}[wl]
 t = time.time(); pr = D.make_sparse_glm(n, p, dens, family=family, n_classes=K, seed=seed); X = D.as_scipy(pr)
 print(f"{wl}: gen {time.time()-t:.1f}s nnz={X.nnz}", flush=True)
 epochs = 2 + 3 * len(batches) + 1
