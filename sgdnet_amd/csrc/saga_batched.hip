@@ -1236,7 +1236,11 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
       set_error("batched mode on dense x needs n_classes * n_features <= 10240 (LDS copy of the accumulator)");
       return SGDNET_EUNSUPPORTED;
     }
-    static bool dense_attr_done = false;
+    // function attributes are per device: one process may drive several GPUs (cv_sgdnet fan-out)
+    static bool dense_attr_done_dev[64] = {};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& dense_attr_done = dense_attr_done_dev[cur_dev & 63];
     if (!dense_attr_done) {
       const int cap = 96 * 1024;
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<1>),
@@ -1260,7 +1264,10 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
     return SGDNET_OK;
   }
   if (g.lds) {
-    static bool attr_done = false;
+    static bool attr_done_dev[64] = {};
+    int cur_dev = 0;
+    (void)hipGetDevice(&cur_dev);
+    bool& attr_done = attr_done_dev[cur_dev & 63];
     if (!attr_done) {
       const int cap = 96 * 1024;   // the dense table is limited to 80 KiB (plan_gather)
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1, true>),

@@ -132,27 +132,28 @@ def cv_sgdnet(x, y, alpha=1, lambda_=None, nfolds=10, foldid=None, type_measure=
     fold_values = np.arange(1, nfolds + 1) if np.all(np.isin(foldid, np.arange(1, nfolds + 1))) else np.unique(foldid)
 
     def fold_job(job):
-        i, j, dev, fit_seed = job
+        i, j, worker, fit_seed = job
+        dev = devices[worker]
         sel = foldid == fold_values[j]
         train = sel if train_on == "fold" else ~sel
         test = ~train
         fit = one_fit(x[train], y[train], lam[i], alpha[i], dev, fit_seed)
         return i, j, score(fit, x[test], y[test], type_measure)
 
-    jobs = [(i, j, devices[(i * nfolds + j) % len(devices)], seed + 1000 + i * nfolds + j)
-            for i in range(alpha.size) for j in range(nfolds)]
+    jobs = [(i, j, (i * nfolds + j) % len(devices), seed + 1000 + i * nfolds + j)
+            for i in range(alpha.size) for j in range(nfolds)]               # (alpha, fold, worker, seed)
     cv_raw = [np.full((nfolds, lam[i].size), np.nan) for i in range(alpha.size)]
     if sequential:
         results = map(fold_job, jobs)
     else:
-        # one worker per device: a device runs one fit at a time
-        pools = {d: ThreadPoolExecutor(max_workers=1) for d in devices}
+        # one worker per entry of `devices` (list a device twice to run two fits on it at a time)
+        pools = [ThreadPoolExecutor(max_workers=1) for _ in devices]
         futures = [pools[job[2]].submit(fold_job, job) for job in jobs]
         results = (f.result() for f in futures)
     for i, j, sc in results:
         cv_raw[i][j, :] = sc
     if not sequential:
-        for pool in pools.values():
+        for pool in pools:
             pool.shutdown()
 
     blocks = []
