@@ -675,3 +675,37 @@ def test_cv_sgdnet_runs_the_reference_protocol(sa, oracle):
     cv2 = sa.cv_sgdnet(X, y, alpha=[0.5, 1.0], nfolds=3, family="binomial", foldid=cv.foldid, devices=[0, 0],
                        nlambda=8, thresh=1e-6)
     assert np.allclose(cv2.cv_summary[:, 2], cv.cv_summary[:, 2], rtol=5e-3)
+
+
+@pytest.mark.parametrize("family,K,penalty,batch", [
+    ("binomial", 1, "elasticnet", 64), ("binomial", 1, "elasticnet", 6000), ("multinomial", 3, "elasticnet", 500),
+    ("multinomial", 3, "elasticnet", 6000), ("multinomial", 10, "ridge", 500), ("mgaussian", 2, "grouplasso", 6000)])
+def test_heavy_tailed_rows_walk_the_overflow_chains(sa, oracle, family, K, penalty, batch):
+    # most samples have ~4 non-zeros (so the packed records are small), 3 % have 60-200: those
+    # continue through several chained overflow records in every gather form and in exact mode
+    rng = np.random.default_rng(33)
+    n, p = 6000, 300
+    z = np.maximum(1, rng.poisson(4, n))
+    heavy = rng.random(n) < 0.03
+    z[heavy] = rng.integers(60, 201, heavy.sum())
+    z[:5] = [0, 1, 200, 21, 41]                                   # an empty row and the record boundaries
+    ptr = np.concatenate([[0], np.cumsum(z)])
+    idx = np.concatenate([np.sort(rng.choice(p, k, replace=False)) for k in z]).astype(np.int32)
+    val = rng.standard_normal(ptr[-1])
+    x = sp.csc_matrix((val, idx, ptr), shape=(p, n))              # column i = sample i
+    lp = (x.T @ rng.standard_normal((p, K))) * 0.3
+    if family == "binomial":
+        y = (rng.random(n) < 1 / (1 + np.exp(-lp[:, 0]))).astype(float).reshape(1, n)
+    elif family == "multinomial":
+        y = np.argmax(lp + rng.gumbel(size=lp.shape), axis=1).astype(float).reshape(1, n)
+    else:
+        y = np.asfortranarray((lp + 0.1 * rng.standard_normal(lp.shape)).T)
+    kw = dict(family=family, K=K, penalty=penalty, gamma=0.002, alpha=1e-3,
+              beta=0.0 if penalty == "ridge" else 2e-3)
+    (ep, rc, st), (ep2, conv, got) = run_both(sa, oracle, x, y, epochs=2, mode="batched", batch=batch, **kw)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_BATCHED, k
+    if batch == 6000:                                             # once per family: the exact kernel too
+        (ep, rc, st), (ep2, conv, got) = run_both(sa, oracle, x, y, epochs=1, mode="exact", **kw)
+        for k in STATE:
+            assert relerr(got[k], st[k]) < TOL_EXACT, k
