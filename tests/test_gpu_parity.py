@@ -709,3 +709,23 @@ def test_heavy_tailed_rows_walk_the_overflow_chains(sa, oracle, family, K, penal
         (ep, rc, st), (ep2, conv, got) = run_both(sa, oracle, x, y, epochs=1, mode="exact", **kw)
         for k in STATE:
             assert relerr(got[k], st[k]) < TOL_EXACT, k
+
+
+def test_fit_with_heavy_tailed_rows_uses_the_device_packer(sa, oracle):
+    # sgdnet_fit_sparse packs the records on the device (setup_device.hip): same data shape as
+    # above, batched fit against the oracle's optimum
+    rng = np.random.default_rng(34)
+    n, p = 5000, 120
+    z = np.maximum(1, rng.poisson(3, n))
+    heavy = rng.random(n) < 0.04
+    z[heavy] = rng.integers(50, 121, heavy.sum())
+    ptr = np.concatenate([[0], np.cumsum(z)])
+    idx = np.concatenate([np.sort(rng.choice(p, k, replace=False)) for k in z]).astype(np.int32)
+    X = sp.csr_matrix((rng.standard_normal(ptr[-1]), idx, ptr), shape=(n, p)).tocsc()
+    y = np.asarray(X @ (rng.standard_normal(p) * (rng.random(p) < 0.2))).ravel() + 0.1 * rng.standard_normal(n)
+    kw = dict(family="gaussian", alpha=0.5, lambda_=[0.01], standardize=False, thresh=1e-10, maxit=2000)
+    ref = oracle.fit(X, y, seed=3, **kw)
+    for mode in ("exact", "batched"):
+        fit = sa.sgdnet(X, y, seed=3, mode=mode, **kw)
+        assert fit.return_codes[0] == 0
+        assert relerr(fit.beta[:, 0], ref["beta"][0, :, 0]) < (1e-9 if mode == "exact" else 1e-7)
