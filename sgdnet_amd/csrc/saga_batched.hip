@@ -355,7 +355,8 @@ template <int U>
 struct K1Draws {
   uint32_t s[U];
   int jf[U], nnz[U];
-  double vf[U], y0[U], gcv[U];
+  double vf[U], y0[U];
+  double gcp;      // lane u of the group: gradient change of draw u (0 on the other lanes)
   bool valid[U];
 
   // stream indices + record loads (nothing waits here)
@@ -405,20 +406,33 @@ struct K1Draws {
         acc[u] += a;
       }
     }
+    // One gradient evaluation for the U draws of the group: after the reduction every lane holds
+    // every lp, so lane u of the group keeps draw u and the exp/division sequence (the bulk of
+    // this kernel's vector instructions, executed by all 64 lanes whatever they hold) runs once
+    // per U draws instead of once per draw; lane u also issues draw u's exchange.
+    double lp_sel = 0.0, y_sel = 0.0;
+    uint32_t s_sel = 0;
+    bool v_sel = false;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const double lp = group_sum(acc[u]) + b0;
-      const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y0[u] - 1.0 / (1.0 + exp(lp)) : lp - y0[u];
-      gcv[u] = 0.0;
-      if (gl == 0 && valid[u]) {
-        if (d.ablate & 1) {                      // timing only: no gradient-memory exchange
-          gcv[u] = g0;
-        } else {
-          // claim, read and update in ONE returning atomic: a repeated draw of the batch reads
-          // back the value just stored (same snapshot, same g0), so its gc is exactly 0
-          const double old = __hip_atomic_exchange(d.M + s[u], g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          gcv[u] = g0 - old;
-        }
+      if (gl == u) {
+        lp_sel = lp;
+        y_sel = y0[u];
+        s_sel = s[u];
+        v_sel = valid[u];
+      }
+    }
+    const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y_sel - 1.0 / (1.0 + exp(lp_sel)) : lp_sel - y_sel;
+    gcp = 0.0;
+    if (gl < U && v_sel) {
+      if (d.ablate & 1) {                        // timing only: no gradient-memory exchange
+        gcp = g0;
+      } else {
+        // claim, read and update in ONE returning atomic: a repeated draw of the batch reads
+        // back the value just stored (same snapshot, same g0), so its gc is exactly 0
+        const double old = __hip_atomic_exchange(d.M + s_sel, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gcp = g0 - old;
       }
     }
   }
@@ -427,13 +441,13 @@ struct K1Draws {
     double tot = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const double gc = __shfl(gcv[u], 0, kGroup);
+      const double gc = __shfl(gcp, u, kGroup);
       if (gc != 0.0 && !(d.ablate & 4)) {
         if (in(d, u, gl)) scatter_add<true>(Dl + jf[u], vf[u] * gc);
         if (tail(d, u)) tail_for_each(d, u, gl, [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
       }
-      tot += gcv[u];
     }
+    tot = gcp;     // every draw counted once: on lane u of its group
     return tot;
   }
 };
