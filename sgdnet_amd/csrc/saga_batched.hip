@@ -355,9 +355,20 @@ template <int U>
 struct K1Draws {
   uint32_t s[U];
   int jf[U], nnz[U];
-  double vf[U], y0[U];
-  double gcp;      // lane u of the group: gradient change of draw u (0 on the other lanes)
+  double vf[U];
+  double gcp;      // on lane owner(u) of the group: gradient change of draw u (0 on the other lanes)
   bool valid[U];
+  // this lane's own draw q = draw_of(gl) (its sample and response come from this lane's own loads,
+  // not from a selection among the U per-draw registers: such a selection is compiled into an
+  // indexed lookup of a private-memory copy of the arrays)
+  uint32_t s_own;
+  double y_own;
+  bool v_own;
+  static __device__ __forceinline__ int draw_of(int gl) { return U == 4 ? gl >> 2 : gl; }
+
+  // the lane of the group that evaluates draw u (see gradient())
+  static __device__ __forceinline__ int owner(int u) { return U == 4 ? 4 * u : u; }
+  static __device__ __forceinline__ bool is_owner(int gl) { return U == 4 ? (gl & 3) == 0 : gl < U; }
 
   // stream indices + record loads (nothing waits here)
   // `safe` < hi: the draw whose (discarded) record stands in for positions past the end
@@ -371,10 +382,17 @@ struct K1Draws {
       s[u] = sp[valid[u] ? iu : safe];
       if (d.ablate & 16) s[u] &= 1023u;         // timing only: records from a cache-resident set
     }
+    {
+      const int q = draw_of(gl);
+      const int iq = i + q * step;
+      v_own = q < U && iq < hi;
+      s_own = sp[v_own ? iq : safe];
+      if (d.ablate & 16) s_own &= 1023u;
+      y_own = *reinterpret_cast<const double*>(d.rec + (size_t)s_own * d.rec_stride);
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const char* base = d.rec + (size_t)s[u] * d.rec_stride;
-      y0[u] = *reinterpret_cast<const double*>(base);
       nnz[u] = *reinterpret_cast<const int*>(base + 8);
       jf[u] = gl < cap ? reinterpret_cast<const int*>(base + 16)[gl] : 0;
       vf[u] = gl < cap ? reinterpret_cast<const double*>(base + d.rec_val_off)[gl] : 0.0;
@@ -406,26 +424,34 @@ struct K1Draws {
         acc[u] += a;
       }
     }
-    // One gradient evaluation for the U draws of the group: after the reduction every lane holds
-    // every lp, so lane u of the group keeps draw u and the exp/division sequence (the bulk of
-    // this kernel's vector instructions, executed by all 64 lanes whatever they hold) runs once
-    // per U draws instead of once per draw; lane u also issues draw u's exchange.
-    double lp_sel = 0.0, y_sel = 0.0;
-    uint32_t s_sel = 0;
-    bool v_sel = false;
+    // One gradient evaluation for the U draws of the group.  The exp/division sequence is the
+    // bulk of this kernel's vector instructions and costs the same whatever the 64 lanes hold,
+    // so the U dot products are reduced TOGETHER: a merged butterfly (U = 4: xor 8 halves four
+    // values to two, xor 4 to one, xor 2 and xor 1 finish: 5 shuffles instead of 16) that
+    // leaves draw q's x.w in lanes 4q..4q+3 of the group.  Lane owner(q) then evaluates draw
+    // q's gradient and issues its exchange: one evaluation and one atomic instruction per U draws.
+    double lp_sel = 0.0;
+    if (U == 4) {
+      const bool hi8 = (gl & 8) != 0, hi4 = (gl & 4) != 0;
+      const double r0 = (hi8 ? acc[2] : acc[0]) + __shfl_xor(hi8 ? acc[0] : acc[2], 8, kGroup);
+      const double r1 = (hi8 ? acc[3] : acc[1]) + __shfl_xor(hi8 ? acc[1] : acc[3], 8, kGroup);
+      double t = (hi4 ? r1 : r0) + __shfl_xor(hi4 ? r0 : r1, 4, kGroup);
+      t += __shfl_xor(t, 2, kGroup);
+      t += __shfl_xor(t, 1, kGroup);
+      lp_sel = t + b0;
+    } else {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const double lp = group_sum(acc[u]) + b0;
-      if (gl == u) {
-        lp_sel = lp;
-        y_sel = y0[u];
-        s_sel = s[u];
-        v_sel = valid[u];
+      for (int u = 0; u < U; ++u) {
+        const double lp = group_sum(acc[u]) + b0;
+        if (gl == owner(u)) lp_sel = lp;
       }
     }
+    const double y_sel = y_own;
+    const uint32_t s_sel = s_own;
+    const bool v_sel = v_own;
     const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y_sel - 1.0 / (1.0 + exp(lp_sel)) : lp_sel - y_sel;
     gcp = 0.0;
-    if (gl < U && v_sel) {
+    if (is_owner(gl) && v_sel) {
       if (d.ablate & 1) {                        // timing only: no gradient-memory exchange
         gcp = g0;
       } else {
@@ -441,13 +467,13 @@ struct K1Draws {
     double tot = 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const double gc = __shfl(gcp, u, kGroup);
+      const double gc = __shfl(gcp, owner(u), kGroup);
       if (gc != 0.0 && !(d.ablate & 4)) {
         if (in(d, u, gl)) scatter_add<true>(Dl + jf[u], vf[u] * gc);
         if (tail(d, u)) tail_for_each(d, u, gl, [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
       }
     }
-    tot = gcp;     // every draw counted once: on lane u of its group
+    tot = gcp;     // every draw counted once: on its owner lane
     return tot;
   }
 };
@@ -522,11 +548,22 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     // for the exchange -- and the bursts of the two halves now overlap instead of queueing):
     //   load A, load B | gradient A (+exchange A) | gradient B (+exchange B) | scatter A | scatter B
 #ifndef SGDNET_PIPE
-#define SGDNET_PIPE 2
+#define SGDNET_PIPE 4
 #endif
     constexpr int U = SGDNET_PIPE;
     const double* wv = kWLds ? Dl + KP : d.w;
     const uint32_t* sp = d.stream + t0;
+#ifndef SGDNET_TWO_HALVES
+    // one pass of U draws per group (two software-pipelined half-passes of U/2 measured 2 us
+    // slower once the gradient was evaluated once per pass: the kernel is bound by the vector
+    // instructions it issues as much as by the memory system)
+    for (int i = lo + group; i < hi; i += kGroups * U) {
+      K1Draws<U> A;
+      A.load(d, sp, i, hi, kGroups, gl, i);
+      A.gradient(d, gl, bk[0], wv);
+      gct[0] += A.scatter(d, gl, Dl);
+    }
+#else
     for (int i = lo + group; i < hi; i += 2 * kGroups * U) {
       K1Draws<U> A, B;
       A.load(d, sp, i, hi, kGroups, gl, i);
@@ -536,6 +573,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
       gct[0] += A.scatter(d, gl, Dl);
       gct[0] += B.scatter(d, gl, Dl);
     }
+#endif
   } else {
     for (int i = lo + group; i < hi; i += kGroups) {
       double gc[KMAX];
