@@ -503,24 +503,37 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   const int K = KMAX == 1 ? 1 : d.K;
   const int64_t KP = (int64_t)K * d.p;
   PHASE(0);
-  for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) Dl[i] = 0.0;
+  // the tables are moved as 16-byte pairs (half the instructions of a double-wise loop: the
+  // kernel is bound by the instructions it issues as much as by memory); an odd last element
+  // is handled by one thread
+  typedef double pair_t __attribute__((ext_vector_type(2)));
+  const int64_t KP2 = KP >> 1;
+  {
+    pair_t* D2 = reinterpret_cast<pair_t*>(Dl);
+    for (int64_t i = threadIdx.x; i < KP2; i += kLdsBlock) D2[i] = pair_t{0.0, 0.0};
+    if ((KP & 1) && threadIdx.x == 0) Dl[KP - 1] = 0.0;
+  }
   if (kWLds) {
-    // all loads of a thread in flight before the first LDS store (a plain copy loop waits
-    // for every load in turn: 2.4 us instead of 0.5 us for 80 KB)
+    // all loads of a thread in flight before its first LDS store (a plain copy loop waits for
+    // every load in turn)
     constexpr int kStage = 4;
-    for (int64_t i0 = threadIdx.x; i0 < KP; i0 += (int64_t)kLdsBlock * kStage) {
-      double t[kStage];
+    double* Wl = Dl + KP + (KP & 1);            // 16-byte aligned
+    const pair_t* w2 = reinterpret_cast<const pair_t*>(d.w);
+    pair_t* W2 = reinterpret_cast<pair_t*>(Wl);
+    for (int64_t i0 = threadIdx.x; i0 < KP2; i0 += (int64_t)kLdsBlock * kStage) {
+      pair_t t[kStage];
 #pragma unroll
       for (int r = 0; r < kStage; ++r) {
         const int64_t i = i0 + (int64_t)r * kLdsBlock;
-        t[r] = i < KP ? d.w[i] : 0.0;
+        t[r] = i < KP2 ? w2[i] : pair_t{0.0, 0.0};
       }
 #pragma unroll
       for (int r = 0; r < kStage; ++r) {
         const int64_t i = i0 + (int64_t)r * kLdsBlock;
-        if (i < KP) Dl[KP + i] = t[r];
+        if (i < KP2) W2[i] = t[r];
       }
     }
+    if ((KP & 1) && threadIdx.x == 0) Wl[KP - 1] = d.w[KP - 1];
   }
   __syncthreads();
   PHASE(1);
@@ -551,7 +564,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
 #define SGDNET_PIPE 4
 #endif
     constexpr int U = SGDNET_PIPE;
-    const double* wv = kWLds ? Dl + KP : d.w;
+    const double* wv = kWLds ? Dl + KP + (KP & 1) : d.w;
     const uint32_t* sp = d.stream + t0;
 #ifndef SGDNET_TWO_HALVES
     // one pass of U draws per group (two software-pipelined half-passes of U/2 measured 2 us
@@ -589,8 +602,15 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   // flush the private copy as this workgroup's slab: plain coalesced stores (atomics would
   // cap the flush at the ~1.3 TB/s atomic rate); the sweep sums the slabs in a fixed order
   double* slab = d.slab + (int64_t)blockIdx.x * KP;
-  if (!(d.ablate & 2))
-    for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
+  if (!(d.ablate & 2)) {
+    if ((KP & 1) == 0) {                        // slabs start at multiples of KP doubles: pairs stay aligned
+      const pair_t* D2 = reinterpret_cast<const pair_t*>(Dl);
+      pair_t* S2 = reinterpret_cast<pair_t*>(slab);
+      for (int64_t i = threadIdx.x; i < KP2; i += kLdsBlock) S2[i] = D2[i];
+    } else {
+      for (int64_t i = threadIdx.x; i < KP; i += kLdsBlock) slab[i] = Dl[i];
+    }
+  }
   PHASE(4);
   if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kLdsBlock>(d, K, batch_id, gct);
   PHASE(5);
@@ -1253,7 +1273,7 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     g.lds_bytes = table;
     static const bool w_lds_on = [] { const char* e = getenv("SGDNET_W_LDS"); return !e || atoi(e) != 0; }();
     g.w_lds = d.K == 1 && w_lds_on && 2 * table + kLdsStaticReserve <= kLdsPerCu;
-    if (g.w_lds) g.lds_bytes = 2 * table;
+    if (g.w_lds) g.lds_bytes = 2 * table + 16;   // + alignment slack of the second table
   } else {
     g.draws_per_block = kBlock / kGroup;
     g.grid = (m + g.draws_per_block - 1) / g.draws_per_block;
