@@ -450,6 +450,22 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   if (rc) return rc;
 
   DrawSource draws(ctl);
+  // built-in generator: the draws are produced in HBM (r_rng_device.hip), one epoch ahead of
+  // the epoch that consumes them, on a side stream (solver.cpp: solver_rng_*)
+  const bool pipe = draws.internal();
+  struct PipeGuard {
+    sgdnet_solver* s;
+    sgdnet_rng* rng;
+    bool on;
+    ~PipeGuard() { if (on) (void)solver_rng_close(s, rng); }
+  } pipe_guard{S, &draws.rng, false};
+  if (pipe) {
+    rc = solver_rng_open(S, &draws.rng, n);
+    if (rc) return rc;
+    pipe_guard.on = true;
+    rc = solver_rng_prefetch(S);
+    if (rc) return rc;
+  }
   std::vector<uint32_t> chunk((size_t)n);
   std::vector<double> w((size_t)(K * p)), b((size_t)K), xbb((size_t)K);
   std::vector<double> losses(ctl->debug ? (size_t)ctl->max_iter : 0);
@@ -470,9 +486,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // one epoch per launch: exactly the draws the reference would consume are taken
     // from the source (R's RNG state after the call matches, SURVEY.md 8b "RNG")
     while (epochs < ctl->max_iter && !converged) {
-      if (draws.internal()) {
-        // built-in generator: the epoch's draws are produced in HBM (r_rng_device.hip)
-        rc = sgdnet_solver_generate_stream(S, &draws.rng, n);
+      int64_t stream_off = 0;
+      if (pipe) {
+        rc = solver_rng_prefetch(S);               // next epoch's draws, concurrently
+        if (rc) return rc;
+        rc = solver_rng_acquire(S, &stream_off);   // this epoch's
         draws.pos += n;
       } else {
         rc = draws.fill((uint32_t)n, chunk.data(), n);
@@ -481,9 +499,13 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       }
       if (rc) return rc;
       unsigned ran = 0;
-      rc = sgdnet_solver_run(S, mode, batch, 0, n, 1, ctl->tol, &ran, &converged,
+      rc = sgdnet_solver_run(S, mode, batch, stream_off, n, 1, ctl->tol, &ran, &converged,
                              ctl->debug ? losses.data() + epochs : nullptr);
       if (rc) return rc;
+      if (pipe) {
+        rc = solver_rng_release(S);
+        if (rc) return rc;
+      }
       epochs += ran;
       if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && batch > 64) {
         // guard of the automatic window: the stale-sum step is only stable below ~L_max/L_F
@@ -539,6 +561,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   pt.mark("lambda path (SAGA + deviance)");
   out->npasses = n_iter;
   out->draws_used = draws.pos;
+  if (pipe) {
+    pipe_guard.on = false;
+    rc = solver_rng_close(S, &draws.rng);          // state after exactly the epochs that ran
+    if (rc) return rc;
+  }
   draws.finish();
   return SGDNET_OK;
 }

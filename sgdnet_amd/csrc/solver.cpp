@@ -60,6 +60,17 @@ struct sgdnet_solver {
   int64_t stream_len = 0;
   int64_t stream_cap = 0;
   uint32_t* rng_dev = nullptr;  // 625 words: the device copy of a sgdnet_rng
+  // sample-order pipeline of the fit driver (solver_rng_*): the next epoch's draws are
+  // generated on a side stream while the current epoch runs
+  struct RngPipe {
+    bool open = false;
+    hipStream_t st = nullptr;
+    hipEvent_t ready[2] = {nullptr, nullptr};   // slot filled (side stream)
+    hipEvent_t freed[2] = {nullptr, nullptr};   // slot consumed (solver stream)
+    uint32_t* state[2] = {nullptr, nullptr};    // generation g reads state[g & 1], writes state[(g + 1) & 1]
+    int64_t n = 0;
+    int64_t gens = 0, used = 0;
+  } pipe;
   int64_t nnz = 0;
   bool penalty_set = false;
   // cached epoch graph
@@ -583,6 +594,15 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
     if (ev) (void)hipEventDestroy(ev);
   if (s->stream_dev) (void)hipFree(s->stream_dev);
   if (s->rng_dev) (void)hipFree(s->rng_dev);
+  if (s->pipe.st) {
+    (void)hipStreamSynchronize(s->pipe.st);
+    (void)hipStreamDestroy(s->pipe.st);
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (s->pipe.ready[i]) (void)hipEventDestroy(s->pipe.ready[i]);
+    if (s->pipe.freed[i]) (void)hipEventDestroy(s->pipe.freed[i]);
+    if (s->pipe.state[i]) (void)hipFree(s->pipe.state[i]);
+  }
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
 }
@@ -693,12 +713,87 @@ int sgdnet_solver_generate_stream(sgdnet_solver* s, sgdnet_rng* rng, int64_t cou
   if (!s->rng_dev) SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rng_dev), sizeof(sgdnet_rng)));
   static_assert(sizeof(sgdnet_rng) == 625 * sizeof(uint32_t), "sgdnet_rng is mti + 624 words");
   SGD_HIP_TRY(hipMemcpyAsync(s->rng_dev, rng, sizeof(sgdnet_rng), hipMemcpyHostToDevice, s->st));
-  rc = launch_rng_fill(s->rng_dev, (uint32_t)s->d.n, s->stream_dev, count, s->st);
+  rc = launch_rng_fill(s->rng_dev, s->rng_dev, (uint32_t)s->d.n, s->stream_dev, count, s->st);
   if (rc) return rc;
   SGD_HIP_TRY(hipMemcpyAsync(rng, s->rng_dev, sizeof(sgdnet_rng), hipMemcpyDeviceToHost, s->st));
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   return SGDNET_OK;
 }
+
+}  // extern "C"
+
+// ---- sample-order pipeline (driver.cpp) -------------------------------------------------------
+// The stream buffer holds two epochs; epoch e reads half e & 1 while the side stream fills the
+// other half with the draws of epoch e + 1.  The generator state ping-pongs between two device
+// buffers, so the state after exactly `used` epochs survives one speculative generation.
+int solver_rng_open(sgdnet_solver* s, const sgdnet_rng* rng, int64_t n) {
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  auto& P = s->pipe;
+  int rc = reserve_stream(s, 2 * n);
+  if (rc) return rc;
+  if (!P.st) {
+    SGD_HIP_TRY(hipStreamCreateWithFlags(&P.st, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      SGD_HIP_TRY(hipEventCreateWithFlags(&P.ready[i], hipEventDisableTiming));
+      SGD_HIP_TRY(hipEventCreateWithFlags(&P.freed[i], hipEventDisableTiming));
+      SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&P.state[i]), sizeof(sgdnet_rng)));
+    }
+  }
+  SGD_HIP_TRY(hipMemcpy(P.state[0], rng, sizeof(sgdnet_rng), hipMemcpyHostToDevice));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  for (int i = 0; i < 2; ++i) SGD_HIP_TRY(hipEventRecord(P.freed[i], s->st));
+  P.n = n;
+  P.gens = P.used = 0;
+  P.open = true;
+  return SGDNET_OK;
+}
+
+// enqueue the next generation (never more than one ahead of the epoch being consumed)
+int solver_rng_prefetch(sgdnet_solver* s) {
+  auto& P = s->pipe;
+  if (!P.open || P.gens > P.used + 1) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  const int slot = (int)(P.gens & 1);
+  SGD_HIP_TRY(hipStreamWaitEvent(P.st, P.freed[slot], 0));
+  int rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
+                           s->stream_dev + (int64_t)slot * P.n, P.n, P.st);
+  if (rc) return rc;
+  SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
+  ++P.gens;
+  return SGDNET_OK;
+}
+
+// the solver's stream waits for the draws of the next unconsumed epoch; *offset = where they are
+int solver_rng_acquire(sgdnet_solver* s, int64_t* offset) {
+  auto& P = s->pipe;
+  if (!P.open || P.gens <= P.used) return SGDNET_EINVAL;
+  const int slot = (int)(P.used & 1);
+  SGD_HIP_TRY(hipStreamWaitEvent(s->st, P.ready[slot], 0));
+  *offset = (int64_t)slot * P.n;
+  return SGDNET_OK;
+}
+
+// the epoch that consumed the acquired draws has been enqueued on the solver's stream
+int solver_rng_release(sgdnet_solver* s) {
+  auto& P = s->pipe;
+  SGD_HIP_TRY(hipEventRecord(P.freed[P.used & 1], s->st));
+  ++P.used;
+  return SGDNET_OK;
+}
+
+// generator state after exactly `used` epochs (a speculative generation is discarded)
+int solver_rng_close(sgdnet_solver* s, sgdnet_rng* rng) {
+  auto& P = s->pipe;
+  if (!P.open) return SGDNET_OK;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(P.st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  SGD_HIP_TRY(hipMemcpy(rng, P.state[P.used & 1], sizeof(sgdnet_rng), hipMemcpyDeviceToHost));
+  P.open = false;
+  return SGDNET_OK;
+}
+
+extern "C" {
 
 int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_offset,
                       int64_t draws_per_epoch, unsigned max_epochs, double tol, unsigned* epochs_run,
