@@ -729,3 +729,37 @@ def test_fit_with_heavy_tailed_rows_uses_the_device_packer(sa, oracle):
         fit = sa.sgdnet(X, y, seed=3, mode=mode, **kw)
         assert fit.return_codes[0] == 0
         assert relerr(fit.beta[:, 0], ref["beta"][0, :, 0]) < (1e-9 if mode == "exact" else 1e-7)
+
+
+@pytest.mark.parametrize("family,K,n,p,dens,batch", [
+    ("binomial", 1, 70, 1, 0.9, 16),            # one feature
+    ("multinomial", 16, 900, 30, 0.2, 128),     # the largest class count of the batched kernels
+    ("mgaussian", 16, 400, 5, 0.6, 64),
+    ("gaussian", 1, 3, 2, 1.0, 2),              # fewer samples than lanes in a group
+    ("binomial", 1, 300, 4000, 0.002, 200),     # p >> n, most columns empty
+])
+def test_extreme_shapes_batched_and_exact(sa, oracle, family, K, n, p, dens, batch):
+    x, y = make_problem(family, K, n, p, dens, seed=41)
+    penalty = "grouplasso" if family == "mgaussian" else "elasticnet"
+    kw = dict(family=family, K=K, penalty=penalty, gamma=0.01, alpha=1e-3, beta=1e-3)
+    (ep, rc, st), (ep2, conv, got) = run_both(sa, oracle, x, y, epochs=2, mode="batched", batch=batch, **kw)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_BATCHED, k
+    (ep, rc, st), (ep2, conv, got) = run_both(sa, oracle, x, y, epochs=2, mode="exact", **kw)
+    for k in STATE:
+        assert relerr(got[k], st[k]) < TOL_EXACT, k
+
+
+def test_fit_with_more_than_sixteen_classes_falls_back_to_exact(sa, oracle):
+    rng = np.random.default_rng(8)
+    n, p, K = 600, 6, 18
+    X = sp.csc_matrix(rng.standard_normal((n, p)) * (rng.random((n, p)) < 0.7))
+    y = rng.integers(0, K, n)
+    y[:K] = np.arange(K)
+    y[K:2 * K] = np.arange(K)                              # every class at least twice
+    kw = dict(family="multinomial", alpha=0.5, lambda_=[0.01], standardize=False, thresh=1e-6, maxit=300)
+    ref = oracle.fit(X, y, seed=2, **kw)
+    fit = sa.sgdnet(X, y, seed=2, mode="batched", **kw)   # K > 16: the exact iteration, same stream
+    assert fit.npasses == ref["npasses"]
+    for k in range(K):
+        assert relerr(fit.beta[k][:, 0], ref["beta"][k, :, 0]) < 1e-8 or np.abs(ref["beta"][k, :, 0]).max() < 1e-12
