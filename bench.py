@@ -239,6 +239,9 @@ def main():
             "avg_launch_us": 1e3 * prof["gather_ms"] / max(1, prof["gather_launches"]),
             "algorithmic_bytes_per_launch": alg_bytes_epoch / max(1, prof["gather_launches"]),
             "sweep_avg_launch_us": 1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]),
+            # other ceilings for this access pattern (GB/s): the guide's measured float4 copy, and
+            # random 256-B records streamed by scripts/microbench/gather_rate (profiles/)
+            "ceilings": {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0},
         },
     }
 
