@@ -10,12 +10,13 @@ sample order, the matrix, y and the solver state resident in HBM before the
 timed region.  For N > 1 the driver launches one process per GPU
 (torch.distributed.run) and the samples are sharded; the total work is fixed as N
 grows ("strong" scaling).  --merge selects the exchange (sgdnet_amd/parallel.py):
-  sync  (default) every global batch is split across the ranks and its scatter
-        accumulator is all-reduced (RCCL) before the sweep: the iterates are those of the
-        single-GPU run, so epochs-to-tolerance does not change with N;
-  epoch one all-reduce of the packed state deltas per epoch, w averaged (the scheme of
-        SURVEY.md 8e): cheap, but the `convergence` object shows it does not reach the
-        tolerance at this workload's lambda = 1/n.
+  avg   (default) every rank runs the batched iteration on its own shard with local
+        normalisation; every n/32 draws per rank one RCCL all-reduce averages the weighted
+        state deltas [dG | dw | dgb | db].  Same fixed point, epochs-to-tolerance close to the
+        single-GPU run's (reported in `convergence`);
+  sync  every global batch is split across the ranks and its scatter accumulator is
+        all-reduced before the sweep: exactly the single-GPU iterates, one collective per
+        batch, no speed-up (reported as `alt_merge` when avg is the headline, and vice versa).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel
 (the batched gather kernel) by the algorithmic bytes of SURVEY.md 8d divided by
@@ -57,9 +58,9 @@ def main():
     ap.add_argument("--conv-max-epochs", type=int, default=400)
     ap.add_argument("--no-alt-merge", action="store_true",
                     help="N > 1: do not also measure the exchange scheme that --merge did not select")
-    ap.add_argument("--merge", default="sync", choices=["sync", "epoch"],
-                    help="N > 1: per-batch all-reduce of the scatter accumulator (exact) or per-epoch "
-                         "averaged merge")
+    ap.add_argument("--merge", default="avg", choices=["avg", "sync"],
+                    help="N > 1: periodic averaging of locally normalised shard runs (default), or a "
+                         "per-batch all-reduce of the scatter accumulator (exact single-GPU iterates)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -74,7 +75,8 @@ def main():
     import torch
     import sgdnet_amd as sa
     from sgdnet_amd import data as D
-    from sgdnet_amd.parallel import HipShard, HipSyncShard, ShardedSaga, SyncShardedSaga, shard_bounds
+    from sgdnet_amd.parallel import (HipShard, HipSyncShard, ShardedSaga, SyncShardedSaga, merge_segments,
+                                     shard_bounds)
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a HIP device: the SAGA backend has no CPU fallback")
@@ -154,21 +156,27 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     def make_job(mode):
-        """mode 'sync' | 'epoch' | 'none' -> (epoch callable, shard, description)."""
+        """mode 'sync' | 'avg' -> (epoch callable, shard, description, sync rounds)."""
         if mode == "sync":
+            S.set_n_total(n)
             sh = HipSyncShard(S, draws_per_epoch=n_local, device=dev, stage_on_host=(backend != "nccl"))
             sj = SyncShardedSaga(sh, n, world, batch, force_reduce=force_merge)
             desc = (f"sync: {backend} all-reduce of the scatter accumulator per global batch "
                     f"({sj.rounds} per epoch)" + (", stream-ordered" if backend == "nccl" else ""))
             return (lambda: sj.epoch(rank)), sh, desc, sj.rounds
-        sh = HipShard(S, batch=min(batch, n_local), draws_per_epoch=n_local, device=dev,
+        S.set_n_total(n_local)                    # local normalisation (sgdnet_amd/parallel.py)
+        lb = min(batch, n_local)
+        pdiv = int(os.environ.get("SGDNET_BENCH_PERIOD_DIV", "32"))     # merge period = n / pdiv draws per rank
+        segs = merge_segments(n_local, n, lb, period=max(1, n // pdiv)) if (world > 1 or force_merge) else [n_local]
+        sh = HipShard(S, batch=lb, draws_per_epoch=n_local, device=dev, weight=n_local / n,
                       stage_on_host=(backend != "nccl"), fused=fused)
-        sj = ShardedSaga(sh, world, force_merge=force_merge)
+        sj = ShardedSaga(sh, world, segs, force_merge=force_merge)
         desc = ("none" if world == 1 and not force_merge else
-                f"per-epoch {backend} all-reduce, w averaged" + (", stream-ordered" if fused else ""))
+                f"avg: locally normalised shard runs, {backend} all-reduce of the weighted state deltas every "
+                f"{segs[0]} draws per rank ({len(segs)} per epoch)" + (", stream-ordered" if fused else ""))
         return sj.epoch, sh, desc, 0
 
-    run_epoch, shard, merge_desc, sync_rounds = make_job("sync" if sync_mode else "epoch")
+    run_epoch, shard, merge_desc, sync_rounds = make_job("sync" if sync_mode else "avg")
 
     def fence():
         S.sync()
@@ -289,7 +297,7 @@ def main():
     # (`sync` is exact but pays a collective per batch; `epoch` is the scheme of the
     # north star, fast per epoch, and does not reach the tolerance at this lambda)
     if (world > 1 or force_merge) and not args.no_alt_merge:
-        alt = "epoch" if sync_mode else "sync"
+        alt = "avg" if sync_mode else "sync"
         if sync_mode:
             shard.close()                           # unbind the sync buffer
         cold_start()

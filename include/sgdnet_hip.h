@@ -243,6 +243,10 @@ int64_t sgdnet_solver_delta_len(const sgdnet_solver* s);
  * synchronisation.  export_delta_async / apply_merged_async only enqueue. */
 void* sgdnet_solver_stream(sgdnet_solver* s);
 int sgdnet_solver_export_delta_async(sgdnet_solver* s, void* device_buf);
+/* same, every delta multiplied by `weight` (the shard's share n_local / n_total) */
+int sgdnet_solver_export_delta_weighted_async(sgdnet_solver* s, void* device_buf, double weight);
+/* state <- snapshot + merged (coefficients: + w_weight * merged); the result also becomes the
+ * snapshot of the next local run */
 int sgdnet_solver_apply_merged_async(sgdnet_solver* s, const void* device_buf, double w_weight);
 
 /* ------------------------------------------------------------------------ */
@@ -259,6 +263,11 @@ int sgdnet_solver_sync_begin(sgdnet_solver* s, int64_t stream_offset, int64_t dr
 int sgdnet_solver_sync_gather(sgdnet_solver* s, int64_t t0_local, int64_t m_local, int round);
 int sgdnet_solver_sync_sweep(sgdnet_solver* s, int64_t m_global, int64_t m_local, int round);
 int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds);
+
+/* The n that g_sum increments are divided by (default: n_total of the problem description).
+ * A sample-sharded job sets it to the shard size (local normalisation) or to the
+ * job's sample count (synchronous mode). */
+int sgdnet_solver_set_n_total(sgdnet_solver* s, int64_t n_total);
 
 /* ConvergenceCheck on the current w against the previous call's w (device-side). */
 int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged);

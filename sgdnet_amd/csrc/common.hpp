@@ -118,9 +118,8 @@ int64_t batch_gather_slab_doubles(const SagaDev& d, int m);
 int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
-int launch_delta_export(const SagaDev& d, const double* ref, double* out, hipStream_t st);
-int launch_delta_apply(const SagaDev& d, const double* ref, const double* merged, double w_weight,
-                       hipStream_t st);
+int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st);
+int launch_delta_apply(const SagaDev& d, double* ref, const double* merged, double w_weight, hipStream_t st);
 int batched_max_classes();
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st);

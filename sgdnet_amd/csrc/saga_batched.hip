@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kBlock) void saga_loss_kernel(SagaDev d, LamParams*
 
 // Multi-GPU merge helpers.  Layout: [dG (Kp) | dw (Kp) | dgb (K) | db (K)].
 __global__ __launch_bounds__(kBlock) void saga_delta_export_kernel(SagaDev d, const double* ref,
-                                                                   double* out) {
+                                                                   double* out, double weight) {
   const int64_t KP = (int64_t)d.K * d.p;
   const int64_t len = 2 * KP + 2 * d.K;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
@@ -1202,19 +1202,23 @@ __global__ __launch_bounds__(kBlock) void saga_delta_export_kernel(SagaDev d, co
     else if (i < 2 * KP) cur = d.w[i - KP];
     else if (i < 2 * KP + d.K) cur = d.gb[i - 2 * KP];
     else cur = d.b[i - 2 * KP - d.K];
-    out[i] = cur - ref[i];
+    out[i] = weight * (cur - ref[i]);
   }
 }
 
-__global__ __launch_bounds__(kBlock) void saga_delta_apply_kernel(SagaDev d, const double* ref,
-                                                                  const double* merged, double w_weight) {
+// the merged state also becomes the new reference (the next local run's snapshot)
+__global__ __launch_bounds__(kBlock) void saga_delta_apply_kernel(SagaDev d, double* ref, const double* merged,
+                                                                  double w_weight) {
   const int64_t KP = (int64_t)d.K * d.p;
   const int64_t len = 2 * KP + 2 * d.K;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
-    if (i < KP) d.G[i] = ref[i] + merged[i];
-    else if (i < 2 * KP) d.w[i - KP] = ref[i] + w_weight * merged[i];
-    else if (i < 2 * KP + d.K) d.gb[i - 2 * KP] = ref[i] + merged[i];
-    else d.b[i - 2 * KP - d.K] = ref[i] + w_weight * merged[i];
+    const bool coef = (i >= KP && i < 2 * KP) || i >= 2 * KP + d.K;
+    const double v = ref[i] + (coef ? w_weight : 1.0) * merged[i];
+    ref[i] = v;
+    if (i < KP) d.G[i] = v;
+    else if (i < 2 * KP) d.w[i - KP] = v;
+    else if (i < 2 * KP + d.K) d.gb[i - 2 * KP] = v;
+    else d.b[i - 2 * KP - d.K] = v;
   }
 }
 
@@ -1441,17 +1445,16 @@ int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st) {
   return SGDNET_OK;
 }
 
-int launch_delta_export(const SagaDev& d, const double* ref, double* out, hipStream_t st) {
+int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st) {
   const int64_t len = 2 * (int64_t)d.K * d.p + 2 * d.K;
   int grid = (int)((len + kBlock - 1) / kBlock);
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(saga_delta_export_kernel, dim3(grid), dim3(kBlock), 0, st, d, ref, out);
+  hipLaunchKernelGGL(saga_delta_export_kernel, dim3(grid), dim3(kBlock), 0, st, d, ref, out, weight);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }
 
-int launch_delta_apply(const SagaDev& d, const double* ref, const double* merged, double w_weight,
-                       hipStream_t st) {
+int launch_delta_apply(const SagaDev& d, double* ref, const double* merged, double w_weight, hipStream_t st) {
   const int64_t len = 2 * (int64_t)d.K * d.p + 2 * d.K;
   int grid = (int)((len + kBlock - 1) / kBlock);
   if (grid > 2048) grid = 2048;

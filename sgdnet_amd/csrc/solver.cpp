@@ -74,9 +74,14 @@ struct sgdnet_solver {
   int64_t nnz = 0;
   bool penalty_set = false;
   // cached epoch graph
+  // captured epochs, one per (batch, draws) shape; gexec is the one selected by ensure_graph
+  struct GraphEntry {
+    int64_t batch, draws;
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+  };
+  std::vector<GraphEntry> graphs;
   hipGraphExec_t gexec = nullptr;
-  hipGraph_t graph = nullptr;
-  int64_t g_batch = 0, g_draws = 0;
   bool w_prev_valid = false;
   double last_change = 0.0, last_size = 0.0;
   int64_t slab_cap = 0;         // doubles the slab buffer can hold
@@ -135,11 +140,12 @@ void batch_factors(double alpha, double gamma, int64_t m, double* r_m, double* l
 }
 
 void drop_graph(sgdnet_solver* s) {
-  if (s->gexec) (void)hipGraphExecDestroy(s->gexec);
-  if (s->graph) (void)hipGraphDestroy(s->graph);
+  for (auto& g : s->graphs) {
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (g.graph) (void)hipGraphDestroy(g.graph);
+  }
+  s->graphs.clear();
   s->gexec = nullptr;
-  s->graph = nullptr;
-  s->g_batch = s->g_draws = 0;
 }
 
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
@@ -209,8 +215,18 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
 }
 
 int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
-  if (s->gexec && s->g_batch == batch && s->g_draws == draws) return SGDNET_OK;
-  drop_graph(s);
+  for (auto& g : s->graphs)
+    if (g.batch == batch && g.draws == draws) {
+      s->gexec = g.exec;
+      return SGDNET_OK;
+    }
+  if (s->graphs.size() >= 4) {   // a sharded epoch uses at most two shapes (segments + remainder)
+    auto& old = s->graphs.front();
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    (void)hipGraphExecDestroy(old.exec);
+    (void)hipGraphDestroy(old.graph);
+    s->graphs.erase(s->graphs.begin());
+  }
   SGD_HIP_TRY(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
   int rc = enqueue_epoch_kernels(s, batch, draws, nullptr);
   hipGraph_t g = nullptr;
@@ -223,10 +239,15 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
     set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e));
     return SGDNET_EHIP;
   }
-  s->graph = g;
-  SGD_HIP_TRY(hipGraphInstantiate(&s->gexec, g, nullptr, nullptr, 0));
-  s->g_batch = batch;
-  s->g_draws = draws;
+  hipGraphExec_t ex = nullptr;
+  e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    return SGDNET_EHIP;
+  }
+  s->graphs.push_back({batch, draws, g, ex});
+  s->gexec = ex;
   return SGDNET_OK;
 }
 
@@ -1055,10 +1076,14 @@ int sgdnet_solver_snapshot(sgdnet_solver* s) {
 
 void* sgdnet_solver_stream(sgdnet_solver* s) { return s ? static_cast<void*>(s->st) : nullptr; }
 
-int sgdnet_solver_export_delta_async(sgdnet_solver* s, void* device_buf) {
+int sgdnet_solver_export_delta_weighted_async(sgdnet_solver* s, void* device_buf, double weight) {
   if (!s || !device_buf) return SGDNET_EINVAL;
   SGD_HIP_TRY(hipSetDevice(s->device));
-  return launch_delta_export(s->d, s->ref, static_cast<double*>(device_buf), s->st);
+  return launch_delta_export(s->d, s->ref, static_cast<double*>(device_buf), weight, s->st);
+}
+
+int sgdnet_solver_export_delta_async(sgdnet_solver* s, void* device_buf) {
+  return sgdnet_solver_export_delta_weighted_async(s, device_buf, 1.0);
 }
 
 int sgdnet_solver_apply_merged_async(sgdnet_solver* s, const void* device_buf, double w_weight) {
@@ -1170,6 +1195,15 @@ int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds) {
   if (rc) return rc;
   s->lam.stream_base += s->lam.draws_per_epoch;   // mirrors saga_epoch_end_kernel
   s->lam.batch_seq += rounds;
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_set_n_total(sgdnet_solver* s, int64_t n_total) {
+  if (!s || n_total <= 0) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  s->d.n_total = (double)n_total;
+  drop_graph(s);   // captured kernels carry the old value
   return SGDNET_OK;
 }
 

@@ -1,39 +1,50 @@
 """Sample-sharded SAGA across the GPUs of one node (BASELINE north star).
 
-Two drivers share the sample sharding (shard_bounds):
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Rank r holds a
+contiguous shard of the samples and their gradient-memory rows; the model state
+(w, g_sum, intercept, g_sum_intercept) is replicated.  Two exchange schemes:
 
-* SyncShardedSaga (default): every GLOBAL batch of B draws is split across the ranks, each
-  rank gathers its B/world draws against the replicated snapshot w into the scatter
-  accumulator, ONE all-reduce sums [D | intercept accumulator] (K*p + 1024*K doubles), and
-  every rank applies the identical feature sweep.  The iterates are exactly those of the
-  single-GPU batched mode with batch B over the interleaved sample order, so convergence is
-  that of one GPU; the cost is one collective per batch.
-* ShardedSaga (per-epoch merge, below): one all-reduce per epoch, averaged iterates.  Cheap,
-  but only safe when the problem is strongly regularised -- on the C4 shape (lambda = 1/n)
-  the averaged iteration oscillates (scripts/merge_rule_experiment.py).
+* ShardedSaga -- periodic averaging with local normalisation (default).  Every rank runs the
+  batched SAGA iteration on ITS shard as if the shard were the whole data set (g_sum increments
+  divided by n_local), starting from the replicated (w, g_sum).  After every `period` local draws
+  one all-reduce sums the packed deltas [dG | dw | dgb | db] (2*K*p + 2*K doubles, 160 KB at 10k
+  features), each pre-scaled by the shard's weight n_local / n_total, and every rank continues
+  from ref + sum.  At the optimum every delta is zero, so the fixed point is the reference's.
+  The direction a rank follows in expectation is  grad f_r(w) - grad f_r(w_ref) + g_sum_ref :
+  its own shard with full curvature plus a stale correction for the others (the DANE
+  correction), which is what makes the local runs agree with each other.  It is stable when the
+  local runs are short: measured (scripts/merge_rule_experiment3.py and the HIP kernels,
+  DESIGN.md 8) with period = n_total / 32 draws per rank the epochs-to-tolerance are those of
+  one process for 2-16 ranks and lambda from 0.1/n to 10/n; n_total / 16 costs up to 1.6x the
+  epochs on one of the two benchmark shapes, n_total / 2 does not converge.  The first version of this file summed dG with weight 1 over
+  globally normalised local runs and averaged w once per epoch: that one does not converge at
+  lambda = 1/n (every rank then sees its own shard's curvature diluted by 1 / world).
+* SyncShardedSaga -- every GLOBAL batch of B draws is split across the ranks, one all-reduce per
+  batch sums the scatter accumulator, every rank applies the same sweep: the iterates are
+  exactly those of the single-GPU batched mode over the interleaved sample order; one
+  collective per batch (77 per epoch at the 10M x 10k benchmark shape) and no speed-up.
 
-Per-epoch merge in detail:
-
-One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI).  Rank r
-holds a contiguous shard of the samples and their gradient-memory rows; the model
-state (w, g_sum, intercept, g_sum_intercept) is replicated.  One job epoch =
-n_total inner iterations, n_total / world of them on every rank, followed by ONE
-all-reduce of the packed deltas [dG | dw | dgb | db] (2*K*p + 2*K doubles; 160 KB
-at 10k features, i.e. latency-bound, so a single fused buffer):
-
-    g_sum, g_sum_intercept  <-  ref + sum_r delta_r        (exact: g_sum is linear in
-                                                            the per-sample memory)
-    w, intercept            <-  ref + w_weight * sum_r delta_r   (w_weight = 1/world)
-
-The fixed point is the reference's: at the optimum every delta is zero.  The
-trajectory is not the sequential one, so parity for world > 1 is asserted at
-convergence (tests/test_parallel_gloo.py).
-
-The local solver is duck-typed (`snapshot`, `local_epoch`, `export_delta`,
-`apply_merged`) so that the merge logic is testable on CPU with gloo; the product
-binding is HipShard below.  The torch import is plumbing (process group, device
-buffer), not compute.
+The local solver is duck-typed (`snapshot`, `local_run`, `export_delta`, `apply_merged`) so
+that the merge logic is testable on CPU with gloo; the product binding is HipShard below.  The
+torch import is plumbing (process group, device buffer), not compute.
 """
+
+
+def merge_segments(n_local, n_total, batch, period=None):
+    """Draws per local run between two merges: [seg, seg, ..., remainder], summing to n_local.
+    period (draws per rank) defaults to n_total / 32, rounded down to a whole number of batches
+    (at least one)."""
+    if period is None:
+        period = max(1, n_total // 32)
+    b = max(1, min(batch, n_local))
+    seg = max(b, (period // b) * b)
+    out = []
+    left = n_local
+    while left > 0:
+        take = min(seg, left)
+        out.append(take)
+        left -= take
+    return out
 
 
 class HipShard:
@@ -45,7 +56,8 @@ class HipShard:
     epoch is ~0.4 ms, so three host syncs per epoch would cost a quarter of it).
     """
 
-    def __init__(self, solver, *, batch, draws_per_epoch, device, stage_on_host=False, fused=False):
+    def __init__(self, solver, *, batch, draws_per_epoch, device, weight=1.0, stage_on_host=False,
+                 fused=False):
         import torch
 
         from . import _lib
@@ -54,6 +66,7 @@ class HipShard:
         self.solver = solver
         self.batch = batch
         self.draws = draws_per_epoch
+        self.weight = float(weight)           # n_local / n_total: this shard's share of the average
         self.buf = torch.zeros(solver.delta_len(), dtype=torch.float64, device=device)
         # functional rehearsals with a CPU-only backend (gloo) reduce a host copy
         self.host = torch.zeros_like(self.buf, device="cpu") if stage_on_host else None
@@ -66,61 +79,67 @@ class HipShard:
     def snapshot(self):
         self.solver.snapshot()
 
-    def local_epoch(self):
-        self.solver.enqueue_epochs(1, batch=self.batch, stream_offset=self.offset,
-                                   draws_per_epoch=self.draws)
-        self.offset += self.draws
+    def local_run(self, draws):
+        self.solver.enqueue_epochs(1, batch=min(self.batch, draws), stream_offset=self.offset,
+                                   draws_per_epoch=draws)
+        self.offset += draws
 
     def export_delta(self):
+        self.solver.export_delta_async(self.buf.data_ptr(), self.weight)
         if self.ext is not None:
-            self.solver.export_delta_async(self.buf.data_ptr())
             return self.buf
-        self.solver.export_delta(self.buf.data_ptr())   # synchronises the solver's stream
+        self.solver.sync()
         if self.host is not None:
             self.host.copy_(self.buf)
             return self.host
         return self.buf
 
-    def apply_merged(self, buf, w_weight):
+    def apply_merged(self, buf):
         import torch
 
         if self.ext is not None:
-            self.solver.apply_merged_async(self.buf.data_ptr(), w_weight)
+            self.solver.apply_merged_async(self.buf.data_ptr(), 1.0)
             return
         if self.host is not None:
             self.buf.copy_(buf)
         torch.cuda.synchronize()                        # all-reduce ran on torch's stream
-        self.solver.apply_merged(self.buf.data_ptr(), w_weight)
+        self.solver.apply_merged(self.buf.data_ptr(), 1.0)
 
 
 class ShardedSaga:
-    """Per-epoch driver of the sharded job; identical on every rank."""
+    """Periodic averaging of locally normalised shard runs; identical on every rank.
 
-    def __init__(self, shard, world_size, w_weight=None, group=None, force_merge=False):
+    segments: draws of the local runs of one job epoch (merge_segments); one all-reduce after
+    each.  The shard's deltas arrive pre-scaled by its weight (HipShard.export_delta), so the
+    merged state is ref + sum over ranks."""
+
+    def __init__(self, shard, world_size, segments, group=None, force_merge=False):
         self.shard = shard
         self.world = world_size
-        self.w_weight = (1.0 / world_size) if w_weight is None else w_weight
+        self.segments = list(segments)
         self.group = group
         self.force_merge = force_merge        # rehearse the merge path with a single rank
 
     def epoch(self):
         sh = self.shard
         if self.world == 1 and not self.force_merge:
-            sh.local_epoch()
+            for seg in self.segments:
+                sh.local_run(seg)
             return
         import torch.distributed as dist
 
-        sh.snapshot()
-        sh.local_epoch()
-        buf = sh.export_delta()
         ext = getattr(sh, "ext", None)
-        if ext is not None:
-            import torch
-            with torch.cuda.stream(ext):      # the collective is ordered on the solver's stream
+        sh.snapshot()                         # later local runs start from apply_merged's result
+        for seg in self.segments:
+            sh.local_run(seg)
+            buf = sh.export_delta()
+            if ext is not None:
+                import torch
+                with torch.cuda.stream(ext):  # the collective is ordered on the solver's stream
+                    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            else:
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        sh.apply_merged(buf, self.w_weight)
+            sh.apply_merged(buf)
 
 
 class HipSyncShard:

@@ -248,12 +248,15 @@ class SagaSolver:
     def sync_end(self, rounds):
         check(self._L.sgdnet_solver_sync_end(self._h, rounds))
 
+    def set_n_total(self, n_total):
+        check(self._L.sgdnet_solver_set_n_total(self._h, n_total))
+
     def stream_handle(self):
         """The solver's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
         return int(self._L.sgdnet_solver_stream(self._h) or 0)
 
-    def export_delta_async(self, device_ptr):
-        check(self._L.sgdnet_solver_export_delta_async(self._h, C.c_void_p(device_ptr)))
+    def export_delta_async(self, device_ptr, weight=1.0):
+        check(self._L.sgdnet_solver_export_delta_weighted_async(self._h, C.c_void_p(device_ptr), weight))
 
     def apply_merged_async(self, device_ptr, w_weight):
         check(self._L.sgdnet_solver_apply_merged_async(self._h, C.c_void_p(device_ptr), w_weight))

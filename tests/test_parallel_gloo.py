@@ -1,11 +1,13 @@
-"""World-size-2 test of the sample-sharded SAGA driver on CPU (gloo).
+"""World-size-2 tests of the sample-sharded SAGA drivers on CPU (gloo).
 
-The product's merge logic (sgdnet_amd/parallel.py: snapshot -> local epoch -> one
-all-reduce of the packed deltas -> apply) runs unchanged; the per-rank local solver is
-an oracle-backed stand-in with the same four methods as the HIP shard, which is the only
-place tests may use the oracle.  Checks: (1) the two-process result equals an in-process
-emulation of the same algorithm bit for bit up to summation order, (2) the merged
-iteration converges to the single-process optimum (the fixed point is preserved).
+The product's merge logic (sgdnet_amd/parallel.py) runs unchanged; the per-rank local solver is
+an oracle-backed stand-in with the same methods as the HIP shard, which is the only place tests
+may use the oracle.
+
+ShardedSaga (periodic averaging of locally normalised shard runs): (1) the two-process result
+equals an in-process emulation of the same algorithm up to summation order, (2) on a WEAKLY
+regularised problem -- the regime where summing globally normalised deltas once per epoch does
+not converge -- it reaches the single-process optimum in about as many epochs as one process.
 """
 import os
 import socket
@@ -17,7 +19,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 N, P, DENS, SEED = 6000, 80, 0.06, 17
-GAMMA, A_L2, B_L1, BATCH = 0.08, 2e-3, 1e-3, 32
+GAMMA, A_L2, B_L1, BATCH = 0.08, 2e-5, 1e-5, 32
+PERIOD = N // 32                                       # draws per rank between merges
+KW = dict(family="binomial", penalty="elasticnet", gamma=GAMMA, alpha=A_L2, beta=B_L1)
 
 
 class OracleShard:
@@ -30,8 +34,10 @@ class OracleShard:
         lo, hi = shard_bounds(N, world, rank)
         pr = D.make_sparse_glm(N, P, DENS, family="binomial", seed=SEED, lo=lo, hi=hi)
         self.X, self.y, self.n = D.as_scipy(pr), pr["y"], hi - lo
+        self.weight = self.n / N
         self.st = po.new_state(1, P, self.n)
         self.rng = po.Rng(SEED + rank)
+        self.D, self.d0 = np.zeros((1, P), order="F"), np.zeros(1)
         self.ref = None
 
     def _pack(self):
@@ -42,22 +48,30 @@ class OracleShard:
     def snapshot(self):
         self.ref = self._pack()
 
-    def local_epoch(self):
-        stream = self.rng.stream(self.n, self.n)
-        self.po.saga(self.X, self.y, self.st, family="binomial", penalty="elasticnet", gamma=GAMMA,
-                     alpha=A_L2, beta=B_L1, max_iter=1, tol=0.0, stream=stream, batch=BATCH,
-                     n_total=N)
+    def local_run(self, draws):
+        # batched SAGA on the shard with local normalisation (n_total = n_local)
+        stream = self.rng.stream(self.n, draws)
+        for t0 in range(0, draws, BATCH):
+            seg = stream[t0:t0 + BATCH]
+            self.po.batch_gather(self.X, self.y, self.st, seg, self.D, self.d0, n_total=self.n, **KW)
+            self.po.batch_sweep((P, self.n), self.st, seg.size, self.D, self.d0, n_total=self.n, **KW)
 
     def export_delta(self):
-        return self.torch.from_numpy(self._pack() - self.ref)
+        return self.torch.from_numpy(self.weight * (self._pack() - self.ref))
 
-    def apply_merged(self, buf, w_weight):
-        m = buf.numpy()
-        s, KP = self.st, P
-        s["g_sum"][:] = (self.ref[:KP] + m[:KP]).reshape(1, P)
-        s["w"][:] = (self.ref[KP:2 * KP] + w_weight * m[KP:2 * KP]).reshape(1, P)
-        s["g_sum_intercept"][:] = self.ref[2 * KP:2 * KP + 1] + m[2 * KP:2 * KP + 1]
-        s["intercept"][:] = self.ref[2 * KP + 1:] + w_weight * m[2 * KP + 1:]
+    def apply_merged(self, buf):
+        v = self.ref + buf.numpy()
+        self.ref = v                          # the merged state is the next local run's snapshot
+        s = self.st
+        s["g_sum"][:] = v[:P].reshape(1, P)
+        s["w"][:] = v[P:2 * P].reshape(1, P)
+        s["g_sum_intercept"][:] = v[2 * P:2 * P + 1]
+        s["intercept"][:] = v[2 * P + 1:]
+
+
+def _segments(n_local):
+    from sgdnet_amd.parallel import merge_segments
+    return merge_segments(n_local, N, BATCH, period=PERIOD)
 
 
 def _worker(rank, world, port, epochs, outdir):
@@ -67,7 +81,7 @@ def _worker(rank, world, port, epochs, outdir):
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
                             world_size=world)
     shard = OracleShard(rank, world)
-    job = ShardedSaga(shard, world)
+    job = ShardedSaga(shard, world, _segments(shard.n))
     for _ in range(epochs):
         job.epoch()
     np.save(os.path.join(outdir, f"w{rank}.npy"), np.r_[shard.st["w"].ravel(), shard.st["intercept"]])
@@ -82,38 +96,63 @@ def _free_port():
     return port
 
 
-def _emulate(world, epochs):
+def _emulate(world, epochs, tol=None):
     shards = [OracleShard(r, world) for r in range(world)]
-    for _ in range(epochs):
+    segs = _segments(shards[0].n)
+    assert all(_segments(s.n) == segs for s in shards)
+    prev, used = None, epochs
+    for e in range(epochs):
         for s in shards:
             s.snapshot()
-            s.local_epoch()
-        total = sum(s.export_delta() for s in shards)
-        for s in shards:
-            s.apply_merged(total.clone(), 1.0 / world)
-    return np.r_[shards[0].st["w"].ravel(), shards[0].st["intercept"]]
+        for seg in segs:
+            for s in shards:
+                s.local_run(seg)
+            total = sum(s.export_delta() for s in shards)
+            for s in shards:
+                s.apply_merged(total.clone())
+        w = shards[0].st["w"].ravel().copy()
+        if tol is not None and prev is not None and np.abs(w - prev).max() <= tol * np.abs(w).max():
+            used = e + 1
+            break
+        prev = w
+    return np.r_[shards[0].st["w"].ravel(), shards[0].st["intercept"]], used
+
+
+def test_merge_segments_cover_the_epoch():
+    from sgdnet_amd.parallel import merge_segments
+    for n_local, n_total, batch in [(1_250_000, 10_000_000, 131072), (5_000_000, 10_000_000, 131072),
+                                    (3000, 6000, 32), (10, 80, 64), (7, 7, 1)]:
+        segs = merge_segments(n_local, n_total, batch)
+        assert sum(segs) == n_local and all(s > 0 for s in segs)
+        assert len(set(segs[:-1])) <= 1 and segs[-1] <= segs[0]
+        b = min(batch, n_local)
+        assert segs[0] % b == 0 or len(segs) == 1
+    assert merge_segments(1_250_000, 10_000_000, 131072) == [262144, 262144, 262144, 262144, 201424]
 
 
 @pytest.mark.timeout(600)
 def test_two_rank_gloo_matches_emulation_and_converges(tmp_path):
     import torch.multiprocessing as mp
-    epochs = 150
+    epochs = 12
     mp.spawn(_worker, args=(2, _free_port(), epochs, str(tmp_path)), nprocs=2, join=True)
     w0 = np.load(tmp_path / "w0.npy")
     w1 = np.load(tmp_path / "w1.npy")
     assert np.array_equal(w0, w1), "ranks must hold identical merged state"
-    emu = _emulate(2, epochs)
+    emu, _ = _emulate(2, epochs)
     np.testing.assert_allclose(w0, emu, rtol=0, atol=1e-13)
 
-    # the single-process optimum of the same problem (exact reference iteration)
+    # weakly regularised: the single-process optimum (exact reference iteration) is reached by the
+    # 2- and 4-rank jobs in about as many epochs as one process needs
     from oracle import pyoracle as po
     from sgdnet_amd import data as D
     pr = D.make_sparse_glm(N, P, DENS, family="binomial", seed=SEED)
     st = po.new_state(1, P, N)
-    po.saga(D.as_scipy(pr), pr["y"], st, family="binomial", penalty="elasticnet", gamma=GAMMA,
-            alpha=A_L2, beta=B_L1, max_iter=400, tol=1e-12, rng=po.Rng(3))
+    ep1, _, _ = po.saga(D.as_scipy(pr), pr["y"], st, max_iter=2000, tol=1e-11, rng=po.Rng(3), **KW)
     opt = np.r_[st["w"].ravel(), st["intercept"]]
-    assert np.abs(w0 - opt).max() / np.abs(opt).max() < 1e-8
+    for world in (2, 4):
+        got, used = _emulate(world, 2000, tol=1e-11)
+        assert np.abs(got - opt).max() / np.abs(opt).max() < 1e-8
+        assert used <= 1.5 * ep1 + 5, (world, used, ep1)
 
 
 # ---------------------------------------------------------------------------------------------
