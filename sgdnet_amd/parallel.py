@@ -16,9 +16,10 @@ contiguous shard of the samples and their gradient-memory rows; the model state
   local runs are short: measured (scripts/merge_rule_experiment3.py and the HIP kernels,
   DESIGN.md 8) with period = n_total / 32 draws per rank the epochs-to-tolerance are those of
   one process for 2-16 ranks and lambda from 0.1/n to 10/n; n_total / 16 costs up to 1.6x the
-  epochs on one of the two benchmark shapes, n_total / 2 does not converge.  The first version of this file summed dG with weight 1 over
-  globally normalised local runs and averaged w once per epoch: that one does not converge at
-  lambda = 1/n (every rank then sees its own shard's curvature diluted by 1 / world).
+  epochs on one of the two benchmark shapes, n_total / 2 does not converge.  The first version
+  of this file summed dG with weight 1 over globally normalised local runs and averaged w once
+  per epoch: that one does not converge at lambda = 1/n (every rank then sees its own shard's
+  curvature diluted by 1 / world).
 * SyncShardedSaga -- every GLOBAL batch of B draws is split across the ranks, one all-reduce per
   batch sums the scatter accumulator, every rank applies the same sweep: the iterates are
   exactly those of the single-GPU batched mode over the interleaved sample order; one
