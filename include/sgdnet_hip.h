@@ -264,6 +264,16 @@ int sgdnet_solver_sync_gather(sgdnet_solver* s, int64_t t0_local, int64_t m_loca
 int sgdnet_solver_sync_sweep(sgdnet_solver* s, int64_t m_global, int64_t m_local, int round);
 int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds);
 
+/* Virtual shards (batched mode, sparse x, one class, no centring): the samples are
+ * split into n_shards contiguous ranges (sizes as shard_bounds of sgdnet_amd/parallel.py), every
+ * range runs the batched iteration on its own replica of (w, g_sum, intercept) with local
+ * normalisation, one launch carries the same batch of all shards, and the replicas are averaged
+ * on the device every n / 32 draws per shard.  An epoch of `draws` consumes draws / n_shards
+ * stream entries per shard, laid out shard after shard: entry t of shard v of the epoch at
+ * stream offset o is stream[o + v * (draws / n_shards) + t] and must be a sample of shard v.
+ * sgdnet_solver_generate_stream produces that layout.  0 or 1 switches it off. */
+int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards);
+
 /* The n that g_sum increments are divided by (default: n_total of the problem description).
  * A sample-sharded job sets it to the shard size (local normalisation) or to the
  * job's sample count (synchronous mode). */

@@ -34,6 +34,18 @@ struct SagaDev {
   int64_t p;     // features
   double n_total;  // samples of the whole job (the 1/n of the gradient average)
   float avg_nnz;   // mean non-zeros per sample (sparse)
+  // virtual shards (K == 1 LDS gather, DESIGN.md 8 "one GPU"): V locally normalised replicas of
+  // (w, g_sum, b, g_sum_b) over V contiguous sample ranges, averaged periodically on the device
+  int V;                 // 0 / 1: off
+  int v_bps;             // gather workgroups per shard
+  int64_t v_dps;         // draws per shard and epoch = stride between the shards' stream regions
+  double v_size[8];      // samples per shard (g_sum normalisation, merge weights = size / n)
+  double* vw;            // V x K*p
+  double* vG;            // V x K*p
+  double* vb;            // V
+  double* vgb;           // V
+  double* vd0;           // one intercept partial per gather workgroup
+  double* vref;          // snapshot [g_sum | w | g_sum_b | b] the replicas started from
   unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
   int force_global;  // synchronous sharded mode: always the global-atomic gather (D must be one array)
   int ablate;      // SGDNET_ABLATE bit mask: timing-only builds of the gather (results are wrong)
@@ -116,6 +128,14 @@ int launch_cw_init(const SagaDev& d, const LamParams* lam, hipStream_t st);
 int batch_gather_blocks(const SagaDev& d, int m);
 int64_t batch_gather_slab_doubles(const SagaDev& d, int m);
 int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
+// virtual shards: one launch covers the same batch of all V shards
+int launch_vs_broadcast(const SagaDev& d, hipStream_t st);
+int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, hipStream_t st,
+                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0 = nullptr,
+                    hipEvent_t ev1 = nullptr);
+int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st);
+bool vs_eligible(const SagaDev& d, int m);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
 int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st);

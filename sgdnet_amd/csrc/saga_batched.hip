@@ -494,7 +494,10 @@ constexpr int kLdsBlock = SGDNET_LDS_BLOCK;
 // kWLds (K == 1, 2*p doubles fit the CU's LDS): the coefficient snapshot is staged next to the
 // accumulator, so the x.w gather -- 64 distinct addresses per wave instruction, which the
 // vector-memory address unit serves at about one lane per clock -- becomes ds_read_b64.
-template <int KMAX, bool kWLds = false>
+// kVS (K == 1, kWLds): virtual shards -- the launch covers the same batch of d.V sample shards;
+// workgroup b works for shard b / d.v_bps on that shard's replica of (w, b), its region of the
+// sample stream and its own intercept partial.
+template <int KMAX, bool kWLds = false, bool kVS = false>
 __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDev d, const LamParams* lamp,
                                                                           int64_t t0_in_epoch, int m,
                                                                           int batch_id_offset,
@@ -502,6 +505,9 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   const int K = KMAX == 1 ? 1 : d.K;
   const int64_t KP = (int64_t)K * d.p;
+  const int vsh = kVS ? (int)blockIdx.x / d.v_bps : 0;          // this workgroup's shard
+  const int vblk = kVS ? (int)blockIdx.x - vsh * d.v_bps : (int)blockIdx.x;
+  const double* w_src = kVS ? d.vw + (int64_t)vsh * KP : d.w;
   PHASE(0);
   // the tables are moved as 16-byte pairs (half the instructions of a double-wise loop: the
   // kernel is bound by the instructions it issues as much as by memory); an odd last element
@@ -518,7 +524,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     // every load in turn)
     constexpr int kStage = 4;
     double* Wl = Dl + KP + (KP & 1);            // 16-byte aligned
-    const pair_t* w2 = reinterpret_cast<const pair_t*>(d.w);
+    const pair_t* w2 = reinterpret_cast<const pair_t*>(w_src);
     pair_t* W2 = reinterpret_cast<pair_t*>(Wl);
     for (int64_t i0 = threadIdx.x; i0 < KP2; i0 += (int64_t)kLdsBlock * kStage) {
       pair_t t[kStage];
@@ -533,23 +539,23 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
         if (i < KP2) W2[i] = t[r];
       }
     }
-    if ((KP & 1) && threadIdx.x == 0) Wl[KP - 1] = d.w[KP - 1];
+    if ((KP & 1) && threadIdx.x == 0) Wl[KP - 1] = w_src[KP - 1];
   }
   __syncthreads();
   PHASE(1);
 
   const int gl = threadIdx.x & (kGroup - 1);
   const int group = threadIdx.x / kGroup;
-  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch + (kVS ? (int64_t)vsh * d.v_dps : 0);
   const int batch_id = lamp->batch_seq + batch_id_offset;
-  const int lo = blockIdx.x * draws_per_block;
+  const int lo = vblk * draws_per_block;
   const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
 
   double gct[KMAX], bk[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     gct[k] = 0.0;
-    bk[k] = k < K ? d.b[k] - (d.standardize ? cw_sum(d, batch_id, k) : 0.0) : 0.0;
+    bk[k] = k < K ? (kVS ? d.vb[vsh] : d.b[k]) - (d.standardize ? cw_sum(d, batch_id, k) : 0.0) : 0.0;
   }
   if (d.standardize) cw_clear_next(d, batch_id);
   constexpr int kGroups = kLdsBlock / kGroup;
@@ -612,7 +618,19 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     }
   }
   PHASE(4);
-  if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kLdsBlock>(d, K, batch_id, gct);
+  if (kVS) {                                    // one partial per workgroup, summed per shard by the sweep
+    __shared__ double vpart[kLdsBlock / 64];
+    const double t = wave_sum(gct[0]);
+    if ((threadIdx.x & 63) == 0) vpart[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int wv = 0; wv < kLdsBlock / 64; ++wv) tot += vpart[wv];
+      d.vd0[blockIdx.x] = tot;
+    }
+  } else if (d.fit_intercept || d.standardize) {
+    store_d0_partial<KMAX, kLdsBlock>(d, K, batch_id, gct);
+  }
   PHASE(5);
 }
 
@@ -1132,6 +1150,122 @@ __global__ __launch_bounds__(kBlock) void saga_cw_init_kernel(SagaDev d, const L
 }
 
 // Advances the epoch bookkeeping that graph replays read.
+// --------------------------------------------------------------------------
+// Virtual shards (K == 1): sweep of all V replicas in one launch.  Block b serves shard
+// b / nfb and the 32 features (b % nfb) * 32 ...; it sums that shard's v_bps slabs in a fixed
+// order, updates the shard's replica of (w, g_sum) with the shard's own normalisation, and the
+// first block of every shard updates the shard's intercept pair.
+// --------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamParams* lamp, int tail, int nfb) {
+  __shared__ double part[kSlabGroups][kSlabElems];
+  __shared__ double red[kBlock / 64];
+  __shared__ double d0_s;
+  const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
+  const int v = (int)blockIdx.x / nfb, fb = (int)blockIdx.x - v * nfb;
+  const int64_t KP = d.p;
+  const double n_d = d.v_size[v];
+  const int e = threadIdx.x % kSlabElems, g = threadIdx.x / kSlabElems;
+  const int64_t j = (int64_t)fb * kSlabElems + e;
+  double acc = 0.0;
+  if (j < KP) {
+    const double* sp = d.slab + (int64_t)v * d.v_bps * KP + j;
+    int bidx = g;
+    for (; bidx + 3 * kSlabGroups < d.v_bps; bidx += 4 * kSlabGroups) {   // 4 loads in flight
+      const double a0 = sp[(int64_t)bidx * KP], a1 = sp[(int64_t)(bidx + kSlabGroups) * KP];
+      const double a2 = sp[(int64_t)(bidx + 2 * kSlabGroups) * KP];
+      const double a3 = sp[(int64_t)(bidx + 3 * kSlabGroups) * KP];
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; bidx < d.v_bps; bidx += kSlabGroups) acc += sp[(int64_t)bidx * KP];
+  }
+  part[g][e] = acc;
+  if (fb == 0) {                                 // the shard's intercept accumulator
+    double a = 0.0;
+    for (int i = threadIdx.x; i < d.v_bps; i += kBlock) a += d.vd0[v * d.v_bps + i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  }
+  __syncthreads();
+  if (fb == 0 && threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int wv = 0; wv < kBlock / 64; ++wv) tot += red[wv];
+    d0_s = tot;
+  }
+  if ((int)threadIdx.x < kSlabElems) {
+    const int64_t jj = (int64_t)fb * kSlabElems + threadIdx.x;
+    if (jj < KP) {
+      double dj = 0.0;
+      for (int gg = 0; gg < kSlabGroups; ++gg) dj += part[gg][threadIdx.x];
+      double* wj = d.vw + (int64_t)v * KP + jj;
+      double* gj = d.vG + (int64_t)v * KP + jj;
+      const double gls = q.gamma * q.ls_m;
+      double val = q.r_m * *wj - gls * *gj - q.gamma * dj;
+      if (q.penalty == SGDNET_ELASTICNET) val = soft_threshold(val, q.beta * q.gamma * q.ls_m);
+      *wj = val;
+      if (dj != 0.0) *gj += dj / n_d;
+    }
+  }
+  __syncthreads();
+  if (fb == 0 && threadIdx.x == 0 && d.fit_intercept) {   // saga-sparse.h:300-304, batched form
+    const double dk = d0_s / n_d;
+    const double gbk = d.vgb[v] + dk;
+    d.vgb[v] = gbk;
+    d.vb[v] -= q.gamma * (gbk * 0.01 * q.m_d + dk);
+  }
+}
+
+// every replica (and the snapshot) <- the solver's current (w, g_sum, b, g_sum_b)
+__global__ __launch_bounds__(kBlock) void saga_vs_broadcast_kernel(SagaDev d) {
+  const int64_t KP = d.p, len = 2 * KP + 2;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+    double val;
+    if (i < KP) val = d.G[i];
+    else if (i < 2 * KP) val = d.w[i - KP];
+    else if (i == 2 * KP) val = d.gb[0];
+    else val = d.b[0];
+    d.vref[i] = val;
+    for (int v = 0; v < d.V; ++v) {
+      if (i < KP) d.vG[(int64_t)v * KP + i] = val;
+      else if (i < 2 * KP) d.vw[(int64_t)v * KP + i - KP] = val;
+      else if (i == 2 * KP) d.vgb[v] = val;
+      else d.vb[v] = val;
+    }
+  }
+}
+
+// periodic average: every replica (and the snapshot) <- snapshot + sum_v (size_v / n) (replica_v - snapshot);
+// final_merge also stores the result as the solver's state
+__global__ __launch_bounds__(kBlock) void saga_vs_merge_kernel(SagaDev d, int final_merge) {
+  const int64_t KP = d.p, len = 2 * KP + 2;
+  double tot_size = 0.0;
+  for (int v = 0; v < d.V; ++v) tot_size += d.v_size[v];
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
+    const double ref = d.vref[i];
+    double val = ref;
+    for (int v = 0; v < d.V; ++v) {
+      double cur;
+      if (i < KP) cur = d.vG[(int64_t)v * KP + i];
+      else if (i < 2 * KP) cur = d.vw[(int64_t)v * KP + i - KP];
+      else if (i == 2 * KP) cur = d.vgb[v];
+      else cur = d.vb[v];
+      val += (d.v_size[v] / tot_size) * (cur - ref);
+    }
+    d.vref[i] = val;
+    for (int v = 0; v < d.V; ++v) {
+      if (i < KP) d.vG[(int64_t)v * KP + i] = val;
+      else if (i < 2 * KP) d.vw[(int64_t)v * KP + i - KP] = val;
+      else if (i == 2 * KP) d.vgb[v] = val;
+      else d.vb[v] = val;
+    }
+    if (final_merge) {
+      if (i < KP) d.G[i] = val;
+      else if (i < 2 * KP) d.w[i - KP] = val;
+      else if (i == 2 * KP) d.gb[0] = val;
+      else d.b[0] = val;
+    }
+  }
+}
+
 __global__ void saga_epoch_end_kernel(LamParams* lamp, int batches) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     lamp->stream_base += lamp->draws_per_epoch;
@@ -1411,6 +1545,73 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
     hipExtLaunchKernelGGL(saga_batch_sweep_kernel<false>, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
                           ev1, 0, d, lam, tail, n_parts, batch_id_offset, ov);
   }
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+// Virtual shards need the K == 1 LDS gather with w staged in LDS and a grid that splits evenly.
+bool vs_eligible(const SagaDev& d, int m) {
+  (void)m;
+  if (d.V < 2 || d.K != 1 || d.standardize || d.force_global || d.xd || !d.vw) return false;
+  const size_t table = sizeof(double) * (size_t)d.p;
+  return 2 * table + 16 + kLdsStaticReserve <= kLdsPerCu;     // accumulator + coefficient snapshot in LDS
+}
+
+static int vs_grid(const SagaDev& d) {
+  static const int target_grid = [] {
+    const char* e = getenv("SGDNET_LDS_GRID");
+    return e ? atoi(e) : 256;
+  }();
+  return (target_grid / d.V) * d.V;
+}
+
+int launch_vs_broadcast(const SagaDev& d, hipStream_t st) {
+  int grid = (int)((2 * d.p + 2 + kBlock - 1) / kBlock);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(saga_vs_broadcast_kernel, dim3(grid), dim3(kBlock), 0, st, d);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st) {
+  int grid = (int)((2 * d.p + 2 + kBlock - 1) / kBlock);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(saga_vs_merge_kernel, dim3(grid), dim3(kBlock), 0, st, d, final_merge);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, hipStream_t st, hipEvent_t ev0,
+                     hipEvent_t ev1) {
+  const int grid = vs_grid(d);
+  if (grid / d.V != d.v_bps || grid > kD0Slots) {
+    set_error("internal: virtual-shard geometry (%d workgroups, %d per shard)", grid, d.v_bps);
+    return SGDNET_EINVAL;
+  }
+  int dpb = (m + d.v_bps - 1) / d.v_bps;
+  const int per_round = kLdsBlock / kGroup;
+  if (dpb < per_round) dpb = per_round;
+  const size_t lds = 2 * sizeof(double) * (size_t)d.p + 16;
+  static bool attr_done_dev[64] = {};
+  int cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  if (!attr_done_dev[cur_dev & 63]) {
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kLdsPerCu - kLdsStaticReserve));
+    attr_done_dev[cur_dev & 63] = true;
+  }
+  hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<1, true, true>), dim3(grid), dim3(kLdsBlock), lds, st, ev0,
+                        ev1, 0, d, lam, t0_in_epoch, m, 0, dpb);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0,
+                    hipEvent_t ev1) {
+  (void)m;
+  const int nfb = (int)((d.p + kSlabElems - 1) / kSlabElems);
+  hipExtLaunchKernelGGL(saga_vs_sweep_kernel, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

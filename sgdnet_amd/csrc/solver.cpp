@@ -86,6 +86,7 @@ struct sgdnet_solver {
   double last_change = 0.0, last_size = 0.0;
   int64_t slab_cap = 0;         // doubles the slab buffer can hold
   double* own_D = nullptr;      // the solver's own D / d0 slots while a sync buffer is bound
+  std::vector<void*> vs_owned;  // virtual-shard replicas
   double* own_d0 = nullptr;
 };
 
@@ -150,6 +151,28 @@ void drop_graph(sgdnet_solver* s) {
 
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
+  if (s->d.V > 1 && vs_eligible(s->d, (int)batch)) {
+    // per-shard batches; the scratch is sized for the launch that carries V of them
+    const int64_t dps = draws / s->d.V;
+    if (batch > dps) batch = dps;
+    s->d.v_dps = dps;
+    const int64_t slab_need = (int64_t)s->d.v_bps * s->d.V * s->d.K * s->d.p;
+    if (slab_need > s->slab_cap) {
+      SGD_HIP_TRY(hipStreamSynchronize(s->st));
+      if (s->d.slab) SGD_HIP_TRY(hipFree(s->d.slab));
+      s->d.slab = nullptr;
+      SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d.slab), sizeof(double) * (size_t)slab_need));
+      s->slab_cap = slab_need;
+      drop_graph(s);
+    }
+    const int64_t tail = dps - (dps / batch) * batch;
+    s->lam.m_full = batch;
+    s->lam.m_tail = tail;
+    batch_factors(s->lam.alpha, s->lam.gamma, batch, &s->lam.r_full, &s->lam.ls_full);
+    batch_factors(s->lam.alpha, s->lam.gamma, tail, &s->lam.r_tail, &s->lam.ls_tail);
+    s->lam.draws_per_epoch = draws;
+    return SGDNET_OK;
+  }
   if (batch > draws) batch = draws;
   // scratch must cover the full batches AND the tail batch, whose launch geometry (and even
   // its gather form) can differ
@@ -180,9 +203,57 @@ int n_batches(int64_t batch, int64_t draws) {
   return (int)((draws + batch - 1) / batch);
 }
 
+// ---- virtual shards (DESIGN.md 8 "one GPU") ----------------------------------------------------
+// `draws` is the epoch's total; every shard does draws / V of them in batches of `batch`, all
+// shards' k-th batch in one gather + one sweep launch; the replicas are averaged every
+// vs_merge_batches batches and at the end of the epoch.
+bool vs_active(const sgdnet_solver* s, int64_t batch) { return s->d.V > 1 && vs_eligible(s->d, (int)batch); }
+
+int vs_merge_batches(const sgdnet_solver* s, int64_t batch) {
+  const int64_t period = s->d.n / 32;            // draws per shard between merges (parallel.py)
+  const int64_t b = period / batch;
+  return (int)(b < 1 ? 1 : b);
+}
+
+int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std::vector<hipEvent_t>* ev) {
+  const SagaDev& d = s->d;
+  const int64_t dps = draws / d.V;
+  if (batch > dps) batch = dps;
+  const int nb = n_batches(batch, dps);
+  const int every = vs_merge_batches(s, batch);
+  int rc = launch_vs_broadcast(d, s->st);
+  if (rc) return rc;
+  for (int k = 0; k < nb; ++k) {
+    const int64_t t0 = (int64_t)k * batch;
+    const int64_t m = (dps - t0 < batch) ? dps - t0 : batch;
+    const int tail = (m != batch) ? 1 : 0;
+    if (ev) {
+      hipEvent_t e[4];
+      for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
+      rc = launch_vs_gather(d, s->lam_dev, t0, (int)m, s->st, e[0], e[1]);
+      if (rc) return rc;
+      rc = launch_vs_sweep(d, s->lam_dev, tail, (int)m, s->st, e[2], e[3]);
+      if (rc) return rc;
+      for (auto x : e) ev->push_back(x);
+    } else {
+      rc = launch_vs_gather(d, s->lam_dev, t0, (int)m, s->st);
+      if (rc) return rc;
+      rc = launch_vs_sweep(d, s->lam_dev, tail, (int)m, s->st);
+      if (rc) return rc;
+    }
+    const bool last = k + 1 == nb;
+    if (last || (k + 1) % every == 0) {
+      rc = launch_vs_merge(d, last ? 1 : 0, s->st);
+      if (rc) return rc;
+    }
+  }
+  return launch_epoch_end(s->lam_dev, nb, s->st);
+}
+
 // Enqueue the kernels of one batched epoch (eager or under stream capture).
 int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::vector<hipEvent_t>* ev) {
   if (batch < 1) batch = 1;
+  if (vs_active(s, batch)) return enqueue_epoch_kernels_vs(s, batch, draws, ev);
   if (batch > draws) batch = draws;
   const int nb = n_batches(batch, draws);
   for (int k = 0; k < nb; ++k) {
@@ -610,6 +681,7 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
   if (s->d.slab) (void)hipFree(s->d.slab);
+  for (void* q : s->vs_owned) (void)hipFree(q);
   if (s->lam_stage) (void)hipHostFree(s->lam_stage);
   for (hipEvent_t ev : s->lam_ev)
     if (ev) (void)hipEventDestroy(ev);
@@ -1195,6 +1267,55 @@ int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds) {
   if (rc) return rc;
   s->lam.stream_base += s->lam.draws_per_epoch;   // mirrors saga_epoch_end_kernel
   s->lam.batch_seq += rounds;
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
+  if (!s || n_shards < 0 || n_shards > 8) {
+    set_error("sgdnet_solver_set_virtual_shards: 0..8 shards");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  drop_graph(s);
+  for (void* q : s->vs_owned) (void)hipFree(q);
+  s->vs_owned.clear();
+  SagaDev& d = s->d;
+  d.V = 0;
+  d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = nullptr;
+  if (n_shards < 2) return SGDNET_OK;
+  if (!s->sparse || d.K != 1 || d.standardize) {
+    set_error("virtual shards: sparse x, one class, no centring");
+    return SGDNET_EUNSUPPORTED;
+  }
+  const int64_t KP = d.p;
+  auto alloc = [&](double** out, size_t count) -> int {
+    void* q = nullptr;
+    if (hipMalloc(&q, sizeof(double) * count) != hipSuccess) return SGDNET_ENOMEM;
+    (void)hipMemset(q, 0, sizeof(double) * count);
+    s->vs_owned.push_back(q);
+    *out = static_cast<double*>(q);
+    return SGDNET_OK;
+  };
+  int rc = alloc(&d.vw, (size_t)n_shards * KP);
+  if (!rc) rc = alloc(&d.vG, (size_t)n_shards * KP);
+  if (!rc) rc = alloc(&d.vb, 8);
+  if (!rc) rc = alloc(&d.vgb, 8);
+  if (!rc) rc = alloc(&d.vd0, 256);
+  if (!rc) rc = alloc(&d.vref, (size_t)(2 * KP + 2));
+  if (rc) {
+    set_error("virtual shards: out of device memory");
+    return rc;
+  }
+  d.V = n_shards;
+  static const int target_grid = [] {
+    const char* e = getenv("SGDNET_LDS_GRID");
+    return e ? atoi(e) : 256;
+  }();
+  d.v_bps = target_grid / n_shards;
+  // shard v owns the samples [v * base + min(v, rem), ...): sgdnet_amd/parallel.py shard_bounds
+  const int64_t base = d.n / n_shards, rem = d.n % n_shards;
+  for (int v = 0; v < 8; ++v) d.v_size[v] = v < n_shards ? (double)(base + (v < rem ? 1 : 0)) : 0.0;
   return SGDNET_OK;
 }
 

@@ -248,6 +248,24 @@ class SagaSolver:
     def sync_end(self, rounds):
         check(self._L.sgdnet_solver_sync_end(self._h, rounds))
 
+    def set_virtual_shards(self, n_shards):
+        check(self._L.sgdnet_solver_set_virtual_shards(self._h, n_shards))
+        self.n_shards = n_shards
+
+    def sharded_stream(self, rngs, epochs):
+        """Host-side sample order for virtual shards: per epoch, shard after shard, n // V draws
+        of each shard from its own generator (rngs: one RRng per shard)."""
+        from .parallel import shard_bounds
+        V = len(rngs)
+        dps = self.n // V
+        out = np.empty(epochs * V * dps, dtype=np.uint32)
+        for e in range(epochs):
+            for v in range(V):
+                lo, hi = shard_bounds(self.n, V, v)
+                seg = rngs[v].stream(hi - lo, dps).astype(np.int64) + lo
+                out[(e * V + v) * dps:(e * V + v + 1) * dps] = seg
+        return out
+
     def set_n_total(self, n_total):
         check(self._L.sgdnet_solver_set_n_total(self._h, n_total))
 

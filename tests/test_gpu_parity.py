@@ -822,3 +822,64 @@ def test_avg_mode_two_ranks_on_one_gpu_reach_the_single_process_optimum(sa, orac
     # at thresh 1e-11 on this small problem the merged job needs 74 epochs against 43 of one
     # process (at the benchmark shapes and thresh 1e-6: 28-30 against 29-32)
     assert int(out[0]["epochs"]) <= 2 * ep1 + 5, (int(out[0]["epochs"]), ep1)
+
+
+# ---------------------------------------------------------------------------------------------
+# Virtual shards on one GPU (sgdnet_solver_set_virtual_shards): V locally normalised replicas,
+# one launch per batch of all shards, averaged on the device every n / 32 draws per shard
+# ---------------------------------------------------------------------------------------------
+def _oracle_virtual_shards(oracle, x, y, V, batch, stream, epochs, kw):
+    """Restatement with the oracle's batch halves: same shards, same streams, same merge points."""
+    from sgdnet_amd.parallel import shard_bounds
+    p, n = x.shape
+    dps = n // V
+    bounds = [shard_bounds(n, V, v) for v in range(V)]
+    sub = [(x[:, lo:hi], np.asfortranarray(y[:, lo:hi])) for lo, hi in bounds]
+    mem = [np.zeros((1, hi - lo), order="F") for lo, hi in bounds]
+    state = dict(w=np.zeros((1, p), order="F"), g_sum=np.zeros((1, p), order="F"), intercept=np.zeros(1),
+                 g_sum_intercept=np.zeros(1))
+    every = max(1, (n // 32) // batch)
+    wts = [(hi - lo) / n for lo, hi in bounds]
+    for e in range(epochs):
+        reps = [dict(w=state["w"].copy(order="F"), g_sum=state["g_sum"].copy(order="F"),
+                     intercept=state["intercept"].copy(), g_sum_intercept=state["g_sum_intercept"].copy(),
+                     g_memory=mem[v]) for v in range(V)]
+        ref = {k: state[k].copy(order="F") for k in state}
+        nb = -(-dps // batch)
+        for k in range(nb):
+            for v in range(V):
+                lo, hi = bounds[v]
+                seg = stream[(e * V + v) * dps + k * batch:(e * V + v) * dps + min(dps, (k + 1) * batch)]
+                local = (seg.astype(np.int64) - lo).astype(np.uint32)
+                Dm, d0 = np.zeros((1, p), order="F"), np.zeros(1)
+                oracle.batch_gather(sub[v][0], sub[v][1], reps[v], local, Dm, d0, n_total=hi - lo, **kw)
+                oracle.batch_sweep((p, hi - lo), reps[v], local.size, Dm, d0, n_total=hi - lo, **kw)
+            if k + 1 == nb or (k + 1) % every == 0:
+                for key in ref:
+                    ref[key] = ref[key] + sum(wts[v] * (reps[v][key] - ref[key]) for v in range(V))
+                    for v in range(V):
+                        reps[v][key][...] = ref[key]
+        state = ref
+    state["g_memory"] = np.concatenate(mem, axis=1)
+    return state
+
+
+@pytest.mark.parametrize("V,n,p,batch,family", [(2, 4000, 60, 64, "binomial"), (4, 6002, 90, 100, "gaussian"),
+                                                (4, 40000, 64, 2500, "binomial")])
+def test_virtual_shards_match_their_oracle_restatement(sa, oracle, V, n, p, batch, family):
+    x, y = make_problem(family, 1, n, p, 0.1, seed=29)
+    kw = dict(family=family, penalty="elasticnet", gamma=0.005, alpha=1e-4, beta=1e-4)
+    epochs = 3
+    S = sa.SagaSolver(x, y, family=family, n_classes=1)
+    S.set_penalty("elasticnet", kw["gamma"], kw["alpha"], kw["beta"])
+    S.set_virtual_shards(V)
+    stream = S.sharded_stream([sa.RRng(60 + v) for v in range(V)], epochs)
+    S.upload_stream(stream)
+    draws = V * (n // V)
+    ep, _ = S.run(mode="batched", batch=batch, draws_per_epoch=draws, max_epochs=epochs, tol=0.0)
+    assert ep == epochs
+    st = _oracle_virtual_shards(oracle, x, y, V, batch, stream, epochs, kw)
+    for k in STATE:
+        assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
+    S.set_virtual_shards(0)
+    S.close()
