@@ -449,6 +449,20 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   rc = sgdnet_solver_set_state(S, 1, b0.data());
   if (rc) return rc;
 
+  // Virtual shards (include/sgdnet_hip.h): with enough samples per feature the batched fit of
+  // one response runs as up to 8 locally normalised replicas over sample ranges, averaged on the
+  // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
+  // at the benchmark shapes.  SGDNET_VSHARDS=0 switches it off, =V forces V.
+  if (mode == SGDNET_MODE_BATCHED && X.sparse && K == 1 && !(ctl->standardize && X.sparse)) {
+    int V = 1;
+    while (V < 8 && (int64_t)(2 * V) * 100 * p <= n) V *= 2;
+    if (const char* e = getenv("SGDNET_VSHARDS")) V = atoi(e);
+    if (V >= 2 && V <= 8) {
+      rc = sgdnet_solver_set_virtual_shards(S, V);
+      if (rc && rc != SGDNET_EUNSUPPORTED) return rc;
+    }
+  }
+
   DrawSource draws(ctl);
   // built-in generator: the draws are produced in HBM (r_rng_device.hip), one epoch ahead of
   // the epoch that consumes them, on a side stream (solver.cpp: solver_rng_*)

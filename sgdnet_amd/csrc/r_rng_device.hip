@@ -98,20 +98,47 @@ __global__ __launch_bounds__(kRngBlock) void r_mt_state_kernel(const uint32_t* s
   if (t == 0) st_out[0] = mti;
 }
 
-__global__ __launch_bounds__(256) void r_mt_convert_kernel(uint32_t* out, int64_t count, uint32_t n_samples) {
+// shards.V > 1 (virtual shards, common.hpp): the epoch's positions are split into V regions of
+// dps draws and region v draws from shard v's sample range -- lo_v + floor(size_v * u); positions
+// past V * dps (n not a multiple of V) keep the plain floor(n * u) and are not consumed
+struct RngShards {
+  int V;
+  int64_t dps;
+  double lo[8], size[8];
+};
+
+__global__ __launch_bounds__(256) void r_mt_convert_kernel(uint32_t* out, int64_t count, uint32_t n_samples,
+                                                           RngShards sh) {
   const double n = (double)n_samples;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
-    out[i] = word_to_draw(out[i], n);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    if (sh.V > 1 && i < sh.dps * sh.V) {
+      const int v = (int)(i / sh.dps);
+      out[i] = (uint32_t)sh.lo[v] + word_to_draw(out[i], sh.size[v]);
+    } else {
+      out[i] = word_to_draw(out[i], n);
+    }
+  }
 }
 
 // state_in -> state_out (may alias); raw words then draws into out[0, count)
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
-                    int64_t count, hipStream_t st) {
+                    int64_t count, hipStream_t st, int n_shards, const double* shard_size) {
+  RngShards sh{};
+  sh.V = n_shards;
+  if (n_shards > 1) {
+    sh.dps = count / n_shards;
+    double lo = 0.0;
+    for (int v = 0; v < n_shards; ++v) {
+      sh.lo[v] = lo;
+      sh.size[v] = shard_size[v];
+      lo += shard_size[v];
+    }
+  }
   hipLaunchKernelGGL(r_mt_state_kernel, dim3(1), dim3(kRngBlock), 0, st, state_in, state_out, out, count);
   int grid = (int)((count + 256 * 8 - 1) / (256 * 8));
   if (grid < 1) grid = 1;
   if (grid > 2048) grid = 2048;
-  hipLaunchKernelGGL(r_mt_convert_kernel, dim3(grid), dim3(256), 0, st, out, count, n_samples);
+  hipLaunchKernelGGL(r_mt_convert_kernel, dim3(grid), dim3(256), 0, st, out, count, n_samples, sh);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

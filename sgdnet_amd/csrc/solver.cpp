@@ -806,7 +806,7 @@ int sgdnet_solver_generate_stream(sgdnet_solver* s, sgdnet_rng* rng, int64_t cou
   if (!s->rng_dev) SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->rng_dev), sizeof(sgdnet_rng)));
   static_assert(sizeof(sgdnet_rng) == 625 * sizeof(uint32_t), "sgdnet_rng is mti + 624 words");
   SGD_HIP_TRY(hipMemcpyAsync(s->rng_dev, rng, sizeof(sgdnet_rng), hipMemcpyHostToDevice, s->st));
-  rc = launch_rng_fill(s->rng_dev, s->rng_dev, (uint32_t)s->d.n, s->stream_dev, count, s->st);
+  rc = launch_rng_fill(s->rng_dev, s->rng_dev, (uint32_t)s->d.n, s->stream_dev, count, s->st, s->d.V, s->d.v_size);
   if (rc) return rc;
   SGD_HIP_TRY(hipMemcpyAsync(rng, s->rng_dev, sizeof(sgdnet_rng), hipMemcpyDeviceToHost, s->st));
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
@@ -849,7 +849,7 @@ int solver_rng_prefetch(sgdnet_solver* s) {
   const int slot = (int)(P.gens & 1);
   SGD_HIP_TRY(hipStreamWaitEvent(P.st, P.freed[slot], 0));
   int rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
-                           s->stream_dev + (int64_t)slot * P.n, P.n, P.st);
+                           s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size);
   if (rc) return rc;
   SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
   ++P.gens;
