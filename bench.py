@@ -56,6 +56,8 @@ def main():
                     help="skip the epochs-to-tolerance leg (outside the timed region)")
     ap.add_argument("--conv-thresh", type=float, default=1e-6)
     ap.add_argument("--conv-max-epochs", type=int, default=400)
+    ap.add_argument("--vshards", type=int, default=-1,
+                    help="virtual shards per GPU (DESIGN.md 8); -1 = the library's rule, 0/1 = off")
     ap.add_argument("--no-alt-merge", action="store_true",
                     help="N > 1: do not also measure the exchange scheme that --merge did not select")
     ap.add_argument("--merge", default="avg", choices=["avg", "sync"],
@@ -142,13 +144,48 @@ def main():
         batch = min(batch, n_local)       # sync mode: `batch` is the GLOBAL staleness window
     note(f"gamma={gamma:.5g} batch={batch}")
     epochs_total = args.warmup + args.steps + 1                 # +1: the event-profiled epoch
-    # sample order: R's Mersenne-Twister, set.seed(config id [+ rank])
-    stream = sa.RRng(seed + rank).stream(n_local, n_local * epochs_total)
-
+    # virtual shards per GPU: the fit driver's rule (driver.cpp) -- up to 8 replicas while every
+    # shard keeps 100 samples per feature; the synchronous mode does not use them
+    V = 1
+    if K == 1 and not sync_mode:
+        while V < 8 and 2 * V * 100 * p <= n_local:
+            V *= 2
+        if args.vshards >= 0:
+            V = max(1, args.vshards)
     S = sa.SagaSolver(X, prob["y"], family=family, n_classes=K, fit_intercept=True, n_total=n,
                       device=local_rank)
     S.set_penalty("elasticnet", gamma, a_l2, b_l1)
     S.set("intercept", b0)
+    # sample order: R's Mersenne-Twister, set.seed(config id [+ rank] [+ 100 shard]).  With virtual
+    # shards every local run (an epoch, or a merge segment when N > 1) is laid out shard after shard
+    # (include/sgdnet_hip.h: sgdnet_solver_set_virtual_shards)
+    merged_job = (world > 1 or force_merge) and not sync_mode
+    # every shard (virtual or not) runs n / 32 draws between merges: a rank with V virtual shards
+    # exchanges after V * n / 32 draws, when its own shards are averaged on the device anyway
+    shard_period = max(1, n // int(os.environ.get("SGDNET_BENCH_PERIOD_DIV", "32")))
+    runs = merge_segments(n_local, n, V * min(batch, n_local // V), period=V * shard_period) \
+        if merged_job else [n_local]
+    if V > 1:
+        from sgdnet_amd.parallel import shard_bounds as sb
+        S.set_virtual_shards(V)
+        S.set_merge_period(shard_period)
+        rngs = [sa.RRng(seed + rank + 100 * v) for v in range(V)]
+
+        def host_stream(epochs):
+            parts = []
+            for _ in range(epochs):
+                for run in runs:
+                    dps = run // V
+                    for v in range(V):
+                        lo_v, hi_v = sb(n_local, V, v)
+                        parts.append((rngs[v].stream(hi_v - lo_v, dps).astype(np.int64) + lo_v).astype(np.uint32))
+                    if run - dps * V:
+                        parts.append(np.zeros(run - dps * V, dtype=np.uint32))  # positions no shard consumes
+            return np.concatenate(parts)
+
+        stream = host_stream(epochs_total)
+    else:
+        stream = sa.RRng(seed + rank).stream(n_local, n_local * epochs_total)
     S.upload_stream(stream)
     # device-ordered merge (no host sync inside an epoch) unless SGDNET_BENCH_FUSED=0
     fused = ((world > 1 or force_merge) and backend == "nccl"
@@ -158,6 +195,7 @@ def main():
     def make_job(mode):
         """mode 'sync' | 'avg' -> (epoch callable, shard, description, sync rounds)."""
         if mode == "sync":
+            S.set_virtual_shards(0)
             S.set_n_total(n)
             sh = HipSyncShard(S, draws_per_epoch=n_local, device=dev, stage_on_host=(backend != "nccl"))
             sj = SyncShardedSaga(sh, n, world, batch, force_reduce=force_merge)
@@ -166,8 +204,8 @@ def main():
             return (lambda: sj.epoch(rank)), sh, desc, sj.rounds
         S.set_n_total(n_local)                    # local normalisation (sgdnet_amd/parallel.py)
         lb = min(batch, n_local)
-        pdiv = int(os.environ.get("SGDNET_BENCH_PERIOD_DIV", "32"))     # merge period = n / pdiv draws per rank
-        segs = merge_segments(n_local, n, lb, period=max(1, n // pdiv)) if (world > 1 or force_merge) else [n_local]
+        segs = runs if merged_job else (
+            merge_segments(n_local, n, lb, period=shard_period) if (world > 1 or force_merge) else [n_local])
         sh = HipShard(S, batch=lb, draws_per_epoch=n_local, device=dev, weight=n_local / n,
                       stage_on_host=(backend != "nccl"), fused=fused)
         sj = ShardedSaga(sh, world, segs, force_merge=force_merge)
@@ -234,7 +272,7 @@ def main():
         "config": {
             "workload": f"{args.workload}: synthetic CSC {n}x{p}, {density:.4%} nnz, family={family}, "
                         f"alpha={mix}, lambda=1/n, intercept, standardize=FALSE",
-            "mode": "batched", "batch": batch, "samples_per_gpu": n_local,
+            "mode": "batched", "batch": batch, "samples_per_gpu": n_local, "virtual_shards": V,
             "sample_order": f"R MT19937 set.seed({seed}+rank), with replacement",
             "merge": merge_desc,
             "gen_s": round(t_gen, 2),
@@ -272,7 +310,10 @@ def main():
         tconv = time.perf_counter()
         done, conv_ep = False, 0
         while not done and conv_ep < max_epochs:
-            S.generate_stream(crng, n_local)       # this epoch's draws, generated on the device
+            if V > 1 and merged_job and S.n_shards == V:
+                S.upload_stream(host_stream(1))    # laid out per merge segment: generated on the host
+            else:
+                S.generate_stream(crng, n_local)   # this epoch's draws, generated on the device
             sh.offset = 0
             epoch_fn()
             S.sync()
@@ -314,8 +355,8 @@ def main():
     # this process); attached only when workload, batch and kernel match that profile
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if (pmc["workload"], pmc["batch"], pmc["n_gpus"], pmc["kernel"]) == \
-                (args.workload, batch, world, prof["gather_kernel"]):
+        if (pmc["workload"], pmc["batch"], pmc["n_gpus"], pmc["kernel"], pmc.get("virtual_shards", 1)) == \
+                (args.workload, batch, world, prof["gather_kernel"], V):
             out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = "profiles/pmc_latest.json"
     except (OSError, KeyError, ValueError):

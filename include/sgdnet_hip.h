@@ -273,6 +273,9 @@ int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds);
  * stream offset o is stream[o + v * (draws / n_shards) + t] and must be a sample of shard v.
  * sgdnet_solver_generate_stream produces that layout.  0 or 1 switches it off. */
 int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards);
+/* draws per shard between two device-side averages (0: n_samples / 32).  A multi-GPU job sets
+ * n_total / 32 of the whole job and merges across GPUs at the same cadence. */
+int sgdnet_solver_set_merge_period(sgdnet_solver* s, int64_t draws_per_shard);
 
 /* The n that g_sum increments are divided by (default: n_total of the problem description).
  * A sample-sharded job sets it to the shard size (local normalisation) or to the

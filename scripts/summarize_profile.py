@@ -25,6 +25,7 @@ f, w = pick(out["FETCH_SIZE"]), pick(out["WRITE_SIZE"])
 # this kernel's own access pattern: one launch must fetch at least batch x 256-B records
 # (33.6 MB at batch 131072) and the raw counter reads 17.45 MB.  WRITE_SIZE is exact.
 latest = {"workload": bench["config"]["workload"].split(":")[0], "batch": bench["config"]["batch"], "n_gpus": bench["n_gpus"],
+          "virtual_shards": bench["config"].get("virtual_shards", 1),
           "kernel": kern, "fetch_raw_bytes_per_launch": f * 1024, "fetch_bytes_per_launch": 2 * f * 1024,
           "write_bytes_per_launch": w * 1024, "traffic_bytes_per_launch": (2 * f + w) * 1024,
           "note": f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/{tag}_pmc_summary.json); "

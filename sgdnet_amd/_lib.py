@@ -26,7 +26,7 @@ EXPORTS = [
     "sgdnet_solver_apply_merged_async", "sgdnet_solver_sync_buffer_len", "sgdnet_solver_sync_bind",
     "sgdnet_solver_sync_begin", "sgdnet_solver_sync_gather", "sgdnet_solver_sync_sweep",
     "sgdnet_solver_sync_end", "sgdnet_solver_set_n_total",
-    "sgdnet_solver_export_delta_weighted_async", "sgdnet_solver_set_virtual_shards",
+    "sgdnet_solver_export_delta_weighted_async", "sgdnet_solver_set_virtual_shards", "sgdnet_solver_set_merge_period",
 ]
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
@@ -146,6 +146,7 @@ def load():
     L.sgdnet_solver_sync_end.argtypes = [C.c_void_p, C.c_int]
     L.sgdnet_solver_set_n_total.argtypes = [C.c_void_p, C.c_int64]
     L.sgdnet_solver_set_virtual_shards.argtypes = [C.c_void_p, C.c_int]
+    L.sgdnet_solver_set_merge_period.argtypes = [C.c_void_p, C.c_int64]
     L.sgdnet_solver_export_delta_weighted_async.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     L.sgdnet_solver_convergence.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int)]
     L.sgdnet_solver_last_change.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]

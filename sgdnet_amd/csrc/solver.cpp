@@ -87,6 +87,7 @@ struct sgdnet_solver {
   int64_t slab_cap = 0;         // doubles the slab buffer can hold
   double* own_D = nullptr;      // the solver's own D / d0 slots while a sync buffer is bound
   std::vector<void*> vs_owned;  // virtual-shard replicas
+  int64_t vs_period = 0;        // draws per shard between device-side merges (0: n / 32)
   double* own_d0 = nullptr;
 };
 
@@ -210,7 +211,8 @@ int n_batches(int64_t batch, int64_t draws) {
 bool vs_active(const sgdnet_solver* s, int64_t batch) { return s->d.V > 1 && vs_eligible(s->d, (int)batch); }
 
 int vs_merge_batches(const sgdnet_solver* s, int64_t batch) {
-  const int64_t period = s->d.n / 32;            // draws per shard between merges (parallel.py)
+  // draws per shard between merges: n / 32 of the job (parallel.py), settable for sharded jobs
+  const int64_t period = s->vs_period > 0 ? s->vs_period : s->d.n / 32;
   const int64_t b = period / batch;
   return (int)(b < 1 ? 1 : b);
 }
@@ -1316,6 +1318,15 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   // shard v owns the samples [v * base + min(v, rem), ...): sgdnet_amd/parallel.py shard_bounds
   const int64_t base = d.n / n_shards, rem = d.n % n_shards;
   for (int v = 0; v < 8; ++v) d.v_size[v] = v < n_shards ? (double)(base + (v < rem ? 1 : 0)) : 0.0;
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_set_merge_period(sgdnet_solver* s, int64_t draws_per_shard) {
+  if (!s || draws_per_shard < 0) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  s->vs_period = draws_per_shard;
+  drop_graph(s);
   return SGDNET_OK;
 }
 

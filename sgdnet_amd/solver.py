@@ -84,6 +84,7 @@ class SagaSolver:
         self.sparse = sp.issparse(x)
         p, n = x.shape
         self.n, self.p, self.K = n, p, n_classes
+        self.n_shards = 0
         y = np.asfortranarray(np.asarray(y, dtype=np.float64).reshape(-1, n) if np.ndim(y) == 1
                               else np.asarray(y, dtype=np.float64))
         pb = _lib.Problem()
@@ -251,6 +252,9 @@ class SagaSolver:
     def set_virtual_shards(self, n_shards):
         check(self._L.sgdnet_solver_set_virtual_shards(self._h, n_shards))
         self.n_shards = n_shards
+
+    def set_merge_period(self, draws_per_shard):
+        check(self._L.sgdnet_solver_set_merge_period(self._h, draws_per_shard))
 
     def sharded_stream(self, rngs, epochs):
         """Host-side sample order for virtual shards: per epoch, shard after shard, n // V draws
