@@ -351,6 +351,163 @@ __device__ __forceinline__ unsigned long long phase_stamp() {
 #endif
 
 // One pipeline stage set for U draws of a 16-lane group (K == 1).
+// --------------------------------------------------------------------------
+// K == 1, 8-lane form (records with rec_cap >= 16): an 8-lane group owns FOUR draws per pass
+// and every lane holds TWO entries of each (one 8-byte index load, one 16-byte value load), so
+// a wavefront carries 32 draws per pass -- twice the records in flight of the 16-lane form for
+// the same number of load, exp and exchange instructions.  Lane 2q of the group owns draw q:
+// it loads the draw's sample id and the record header (response, nnz, overflow link),
+// evaluates the gradient and issues the gradient-memory exchange.  Entries 16.. of a row
+// (2.7 % of the rows at 10 non-zeros per row) take the tail path below.
+// Unused slots of a record are zero (both packers clear the records), so no per-entry count
+// is needed: a zero value contributes nothing and is skipped by the scatter.
+// --------------------------------------------------------------------------
+constexpr int kLanes8 = 8;
+constexpr int kInReg8 = 16;          // entries of a row held in registers
+
+template <class F>
+__device__ __forceinline__ void row_tail8(const SagaDev& d, const char* base, int nnz, int ovf, int gl, F f) {
+  const int cap = d.rec_cap;
+  const int cnt0 = nnz < cap ? nnz : cap;
+  const int* ridx = reinterpret_cast<const int*>(base + 16);
+  const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
+  for (int e = kInReg8 + gl; e < cnt0; e += kLanes8) f((int64_t)ridx[e], rval[e]);
+  int rem = nnz - cnt0;
+  while (rem > 0) {
+    const char* ob = d.ovf + (size_t)ovf * kOvfStride;
+    const int next = reinterpret_cast<const int*>(ob)[0];
+    const int c = reinterpret_cast<const int*>(ob)[1];
+    const int* oi = reinterpret_cast<const int*>(ob + 8);
+    const double* ov = reinterpret_cast<const double*>(ob + 8 + 4 * kOvfCap);
+    for (int e = gl; e < c; e += kLanes8) f((int64_t)oi[e], ov[e]);
+    rem -= c;
+    ovf = next;
+  }
+}
+
+struct RecHeader {
+  double y;
+  int nnz;
+  int ovf;
+};
+
+// All draws lo + g8 + k * (groups * 4) .. of one group; returns the sum of the gradient changes
+// of the draws this lane owns.
+template <int kThreads>
+__device__ __forceinline__ double k1_lanes8_draws(const SagaDev& d, const uint32_t* sp, int lo, int hi, double b0,
+                                                  const double* wv, double* Dl) {
+  typedef int ipair_t __attribute__((ext_vector_type(2)));
+  typedef double dpair_t __attribute__((ext_vector_type(2)));
+  constexpr int U = 4;
+  constexpr int kG = kThreads / kLanes8;        // groups per workgroup
+  constexpr int kStep = kG * U;                 // draws per workgroup pass
+  const int gl = threadIdx.x & (kLanes8 - 1);
+  const int g8 = threadIdx.x / kLanes8;
+  const int q = gl >> 1;                        // the draw of the pass this lane owns / holds x.w of
+  const bool is_owner = (gl & 1) == 0;
+  const size_t stride = (size_t)d.rec_stride;
+  const int val_off = d.rec_val_off;
+  double gct = 0.0;
+  int i = lo + g8;
+  if (i >= hi) return 0.0;
+  // sample id of this lane's own draw; draws past the end stand in with draw i (discarded)
+  uint32_t s_own = sp[i + q * kG < hi ? i + q * kG : i];
+  for (; i < hi; i += kStep) {
+    const bool v_own = i + q * kG < hi;
+    uint32_t su[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) su[u] = (uint32_t)__shfl((int)s_own, 2 * u, kLanes8);
+    const RecHeader hd = *reinterpret_cast<const RecHeader*>(d.rec + (size_t)s_own * stride);
+    ipair_t jf[U];
+    dpair_t vf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const char* base = d.rec + (size_t)su[u] * stride;
+      jf[u] = *reinterpret_cast<const ipair_t*>(base + 16 + 8 * gl);
+      vf[u] = *reinterpret_cast<const dpair_t*>(base + val_off + 16 * gl);
+    }
+    // ids of the next pass: requested before this pass's records are waited for
+    const uint32_t s_this = s_own;
+    {
+      const int in = i + kStep;
+      if (in < hi) s_own = sp[in + q * kG < hi ? in + q * kG : in];
+    }
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = vf[u].x * wv[jf[u].x] + vf[u].y * wv[jf[u].y];
+    const bool own_tail = v_own && hd.nnz > kInReg8;
+    const bool any_tail = __ballot(own_tail) != 0;        // wave-uniform
+    if (any_tail) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int nz = __shfl(own_tail ? hd.nnz : 0, 2 * u, kLanes8);
+        if (nz > kInReg8) {
+          const int ov = __shfl(hd.ovf, 2 * u, kLanes8);
+          double a = 0.0;
+          row_tail8(d, d.rec + (size_t)su[u] * stride, nz, ov, gl, [&](int64_t j, double v) { a += v * wv[j]; });
+          acc[u] += a;
+        }
+      }
+    }
+    // merged butterfly: xor 4 halves four values to two, xor 2 to one, xor 1 finishes; draw q's
+    // x.w ends up in lanes 2q, 2q+1 of the group
+    const bool hi4 = (gl & 4) != 0, hi2 = (gl & 2) != 0;
+    const double r0 = (hi4 ? acc[2] : acc[0]) + __shfl_xor(hi4 ? acc[0] : acc[2], 4, kLanes8);
+    const double r1 = (hi4 ? acc[3] : acc[1]) + __shfl_xor(hi4 ? acc[1] : acc[3], 4, kLanes8);
+    double t = (hi2 ? r1 : r0) + __shfl_xor(hi2 ? r0 : r1, 2, kLanes8);
+    t += __shfl_xor(t, 1, kLanes8);
+    const double lp = t + b0;
+    const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - hd.y - 1.0 / (1.0 + exp(lp)) : lp - hd.y;
+    double gcp = 0.0;
+    if (is_owner && v_own) {
+      // claim, read and update in ONE returning atomic: a repeated draw of the batch reads back
+      // the value just stored (same snapshot, same g0), so its gc is exactly 0
+      const double old = __hip_atomic_exchange(d.M + s_this, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gcp = g0 - old;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double gc = __shfl(gcp, 2 * u, kLanes8);
+      if (gc != 0.0) {
+        if (vf[u].x != 0.0) scatter_add<true>(Dl + jf[u].x, vf[u].x * gc);
+        if (vf[u].y != 0.0) scatter_add<true>(Dl + jf[u].y, vf[u].y * gc);
+        if (any_tail) {
+          const int nz = __shfl(own_tail ? hd.nnz : 0, 2 * u, kLanes8);
+          if (nz > kInReg8) {
+            const int ov = __shfl(hd.ovf, 2 * u, kLanes8);
+            row_tail8(d, d.rec + (size_t)su[u] * stride, nz, ov, gl,
+                      [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
+          }
+        }
+      }
+    }
+    gct += gcp;
+  }
+  return gct;
+}
+
+template <int U>
+struct K1IdsOnly {
+  uint32_t s[U];
+  bool valid[U];
+  uint32_t s_own;
+  bool v_own;
+  bool valid_any;
+  __device__ __forceinline__ void load(const SagaDev& d, const uint32_t* sp, int i, int hi, int step, int gl,
+                                       int safe) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int iu = i + u * step;
+      valid[u] = iu < hi;
+      s[u] = sp[valid[u] ? iu : safe];
+    }
+    const int q = U == 4 ? gl >> 2 : gl;
+    const int iq = i + q * step;
+    v_own = q < U && iq < hi;
+    s_own = sp[v_own ? iq : safe];
+  }
+};
+
 template <int U>
 struct K1Draws {
   uint32_t s[U];
@@ -372,9 +529,8 @@ struct K1Draws {
 
   // stream indices + record loads (nothing waits here)
   // `safe` < hi: the draw whose (discarded) record stands in for positions past the end
-  __device__ __forceinline__ void load(const SagaDev& d, const uint32_t* sp, int i, int hi, int step, int gl,
-                                       int safe) {
-    const int cap = d.rec_cap;
+  __device__ __forceinline__ void load_ids(const SagaDev& d, const uint32_t* sp, int i, int hi, int step, int gl,
+                                           int safe) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int iu = i + u * step;
@@ -382,14 +538,15 @@ struct K1Draws {
       s[u] = sp[valid[u] ? iu : safe];
       if (d.ablate & 16) s[u] &= 1023u;         // timing only: records from a cache-resident set
     }
-    {
-      const int q = draw_of(gl);
-      const int iq = i + q * step;
-      v_own = q < U && iq < hi;
-      s_own = sp[v_own ? iq : safe];
-      if (d.ablate & 16) s_own &= 1023u;
-      y_own = *reinterpret_cast<const double*>(d.rec + (size_t)s_own * d.rec_stride);
-    }
+    const int q = draw_of(gl);
+    const int iq = i + q * step;
+    v_own = q < U && iq < hi;
+    s_own = sp[v_own ? iq : safe];
+    if (d.ablate & 16) s_own &= 1023u;
+  }
+  __device__ __forceinline__ void load_records(const SagaDev& d, int gl) {
+    const int cap = d.rec_cap;
+    y_own = *reinterpret_cast<const double*>(d.rec + (size_t)s_own * d.rec_stride);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const char* base = d.rec + (size_t)s[u] * d.rec_stride;
@@ -397,6 +554,22 @@ struct K1Draws {
       jf[u] = gl < cap ? reinterpret_cast<const int*>(base + 16)[gl] : 0;
       vf[u] = gl < cap ? reinterpret_cast<const double*>(base + d.rec_val_off)[gl] : 0.0;
     }
+  }
+  __device__ __forceinline__ void load(const SagaDev& d, const uint32_t* sp, int i, int hi, int step, int gl,
+                                       int safe) {
+    load_ids(d, sp, i, hi, step, gl, safe);
+    load_records(d, gl);
+  }
+  // the ids of another pass, taken over without touching this pass's records
+  template <class O>
+  __device__ __forceinline__ void take_ids(const O& o) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s[u] = o.s[u];
+      valid[u] = o.valid[u];
+    }
+    s_own = o.s_own;
+    v_own = o.v_own;
   }
   __device__ __forceinline__ bool in(const SagaDev& d, int u, int gl) const {
     const int cnt0 = nnz[u] < d.rec_cap ? nnz[u] : d.rec_cap;
@@ -497,7 +670,7 @@ constexpr int kLdsBlock = SGDNET_LDS_BLOCK;
 // kVS (K == 1, kWLds): virtual shards -- the launch covers the same batch of d.V sample shards;
 // workgroup b works for shard b / d.v_bps on that shard's replica of (w, b), its region of the
 // sample stream and its own intercept partial.
-template <int KMAX, bool kWLds = false, bool kVS = false>
+template <int KMAX, bool kWLds = false, bool kVS = false, int kLanes = kGroup>
 __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDev d, const LamParams* lamp,
                                                                           int64_t t0_in_epoch, int m,
                                                                           int batch_id_offset,
@@ -572,16 +745,39 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     constexpr int U = SGDNET_PIPE;
     const double* wv = kWLds ? Dl + KP + (KP & 1) : d.w;
     const uint32_t* sp = d.stream + t0;
+    if constexpr (kLanes == kLanes8) {
+      gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
+    } else {
 #ifndef SGDNET_TWO_HALVES
     // one pass of U draws per group (two software-pipelined half-passes of U/2 measured 2 us
     // slower once the gradient was evaluated once per pass: the kernel is bound by the vector
     // instructions it issues as much as by the memory system)
+#ifndef SGDNET_NO_IDS_AHEAD
+    // the sample ids of the NEXT pass are requested before this pass's records are waited for:
+    // a pass is a chain of dependent round trips (ids -> records -> gradient-memory exchange)
+    // and this takes the first one off it
+    if (lo + group < hi) {
+      K1Draws<U> A;
+      A.load_ids(d, sp, lo + group, hi, kGroups, gl, lo + group);
+      for (int i = lo + group; i < hi; i += kGroups * U) {
+        A.load_records(d, gl);
+        K1IdsOnly<U> N;
+        const int in = i + kGroups * U;
+        N.valid_any = in < hi;
+        if (N.valid_any) N.load(d, sp, in, hi, kGroups, gl, in);
+        A.gradient(d, gl, bk[0], wv);
+        gct[0] += A.scatter(d, gl, Dl);
+        if (N.valid_any) A.take_ids(N);
+      }
+    }
+#else
     for (int i = lo + group; i < hi; i += kGroups * U) {
       K1Draws<U> A;
       A.load(d, sp, i, hi, kGroups, gl, i);
       A.gradient(d, gl, bk[0], wv);
       gct[0] += A.scatter(d, gl, Dl);
     }
+#endif
 #else
     for (int i = lo + group; i < hi; i += 2 * kGroups * U) {
       K1Draws<U> A, B;
@@ -593,6 +789,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
       gct[0] += B.scatter(d, gl, Dl);
     }
 #endif
+    }
   } else {
     for (int i = lo + group; i < hi; i += kGroups) {
       double gc[KMAX];
@@ -1424,6 +1621,15 @@ int batch_gather_blocks(const SagaDev& d, int m) { return plan_gather(d, m).grid
 
 // Doubles of slab storage the LDS-privatised gather needs for batches of m draws (0: the
 // global-atomic form is used).
+// the 8-lane K == 1 form reads two entries per lane: records must hold 16 entries
+static bool lanes8_ok(const SagaDev& d) {
+  static const int allow = [] {
+    const char* e = getenv("SGDNET_LANES8");
+    return e ? atoi(e) : 1;
+  }();
+  return allow && d.rec_cap >= kInReg8 && !d.ablate;
+}
+
 int64_t batch_gather_slab_doubles(const SagaDev& d, int m) {
   SagaDev probe = d;
   probe.slab = reinterpret_cast<double*>(1);
@@ -1483,6 +1689,9 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize,
                                       kLdsPerCu - kLdsStaticReserve));
+      SGD_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1, true, false, kLanes8>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<4>),
@@ -1491,7 +1700,11 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
                                       hipFuncAttributeMaxDynamicSharedMemorySize, cap));
       attr_done = true;
     }
-    if (d.K == 1 && g.w_lds)
+    if (d.K == 1 && g.w_lds && lanes8_ok(d))
+      hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<1, true, false, kLanes8>), dim3(g.grid), dim3(kLdsBlock),
+                            g.lds_bytes, st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset,
+                            g.draws_per_block);
+    else if (d.K == 1 && g.w_lds)
       hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<1, true>), dim3(g.grid), dim3(kLdsBlock), g.lds_bytes,
                             st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
     else if (d.K == 1)
@@ -1599,10 +1812,17 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
     SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1, true, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize,
                                     kLdsPerCu - kLdsStaticReserve));
+    SGD_HIP_TRY(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<1, true, true, kLanes8>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
     attr_done_dev[cur_dev & 63] = true;
   }
-  hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<1, true, true>), dim3(grid), dim3(kLdsBlock), lds, st, ev0,
-                        ev1, 0, d, lam, t0_in_epoch, m, 0, dpb);
+  if (lanes8_ok(d))
+    hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<1, true, true, kLanes8>), dim3(grid), dim3(kLdsBlock), lds,
+                          st, ev0, ev1, 0, d, lam, t0_in_epoch, m, 0, dpb);
+  else
+    hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<1, true, true>), dim3(grid), dim3(kLdsBlock), lds, st, ev0,
+                          ev1, 0, d, lam, t0_in_epoch, m, 0, dpb);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }
