@@ -62,6 +62,10 @@ struct SagaDev {
   int rec_stride;
   int rec_cap;        // entries held by the main record
   int rec_val_off;    // byte offset of val[] inside a record
+  // compact two-plane records of the K == 1 LDS gather (saga_batched.hip) or nullptr
+  const char* cP;     // n x 128 B: response + first 12 entries, 16-bit feature ids
+  const char* cQ;     // n x 128 B: entries 12..23 of the rows that have them
+  const uint32_t* clong;  // bitmap of the rows with more than 12 entries
   // solver state (K fastest, like the reference's ArrayXXd K x p / K x n)
   double* w;
   double* G;      // g_sum
@@ -136,6 +140,8 @@ int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream
                     hipEvent_t ev1 = nullptr);
 int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st);
 bool vs_eligible(const SagaDev& d, int m);
+bool compact_eligible(const SagaDev& d);
+int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* longmap, hipStream_t st);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
 int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st);

@@ -486,6 +486,168 @@ __device__ __forceinline__ double k1_lanes8_draws(const SagaDev& d, const uint32
   return gct;
 }
 
+// --------------------------------------------------------------------------
+// Compact records (K == 1, p <= 65536): two planes of n x 128 B.  Plane P holds the response
+// and the first 12 entries of every row with 16-bit feature ids
+//     [ y : 8 | id[12] : 24 | val[12] : 96 ]
+// and plane Q, touched only for rows with more than 12 entries (21 % at 10 non-zeros per row),
+// holds the next 12:
+//     [ nnz : 4 | - : 4 | id[12] : 24 | val[12] : 96 ]
+// Entries 24.. of a row are read from the sample-major CSR arrays.  A draw moves 128 B for four
+// rows out of five instead of 256 B for every row -- 155 B per draw at z = 10, next to the
+// 152 algorithmic bytes.  Whether a row is long must be known BEFORE its record is requested
+// (asking the record would be a second dependent round trip), so a bitmap of the long rows
+// (n bits) is looked up one pass ahead, for sample ids that were requested two passes ahead.
+// Same lane mapping as k1_lanes8_draws: lanes 0..5 of the 8-lane group hold P's twelve entries,
+// lanes 6..7 the first four of Q; entries 16.. take the tail path.
+// --------------------------------------------------------------------------
+constexpr int kCStride = 128;
+constexpr int kCP = 12;               // entries in plane P (and in plane Q)
+constexpr uint32_t kLongBit = 0x80000000u;
+
+__global__ __launch_bounds__(256) void pack_compact_kernel(const int64_t* ptr, const int32_t* idx,
+                                                           const double* val, const double* y, int64_t n,
+                                                           char* P, char* Q, uint32_t* longmap) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t q0 = ptr[i];
+    const int nnz = (int)(ptr[i + 1] - q0);
+    char* pb = P + (size_t)i * kCStride;
+    *reinterpret_cast<double*>(pb) = y[i];
+    uint16_t* pid = reinterpret_cast<uint16_t*>(pb + 8);
+    double* pv = reinterpret_cast<double*>(pb + 32);
+    for (int e = 0; e < kCP; ++e) {
+      pid[e] = e < nnz ? (uint16_t)idx[q0 + e] : (uint16_t)0;
+      pv[e] = e < nnz ? val[q0 + e] : 0.0;
+    }
+    if (nnz > kCP) {
+      char* qb = Q + (size_t)i * kCStride;
+      reinterpret_cast<int*>(qb)[0] = nnz;
+      reinterpret_cast<int*>(qb)[1] = 0;
+      uint16_t* qid = reinterpret_cast<uint16_t*>(qb + 8);
+      double* qv = reinterpret_cast<double*>(qb + 32);
+      for (int e = 0; e < kCP; ++e) {
+        qid[e] = kCP + e < nnz ? (uint16_t)idx[q0 + kCP + e] : (uint16_t)0;
+        qv[e] = kCP + e < nnz ? val[q0 + kCP + e] : 0.0;
+      }
+      atomicOr(longmap + (i >> 5), 1u << (i & 31));
+    }
+  }
+}
+
+// entries 16.. of a long row
+template <class F>
+__device__ __forceinline__ void row_tail_compact(const SagaDev& d, uint32_t sid, int nnz, int gl, F f) {
+  const char* qb = d.cQ + (size_t)sid * kCStride;
+  for (int e = kInReg8 + gl; e < nnz; e += kLanes8) {
+    if (e < 2 * kCP) {
+      f((int64_t) reinterpret_cast<const uint16_t*>(qb + 8)[e - kCP],
+        reinterpret_cast<const double*>(qb + 32)[e - kCP]);
+    } else {
+      const int64_t q0 = d.ptr[sid];
+      f((int64_t)d.idx[q0 + e], d.val[q0 + e]);
+    }
+  }
+}
+
+template <int kThreads>
+__device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint32_t* sp, int lo, int hi, double b0,
+                                                    const double* wv, double* Dl) {
+  typedef double dpair_t __attribute__((ext_vector_type(2)));
+  constexpr int U = 4;
+  constexpr int kG = kThreads / kLanes8;
+  constexpr int kStep = kG * U;
+  const int gl = threadIdx.x & (kLanes8 - 1);
+  const int g8 = threadIdx.x / kLanes8;
+  const int q = gl >> 1;
+  const bool is_owner = (gl & 1) == 0;
+  const bool in_p = gl < 6;                     // this lane's two entries come from plane P
+  const char* plane = in_p ? d.cP : d.cQ;
+  const int slot = in_p ? gl : gl - 6;
+  const uint32_t* lm = d.clong;
+  double gct = 0.0;
+  int i = lo + g8;
+  if (i >= hi) return 0.0;
+  auto own_pos = [&](int base) { return base + q * kG < hi ? base + q * kG : base; };
+  auto tagged = [&](uint32_t sid) { return sid | (((lm[sid >> 5] >> (sid & 31)) & 1u) ? kLongBit : 0u); };
+  uint32_t s_cur = sp[own_pos(i)];
+  uint32_t s_nxt = i + kStep < hi ? sp[own_pos(i + kStep)] : 0u;
+  s_cur = tagged(s_cur);
+  for (; i < hi; i += kStep) {
+    const bool v_own = i + q * kG < hi;
+    uint32_t su[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) su[u] = (uint32_t)__shfl((int)s_cur, 2 * u, kLanes8);
+    const uint32_t s_this = s_cur & ~kLongBit;
+    const bool long_own = (s_cur & kLongBit) != 0;
+    const double y_own = *reinterpret_cast<const double*>(d.cP + (size_t)s_this * kCStride);
+    int nnz_own = 0;
+    if (long_own) nnz_own = *reinterpret_cast<const int*>(d.cQ + (size_t)s_this * kCStride);
+    uint32_t jf[U];
+    dpair_t vf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool on = in_p || (su[u] & kLongBit) != 0;
+      const char* base = plane + (size_t)(su[u] & ~kLongBit) * kCStride;
+      jf[u] = 0u;
+      vf[u] = dpair_t{0.0, 0.0};
+      if (on) {
+        jf[u] = *reinterpret_cast<const uint32_t*>(base + 8 + 4 * slot);
+        vf[u] = *reinterpret_cast<const dpair_t*>(base + 32 + 16 * slot);
+      }
+    }
+    // sample ids two passes ahead; long-row bits one pass ahead (its ids arrived a pass ago)
+    uint32_t s_nn = 0u;
+    if (i + 2 * kStep < hi) s_nn = sp[own_pos(i + 2 * kStep)];
+    if (i + kStep < hi) s_nxt = tagged(s_nxt);
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = vf[u].x * wv[jf[u] & 0xffffu] + vf[u].y * wv[jf[u] >> 16];
+    const bool own_tail = v_own && nnz_own > kInReg8;
+    const bool any_tail = __ballot(own_tail) != 0;
+    if (any_tail) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int nz = __shfl(own_tail ? nnz_own : 0, 2 * u, kLanes8);
+        if (nz > kInReg8) {
+          double a = 0.0;
+          row_tail_compact(d, su[u] & ~kLongBit, nz, gl, [&](int64_t j, double v) { a += v * wv[j]; });
+          acc[u] += a;
+        }
+      }
+    }
+    const bool hi4 = (gl & 4) != 0, hi2 = (gl & 2) != 0;
+    const double r0 = (hi4 ? acc[2] : acc[0]) + __shfl_xor(hi4 ? acc[0] : acc[2], 4, kLanes8);
+    const double r1 = (hi4 ? acc[3] : acc[1]) + __shfl_xor(hi4 ? acc[1] : acc[3], 4, kLanes8);
+    double t = (hi2 ? r1 : r0) + __shfl_xor(hi2 ? r0 : r1, 2, kLanes8);
+    t += __shfl_xor(t, 1, kLanes8);
+    const double lp = t + b0;
+    const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y_own - 1.0 / (1.0 + exp(lp)) : lp - y_own;
+    double gcp = 0.0;
+    if (is_owner && v_own) {
+      const double old = __hip_atomic_exchange(d.M + s_this, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gcp = g0 - old;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double gc = __shfl(gcp, 2 * u, kLanes8);
+      if (gc != 0.0) {
+        if (vf[u].x != 0.0) scatter_add<true>(Dl + (jf[u] & 0xffffu), vf[u].x * gc);
+        if (vf[u].y != 0.0) scatter_add<true>(Dl + (jf[u] >> 16), vf[u].y * gc);
+        if (any_tail) {
+          const int nz = __shfl(own_tail ? nnz_own : 0, 2 * u, kLanes8);
+          if (nz > kInReg8)
+            row_tail_compact(d, su[u] & ~kLongBit, nz, gl,
+                             [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
+        }
+      }
+    }
+    gct += gcp;
+    s_cur = s_nxt;
+    s_nxt = s_nn;
+  }
+  return gct;
+}
+
 template <int U>
 struct K1IdsOnly {
   uint32_t s[U];
@@ -746,7 +908,10 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     const double* wv = kWLds ? Dl + KP + (KP & 1) : d.w;
     const uint32_t* sp = d.stream + t0;
     if constexpr (kLanes == kLanes8) {
-      gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
+      if (d.cP)
+        gct[0] = k1_lanes8_compact<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
+      else
+        gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
     } else {
 #ifndef SGDNET_TWO_HALVES
     // one pass of U draws per group (two software-pipelined half-passes of U/2 measured 2 us
@@ -1627,7 +1792,28 @@ static bool lanes8_ok(const SagaDev& d) {
     const char* e = getenv("SGDNET_LANES8");
     return e ? atoi(e) : 1;
   }();
-  return allow && d.rec_cap >= kInReg8 && !d.ablate;
+  return allow && (d.cP || d.rec_cap >= kInReg8) && !d.ablate;
+}
+
+// Compact planes for a K == 1 sparse problem (d.ptr / d.idx / d.val / d.y resident).
+bool compact_eligible(const SagaDev& d) {
+  static const int allow = [] {
+    const char* e = getenv("SGDNET_COMPACT");
+    return e ? atoi(e) : 1;
+  }();
+  if (!allow || d.K != 1 || d.Ky != 1 || d.xd || !d.ptr || d.p > 65536) return false;
+  if (2 * sizeof(double) * (size_t)d.p + 16 + kLdsStaticReserve > (size_t)kLdsPerCu) return false;  // no LDS form
+  return (double)d.n * 2.0 * kCStride <= 48e9;
+}
+
+int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* longmap, hipStream_t st) {
+  SGD_HIP_TRY(hipMemsetAsync(longmap, 0, sizeof(uint32_t) * (size_t)((d.n + 31) / 32 + 1), st));
+  int64_t grid = (d.n + 255) / 256;
+  if (grid > 65536) grid = 65536;
+  hipLaunchKernelGGL(pack_compact_kernel, dim3((unsigned)grid), dim3(256), 0, st, d.ptr, d.idx, d.val, d.y, d.n, P, Q,
+                     longmap);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
 }
 
 int64_t batch_gather_slab_doubles(const SagaDev& d, int m) {

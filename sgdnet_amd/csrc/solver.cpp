@@ -635,6 +635,17 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
       d.c = c;
     }
   }
+  if (s->sparse && compact_eligible(d)) {
+    char *cP = nullptr, *cQ = nullptr;
+    uint32_t* lm = nullptr;
+    TRY(dev_alloc(s, &cP, (n + 1) * 128, false));
+    TRY(dev_alloc(s, &cQ, (n + 1) * 128, false));
+    TRY(dev_alloc(s, &lm, (n + 31) / 32 + 1, false));
+    TRY(launch_pack_compact(d, cP, cQ, lm, s->st));
+    d.cP = cP;
+    d.cQ = cQ;
+    d.clong = lm;
+  }
   TRY(dev_alloc(s, &d.w, K * p, true));
   TRY(dev_alloc(s, &d.G, K * p, true));
   TRY(dev_alloc(s, &d.M, K * n, true));
