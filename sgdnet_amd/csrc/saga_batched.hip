@@ -549,15 +549,39 @@ __device__ __forceinline__ void row_tail_compact(const SagaDev& d, uint32_t sid,
   }
 }
 
-template <int kThreads>
-__device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint32_t* sp, int lo, int hi, double b0,
-                                                    const double* wv, double* Dl) {
+#ifndef SGDNET_LDS_BLOCK
+#define SGDNET_LDS_BLOCK 1024
+#endif
+constexpr int kLdsBlock = SGDNET_LDS_BLOCK;
+
+// Work distribution: a wavefront works through tickets of 32 consecutive draws (one pass:
+// 8 groups x 4 draws, one 128-B line of the sample stream); ticket t of wave w in workgroup b
+// is the fixed position ((b * T + t) * 16 + w) * 32.
+// Tried and removed: handing the last 6-20 % of a launch out dynamically from a per-shard
+// counter, because the slowest workgroup of a launch needs ~20 % longer than the mean (CUs see
+// different memory latencies, differently in every launch).  The tickets serialise on one L2
+// atomic unit (5-10 ns each): C4 with 8 shards 1256 -> 1141..1186 epochs/s, with 4 shards
+// 1016 -> 729; all tickets from the counter: 160 us per 131 072-draw launch.
+constexpr int kTicket = 32;           // draws per wavefront pass
+
+struct TicketSource {
+  int t, T;            // next ticket, number of tickets
+  int fixed_base;      // position of this wavefront's ticket 0
+  int m;
+  __device__ __forceinline__ int next() {
+    const int b = t < T ? fixed_base + t * (kLdsBlock / 64) * kTicket : m;
+    ++t;
+    return b < m ? b : m;
+  }
+};
+
+__device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint32_t* sp, int m, int blk, int nblk,
+                                                    double b0, const double* wv, double* Dl) {
   typedef double dpair_t __attribute__((ext_vector_type(2)));
   constexpr int U = 4;
-  constexpr int kG = kThreads / kLanes8;
-  constexpr int kStep = kG * U;
+  constexpr int kWgPass = (kLdsBlock / 64) * kTicket;   // draws of one pass of a whole workgroup
   const int gl = threadIdx.x & (kLanes8 - 1);
-  const int g8 = threadIdx.x / kLanes8;
+  const int g = (threadIdx.x & 63) >> 3;        // group inside the wavefront
   const int q = gl >> 1;
   const bool is_owner = (gl & 1) == 0;
   const bool in_p = gl < 6;                     // this lane's two entries come from plane P
@@ -565,15 +589,26 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
   const int slot = in_p ? gl : gl - 6;
   const uint32_t* lm = d.clong;
   double gct = 0.0;
-  int i = lo + g8;
-  if (i >= hi) return 0.0;
-  auto own_pos = [&](int base) { return base + q * kG < hi ? base + q * kG : base; };
+  TicketSource tk;
+  {
+    tk.T = (m + nblk * kWgPass - 1) / (nblk * kWgPass);
+    tk.t = 0;
+    tk.fixed_base = blk * tk.T * kWgPass + (int)(threadIdx.x >> 6) * kTicket;
+    tk.m = m;
+  }
+  // this lane's own draw of the pass whose ticket is `base` (positions past the end stand in with
+  // the ticket's first draw and are discarded)
+  auto own_pos = [&](int base) { return base + U * g + q < m ? base + U * g + q : base; };
   auto tagged = [&](uint32_t sid) { return sid | (((lm[sid >> 5] >> (sid & 31)) & 1u) ? kLongBit : 0u); };
-  uint32_t s_cur = sp[own_pos(i)];
-  uint32_t s_nxt = i + kStep < hi ? sp[own_pos(i + kStep)] : 0u;
+  int b_cur = tk.next();
+  if (b_cur >= m) return 0.0;
+  int b_nxt = tk.next();
+  int b_nn = tk.next();
+  uint32_t s_cur = sp[own_pos(b_cur)];
+  uint32_t s_nxt = b_nxt < m ? sp[own_pos(b_nxt)] : 0u;
   s_cur = tagged(s_cur);
-  for (; i < hi; i += kStep) {
-    const bool v_own = i + q * kG < hi;
+  while (b_cur < m) {
+    const bool v_own = b_cur + U * g + q < m;
     uint32_t su[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) su[u] = (uint32_t)__shfl((int)s_cur, 2 * u, kLanes8);
@@ -595,10 +630,11 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
         vf[u] = *reinterpret_cast<const dpair_t*>(base + 32 + 16 * slot);
       }
     }
-    // sample ids two passes ahead; long-row bits one pass ahead (its ids arrived a pass ago)
+    // sample ids two passes ahead, long-row bits one pass ahead
+    const int b_n3 = b_nn < m ? tk.next() : m;
     uint32_t s_nn = 0u;
-    if (i + 2 * kStep < hi) s_nn = sp[own_pos(i + 2 * kStep)];
-    if (i + kStep < hi) s_nxt = tagged(s_nxt);
+    if (b_nn < m) s_nn = sp[own_pos(b_nn)];
+    if (b_nxt < m) s_nxt = tagged(s_nxt);
     double acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = vf[u].x * wv[jf[u] & 0xffffu] + vf[u].y * wv[jf[u] >> 16];
@@ -644,6 +680,9 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
     gct += gcp;
     s_cur = s_nxt;
     s_nxt = s_nn;
+    b_cur = b_nxt;
+    b_nxt = b_nn;
+    b_nn = b_n3;
   }
   return gct;
 }
@@ -821,10 +860,6 @@ struct K1Draws {
 // wave hit one 64-B line, so a workgroup issues at most K*p/8 atomic requests
 // instead of one per non-zero.
 // --------------------------------------------------------------------------
-#ifndef SGDNET_LDS_BLOCK
-#define SGDNET_LDS_BLOCK 1024
-#endif
-constexpr int kLdsBlock = SGDNET_LDS_BLOCK;
 
 // kWLds (K == 1, 2*p doubles fit the CU's LDS): the coefficient snapshot is staged next to the
 // accumulator, so the x.w gather -- 64 distinct addresses per wave instruction, which the
@@ -909,7 +944,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     const uint32_t* sp = d.stream + t0;
     if constexpr (kLanes == kLanes8) {
       if (d.cP)
-        gct[0] = k1_lanes8_compact<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
+        gct[0] = k1_lanes8_compact(d, sp, m, vblk, kVS ? d.v_bps : (int)gridDim.x, bk[0], wv, Dl);
       else
         gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
     } else {

@@ -1102,6 +1102,13 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
       if (t[b * 16] && t[b * 16] < first) first = t[b * 16];
       if (t[b * 16 + 5] > last) last = t[b * 16 + 5];
     }
+    if (getenv("SGDNET_PHASE_DUMP")) {
+      fprintf(stderr, "[phase-dump] draw loop us by workgroup:");
+      for (int b = 0; b < 256; ++b) fprintf(stderr, " %.1f", (double)(t[b * 16 + 2] - t[b * 16 + 1]) / 100.0);
+      fprintf(stderr, "\n[phase-dump] start offset us by workgroup:");
+      for (int b = 0; b < 256; ++b) fprintf(stderr, " %.1f", (double)(t[b * 16 + 1] - first) / 100.0);
+      fprintf(stderr, "\n");
+    }
     static const char* nm[11] = {"lds zero+sync", "draw loop", "barrier", "slab flush", "d0 partial", "",
                                  "stream idx", "record loads", "w gather", "M exchange", "scatter"};
     fprintf(stderr, "[phase] kernel span %.2f us (memtime ticks at 100 MHz)\n", (double)(last - first) / 100.0);

@@ -883,3 +883,45 @@ def test_virtual_shards_match_their_oracle_restatement(sa, oracle, V, n, p, batc
         assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
     S.set_virtual_shards(0)
     S.close()
+
+
+@pytest.mark.parametrize("V,batch,family", [(0, 9000, "binomial"), (0, 1500, "gaussian"), (2, 4500, "binomial"),
+                                            (4, 1000, "gaussian")])
+def test_compact_records_row_length_boundaries(sa, oracle, V, batch, family):
+    # the K = 1 LDS gather reads two-plane compact records: 12 entries in the first plane, 12 in
+    # the second (4 of them in registers, 8 on the tail path), the rest from the CSR arrays --
+    # rows sit on every one of those boundaries, with and without virtual shards
+    rng = np.random.default_rng(77)
+    n, p = 9000, 400
+    lengths = np.array([0, 1, 2, 11, 12, 13, 15, 16, 17, 23, 24, 25, 26, 40, 90])
+    z = lengths[rng.integers(0, len(lengths), n)]
+    z[:len(lengths)] = lengths
+    ptr = np.concatenate([[0], np.cumsum(z)])
+    idx = np.concatenate([np.sort(rng.choice(p, k, replace=False)) for k in z] + [np.zeros(0, int)]).astype(np.int32)
+    val = rng.standard_normal(ptr[-1])
+    x = sp.csc_matrix((val, idx, ptr), shape=(p, n))              # column i = sample i
+    lp = np.asarray(x.T @ rng.standard_normal(p)) * 0.2
+    if family == "binomial":
+        y = (rng.random(n) < 1 / (1 + np.exp(-lp))).astype(float).reshape(1, n)
+    else:
+        y = (lp + 0.1 * rng.standard_normal(n)).reshape(1, n)
+    kw = dict(family=family, penalty="elasticnet", gamma=0.001, alpha=1e-4, beta=2e-4)
+    epochs = 2
+    if V == 0:
+        (ep, rc, st), (ep2, conv, got) = run_both(sa, oracle, x, y, epochs=epochs, mode="batched", batch=batch, K=1,
+                                                  **kw)
+        for k in STATE:
+            assert relerr(got[k], st[k]) < TOL_BATCHED, k
+        return
+    S = sa.SagaSolver(x, y, family=family, n_classes=1)
+    S.set_penalty("elasticnet", kw["gamma"], kw["alpha"], kw["beta"])
+    S.set_virtual_shards(V)
+    stream = S.sharded_stream([sa.RRng(90 + v) for v in range(V)], epochs)
+    S.upload_stream(stream)
+    ep, _ = S.run(mode="batched", batch=batch, draws_per_epoch=V * (n // V), max_epochs=epochs, tol=0.0)
+    assert ep == epochs
+    st = _oracle_virtual_shards(oracle, x, y, V, batch, stream, epochs, kw)
+    for k in STATE:
+        assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
+    S.set_virtual_shards(0)
+    S.close()
