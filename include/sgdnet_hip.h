@@ -288,6 +288,30 @@ int sgdnet_solver_convergence(sgdnet_solver* s, double tol, int* converged);
 /* max|w - w_prev| and max|w| of the most recent ConvergenceCheck (src/utils.h:248-249). */
 int sgdnet_solver_last_change(const sgdnet_solver* s, double* max_change, double* max_size);
 
+/* ---- prediction and prediction error along the lambda path ----
+ * Device versions of what the reference does on the host in R: predict.sgdnet
+ * (R/predict.sgdnet.R:347-402, type = "link": cbind2(1, newx) %*% beta for every lambda) and
+ * score.sgdnet_<family> (R/score.R:55-186), which cv_sgdnet (R/cv_sgdnet.R:161-199) calls once per
+ * (alpha, fold).  x is SAMPLE-major: CSR (rowptr int64[n+1], colidx int32, values) or dense
+ * row-major n x p.  a0 is K x n_lambda and beta K x p x n_lambda, K fastest, exactly as
+ * sgdnet_result holds them.  y as in sgdnet_fit_*: y_rows x n (class index for binomial /
+ * multinomial).  out: one value per lambda; link: n x n_lambda x K (K fastest). */
+#define SGDNET_MEASURE_DEVIANCE 0
+#define SGDNET_MEASURE_MSE      1
+#define SGDNET_MEASURE_MAE      2
+#define SGDNET_MEASURE_CLASS    3   /* binomial / multinomial */
+int sgdnet_score_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+                        const double* y, int y_rows, int family, int n_classes, const double* a0,
+                        const double* beta, int n_lambda, int measure, int device, double* out);
+int sgdnet_score_dense(const double* x, int64_t n, int64_t p, const double* y, int y_rows, int family,
+                       int n_classes, const double* a0, const double* beta, int n_lambda, int measure, int device,
+                       double* out);
+int sgdnet_predict_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx,
+                          const double* values, int n_classes, const double* a0, const double* beta,
+                          int n_lambda, int device, double* link);
+int sgdnet_predict_dense(const double* x, int64_t n, int64_t p, int n_classes, const double* a0, const double* beta,
+                         int n_lambda, int device, double* link);
+
 /* Default staleness window of the batched mode: about 2 * L_max / L_F, where L_max is the
  * largest squared sample norm and L_F is bounded below by the largest mean squared feature
  * value (the diagonal of X'X/n); clamped to [64, 131072].  DESIGN.md "Choosing the batch". */

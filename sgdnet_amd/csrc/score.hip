@@ -1,0 +1,317 @@
+// Prediction and prediction error along the lambda path on the device.
+//
+// The reference computes both on the host in R: predict.sgdnet (R/predict.sgdnet.R:347-402) is
+// cbind2(1, newx) %*% beta for every lambda, score.sgdnet_<family> (R/score.R:55-186) turns the
+// linear predictors into one loss per (sample, lambda) and averages over the samples.
+// cv_sgdnet (R/cv_sgdnet.R:161-199) calls them n_alpha * n_folds times.  Here it is one SpMM-shaped
+// kernel: a wavefront owns a sample, lane c owns the (lambda, class) pair c, the coefficient
+// matrix is re-laid (p, lambda, class) so that one non-zero of the sample meets 64 contiguous
+// coefficients, and the per-sample losses are reduced per lambda without leaving the kernel.
+#include <vector>
+
+#include "common.hpp"
+#include "device_math.hpp"
+
+namespace sgdnet {
+namespace {
+
+constexpr int kScoreBlock = 256;           // 4 wavefronts, one sample each at a time
+constexpr int kMaxPairs = 1024;            // (lambda, class) pairs per call (LDS: 4 x 8 KB)
+constexpr int kMaxLambda = 256;            // lambdas per call (4 running sums per lane)
+constexpr double kProbMin = 1e-05;         // R/score.R:88, 133
+
+struct ScoreArgs {
+  int64_t n, p;
+  int family, K, Ky, L, measure;
+  const int64_t* ptr;      // sparse, sample-major
+  const int32_t* idx;
+  const double* val;
+  const double* xd;        // dense, sample-major n x p
+  const double* y;         // Ky x n
+  const double* a0;        // K x L  (index l * K + k)
+  const double* B;         // p x L x K
+  double* link;            // n x L x K or nullptr
+  double* out;             // L sums or nullptr
+};
+
+// beta[k + K * (j + p * l)]  ->  B[(j * L + l) * K + k]
+__global__ __launch_bounds__(256) void relayout_beta_kernel(const double* beta, int64_t p, int K, int L, double* B) {
+  const int64_t total = p * (int64_t)L * K;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+    const int k = (int)(t % K);
+    const int64_t jl = t / K;
+    const int l = (int)(jl % L);
+    const int64_t j = jl / L;
+    B[t] = beta[k + (int64_t)K * (j + p * l)];
+  }
+}
+
+// one (sample, lambda) loss from the K linear predictors lp[0..K)
+__device__ __forceinline__ double sample_loss(const ScoreArgs& a, const double* lp, const double* ys) {
+  const int K = a.K;
+  if (a.family == SGDNET_GAUSSIAN) {                       // R/score.R:55-70
+    const double d = lp[0] - ys[0];
+    return a.measure == SGDNET_MEASURE_MAE ? fabs(d) : d * d;
+  }
+  if (a.family == SGDNET_MGAUSSIAN) {                      // :172-186
+    double e = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const double d = lp[k] - ys[k];
+      e += a.measure == SGDNET_MEASURE_MAE ? fabs(d) : d * d;
+    }
+    return e;
+  }
+  if (a.family == SGDNET_BINOMIAL) {                       // :74-115
+    double ph = 1.0 / (1.0 + exp(-lp[0]));
+    const double y2 = ys[0] > 0.5 ? 1.0 : 0.0, y1 = 1.0 - y2;
+    switch (a.measure) {
+      case SGDNET_MEASURE_MSE: return (ph + y1 - 1.0) * (ph + y1 - 1.0) + (ph - y2) * (ph - y2);
+      case SGDNET_MEASURE_MAE: return fabs(ph + y1 - 1.0) + fabs(ph - y2);
+      case SGDNET_MEASURE_CLASS: return y1 * (ph > 0.5 ? 1.0 : 0.0) + y2 * (ph <= 0.5 ? 1.0 : 0.0);
+      default:
+        ph = fmin(fmax(ph, kProbMin), 1.0 - kProbMin);
+        return 2.0 * (0.0 - (y1 * log(1.0 - ph) + y2 * log(ph)));
+    }
+  }
+  // multinomial, :119-168: response = exp(lp) / sum exp(lp) (R/predict.sgdnet.R:395-399)
+  const int cls = (int)(ys[0] + 0.5);
+  double den = 0.0;
+  for (int k = 0; k < K; ++k) den += exp(lp[k]);
+  double e = 0.0;
+  if (a.measure == SGDNET_MEASURE_CLASS) {
+    int best = 0;                                          // first maximum wins
+    for (int k = 1; k < K; ++k)
+      if (lp[k] > lp[best]) best = k;
+    return best == cls ? 0.0 : 1.0;
+  }
+  for (int k = 0; k < K; ++k) {
+    double ph = exp(lp[k]) / den;
+    const double yk = k == cls ? 1.0 : 0.0;
+    if (a.measure == SGDNET_MEASURE_MSE) {
+      e += (yk - ph) * (yk - ph);
+    } else if (a.measure == SGDNET_MEASURE_MAE) {
+      e += fabs(yk - ph);
+    } else {
+      ph = fmin(fmax(ph, kProbMin), 1.0 - kProbMin);
+      e += 2.0 * (0.0 - yk * log(ph));
+    }
+  }
+  return e;
+}
+
+template <bool kSparse>
+__global__ __launch_bounds__(kScoreBlock) void score_kernel(ScoreArgs a) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int LK = a.L * a.K;
+  double* lp = lds + (size_t)wave * LK;
+  double sums[kMaxLambda / 64] = {0.0, 0.0, 0.0, 0.0};
+  const int64_t wave_id = (int64_t)blockIdx.x * (kScoreBlock / 64) + wave;
+  const int64_t n_waves = (int64_t)gridDim.x * (kScoreBlock / 64);
+  for (int64_t i = wave_id; i < a.n; i += n_waves) {
+    for (int c0 = 0; c0 < LK; c0 += 64) {
+      const int c = c0 + lane;
+      const bool on = c < LK;
+      double acc = 0.0;
+      if (kSparse) {
+        const int64_t q1 = a.ptr[i + 1];
+        for (int64_t q = a.ptr[i]; q < q1; ++q) {
+          const double v = a.val[q];
+          const int64_t j = a.idx[q];
+          if (on) acc += v * a.B[j * LK + c];
+        }
+      } else {
+        const double* xs = a.xd + i * a.p;
+        for (int64_t j = 0; j < a.p; ++j) {
+          const double v = xs[j];
+          if (on && v != 0.0) acc += v * a.B[j * LK + c];
+        }
+      }
+      if (on) {
+        acc += a.a0[c];
+        lp[c] = acc;
+        if (a.link) a.link[i * LK + c] = acc;
+      }
+    }
+    if (a.out) {
+      // the wave's own LDS row: LDS operations of one wave are served in issue order; the fence
+      // keeps the compiler from moving the reads above the writes
+      __threadfence_block();
+      const double* ys = a.y + i * a.Ky;
+#pragma unroll
+      for (int r = 0; r < kMaxLambda / 64; ++r) {
+        const int l = lane + 64 * r;
+        if (l < a.L) sums[r] += sample_loss(a, lp + (size_t)l * a.K, ys);
+      }
+      __threadfence_block();
+    }
+  }
+  if (a.out) {
+#pragma unroll
+    for (int r = 0; r < kMaxLambda / 64; ++r) {
+      const int l = lane + 64 * r;
+      if (l < a.L) __hip_atomic_fetch_add(a.out + l, sums[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+struct DevBufs {
+  std::vector<void*> all;
+  ~DevBufs() {
+    for (void* q : all) (void)hipFree(q);
+  }
+  template <typename T>
+  int upload(T** out, const T* host, size_t count, hipStream_t st) {
+    void* q = nullptr;
+    if (hipMalloc(&q, sizeof(T) * (count ? count : 1)) != hipSuccess) {
+      set_error("hipMalloc(%zu bytes) failed", sizeof(T) * count);
+      return SGDNET_ENOMEM;
+    }
+    all.push_back(q);
+    if (host && count) SGD_HIP_TRY(hipMemcpyAsync(q, host, sizeof(T) * count, hipMemcpyHostToDevice, st));
+    *out = static_cast<T*>(q);
+    return SGDNET_OK;
+  }
+};
+
+int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+              const double* x_dense, const double* y, int y_rows, int family, int n_classes, const double* a0,
+              const double* beta, int n_lambda, int measure, int device, double* out, double* link) {
+  if (n < 1 || p < 1 || n_lambda < 1 || n_classes < 1 || !a0 || !beta || (!out && !link) ||
+      (out && (!y || y_rows < 1)) || family < SGDNET_GAUSSIAN || family > SGDNET_MGAUSSIAN ||
+      measure < SGDNET_MEASURE_DEVIANCE || measure > SGDNET_MEASURE_CLASS ||
+      (measure == SGDNET_MEASURE_CLASS && family != SGDNET_BINOMIAL && family != SGDNET_MULTINOMIAL) ||
+      (!x_dense && !(rowptr && colidx && values))) {
+    set_error("sgdnet_score/predict: bad argument");
+    return SGDNET_EINVAL;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    set_error("no HIP device");
+    return SGDNET_ENODEVICE;
+  }
+  if (device < 0 || device >= ndev) {
+    set_error("device %d out of range (%d devices)", device, ndev);
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(device));
+  hipStream_t st = nullptr;
+  SGD_HIP_TRY(hipStreamCreate(&st));
+  struct StreamGuard {
+    hipStream_t s;
+    ~StreamGuard() { (void)hipStreamDestroy(s); }
+  } guard{st};
+  DevBufs bufs;
+  ScoreArgs a{};
+  a.n = n;
+  a.p = p;
+  a.family = family;
+  a.K = n_classes;
+  a.Ky = y_rows > 0 ? y_rows : 1;
+  a.measure = measure;
+  int rc;
+  if (x_dense) {
+    double* xd;
+    if ((rc = bufs.upload(&xd, x_dense, (size_t)n * p, st))) return rc;
+    a.xd = xd;
+  } else {
+    int64_t* ptr;
+    int32_t* idx;
+    double* val;
+    const size_t nnz = (size_t)rowptr[n];
+    if ((rc = bufs.upload(&ptr, rowptr, (size_t)n + 1, st)) || (rc = bufs.upload(&idx, colidx, nnz, st)) ||
+        (rc = bufs.upload(&val, values, nnz, st)))
+      return rc;
+    a.ptr = ptr;
+    a.idx = idx;
+    a.val = val;
+  }
+  if (y) {
+    double* yd;
+    if ((rc = bufs.upload(&yd, y, (size_t)n * a.Ky, st))) return rc;
+    a.y = yd;
+  }
+  // lambdas in chunks that fit the kernel's LDS rows and running sums
+  int chunk = kMaxPairs / n_classes;
+  if (chunk > kMaxLambda) chunk = kMaxLambda;
+  if (chunk < 1) {
+    set_error("sgdnet_score/predict: more than %d classes", kMaxPairs);
+    return SGDNET_EUNSUPPORTED;
+  }
+  double *beta_d, *B, *a0_d, *out_d = nullptr, *link_d = nullptr;
+  const size_t K = (size_t)n_classes;
+  if ((rc = bufs.upload(&beta_d, beta, K * p * n_lambda, st)) || (rc = bufs.upload(&a0_d, a0, K * n_lambda, st)) ||
+      (rc = bufs.upload<double>(&B, nullptr, K * p * chunk, st)))
+    return rc;
+  if (out && (rc = bufs.upload<double>(&out_d, nullptr, (size_t)n_lambda, st))) return rc;
+  if (out) SGD_HIP_TRY(hipMemsetAsync(out_d, 0, sizeof(double) * n_lambda, st));
+  if (link && (rc = bufs.upload<double>(&link_d, nullptr, (size_t)n * K * chunk, st))) return rc;
+  int64_t grid = (n + 3) / 4;
+  if (grid > 8192) grid = 8192;
+  for (int l0 = 0; l0 < n_lambda; l0 += chunk) {
+    const int L = n_lambda - l0 < chunk ? n_lambda - l0 : chunk;
+    int rgrid = (int)((K * p * L + 255) / 256);
+    if (rgrid > 4096) rgrid = 4096;
+    hipLaunchKernelGGL(relayout_beta_kernel, dim3(rgrid), dim3(256), 0, st, beta_d + K * p * l0, p, n_classes, L, B);
+    a.L = L;
+    a.a0 = a0_d + K * l0;
+    a.B = B;
+    a.out = out ? out_d + l0 : nullptr;
+    a.link = link_d;
+    const size_t lds = sizeof(double) * (size_t)(kScoreBlock / 64) * L * K;
+    if (x_dense)
+      hipLaunchKernelGGL(score_kernel<false>, dim3((unsigned)grid), dim3(kScoreBlock), lds, st, a);
+    else
+      hipLaunchKernelGGL(score_kernel<true>, dim3((unsigned)grid), dim3(kScoreBlock), lds, st, a);
+    SGD_HIP_TRY(hipGetLastError());
+    if (link) {
+      // host layout: link[(i * n_lambda + l) * K + k]
+      SGD_HIP_TRY(hipMemcpy2DAsync(link + K * l0, sizeof(double) * K * n_lambda, link_d, sizeof(double) * K * L,
+                                   sizeof(double) * K * L, (size_t)n, hipMemcpyDeviceToHost, st));
+      SGD_HIP_TRY(hipStreamSynchronize(st));
+    }
+  }
+  if (out) {
+    SGD_HIP_TRY(hipMemcpyAsync(out, out_d, sizeof(double) * n_lambda, hipMemcpyDeviceToHost, st));
+    SGD_HIP_TRY(hipStreamSynchronize(st));
+    // R/score.R: mean over the samples; mgaussian: colSums over the samples, mean over the responses
+    const double scale = family == SGDNET_MGAUSSIAN ? 1.0 / (double)n_classes : 1.0 / (double)n;
+    for (int l = 0; l < n_lambda; ++l) out[l] *= scale;
+  }
+  SGD_HIP_TRY(hipStreamSynchronize(st));
+  return SGDNET_OK;
+}
+
+}  // namespace
+}  // namespace sgdnet
+
+extern "C" {
+
+int sgdnet_score_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+                        const double* y, int y_rows, int family, int n_classes, const double* a0,
+                        const double* beta, int n_lambda, int measure, int device, double* out) {
+  return sgdnet::run_score(n, p, rowptr, colidx, values, nullptr, y, y_rows, family, n_classes, a0, beta, n_lambda,
+                           measure, device, out, nullptr);
+}
+
+int sgdnet_score_dense(const double* x, int64_t n, int64_t p, const double* y, int y_rows, int family,
+                       int n_classes, const double* a0, const double* beta, int n_lambda, int measure, int device,
+                       double* out) {
+  return sgdnet::run_score(n, p, nullptr, nullptr, nullptr, x, y, y_rows, family, n_classes, a0, beta, n_lambda,
+                           measure, device, out, nullptr);
+}
+
+int sgdnet_predict_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+                          int n_classes, const double* a0, const double* beta, int n_lambda, int device,
+                          double* link) {
+  return sgdnet::run_score(n, p, rowptr, colidx, values, nullptr, nullptr, 0, SGDNET_GAUSSIAN, n_classes, a0, beta,
+                           n_lambda, SGDNET_MEASURE_DEVIANCE, device, nullptr, link);
+}
+
+int sgdnet_predict_dense(const double* x, int64_t n, int64_t p, int n_classes, const double* a0, const double* beta,
+                         int n_lambda, int device, double* link) {
+  return sgdnet::run_score(n, p, nullptr, nullptr, nullptr, x, nullptr, 0, SGDNET_GAUSSIAN, n_classes, a0, beta,
+                           n_lambda, SGDNET_MEASURE_DEVIANCE, device, nullptr, link);
+}
+
+}  // extern "C"

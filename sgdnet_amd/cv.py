@@ -138,7 +138,7 @@ def cv_sgdnet(x, y, alpha=1, lambda_=None, nfolds=10, foldid=None, type_measure=
         train = sel if train_on == "fold" else ~sel
         test = ~train
         fit = one_fit(x[train], y[train], lam[i], alpha[i], dev, fit_seed)
-        return i, j, score(fit, x[test], y[test], type_measure)
+        return i, j, score(fit, x[test], y[test], type_measure, device=dev)
 
     jobs = [(i, j, (i * nfolds + j) % len(devices), seed + 1000 + i * nfolds + j)
             for i in range(alpha.size) for j in range(nfolds)]               # (alpha, fold, worker, seed)

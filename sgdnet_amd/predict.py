@@ -48,9 +48,51 @@ def coef(fit, s=None):
     return nb if isinstance(fit.beta, list) else nb[0]
 
 
-def predict(fit, newx=None, s=None, type="link", exact=False):
+def _stacked_coefficients(nb):
+    """(a0, beta) as the C ABI holds them: a0 K x L and beta K x p x L, K fastest."""
+    K, L = len(nb), nb[0].shape[1]
+    p = nb[0].shape[0] - 1
+    a0 = np.empty((L, K))
+    beta = np.empty((L, p, K))
+    for k, m in enumerate(nb):
+        a0[:, k] = m[0, :]
+        beta[:, :, k] = m[1:, :].T
+    return np.ascontiguousarray(a0), np.ascontiguousarray(beta), K, p, L
+
+
+def device_link(nb, newx, device):
+    """cbind2(1, newx) %*% beta for every lambda on the GPU (sgdnet_predict_*, score.hip):
+    list over classes of (n, n_lambda) arrays."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from . import _lib
+    from ._lib import check, dptr
+    a0, beta, K, p, L = _stacked_coefficients(nb)
+    Lh = _lib.load()
+    if sp.issparse(newx):
+        X = sp.csr_matrix(newx, dtype=np.float64)
+        X.sort_indices()
+        n = X.shape[0]
+        link = np.empty((n, L, K))
+        ptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        idx = np.ascontiguousarray(X.indices, dtype=np.int32)
+        val = np.ascontiguousarray(X.data, dtype=np.float64)
+        check(Lh.sgdnet_predict_sparse(C.c_int64(n), C.c_int64(p), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                       idx.ctypes.data_as(C.POINTER(C.c_int32)), dptr(val), C.c_int(K), dptr(a0),
+                                       dptr(beta), C.c_int(L), C.c_int(device), dptr(link)))
+    else:
+        X = np.ascontiguousarray(newx, dtype=np.float64)
+        n = X.shape[0]
+        link = np.empty((n, L, K))
+        check(Lh.sgdnet_predict_dense(dptr(X), C.c_int64(n), C.c_int64(p), C.c_int(K), dptr(a0), dptr(beta),
+                                      C.c_int(L), C.c_int(device), dptr(link)))
+    return [link[:, :, k] for k in range(K)]
+
+
+def predict(fit, newx=None, s=None, type="link", exact=False, device=None):
     """predict.sgdnet_<family> (R/predict.sgdnet.R:347-583).  `exact=TRUE` (refit at s) is a
-    front-end loop around sgdnet() and is not mirrored: call sgdnet() with the wanted lambdas."""
+    front-end loop around sgdnet() and is not mirrored: call sgdnet() with the wanted lambdas.
+    device: compute the linear predictors on that GPU (sgdnet_predict_*) instead of in numpy."""
     if exact:
         raise NotImplementedError("exact = TRUE refits the model: call sgdnet() with lambda_ = s instead")
     fam = fit.family
@@ -73,7 +115,12 @@ def predict(fit, newx=None, s=None, type="link", exact=False):
     if X.ndim == 1:
         X = X.reshape(1, -1)
     mats = nb if multi else [nb]
-    link = [np.asarray(X @ m[1:, :]) + m[0:1, :] for m in mats]                # cbind2(1, newx) %*% beta
+    if device is not None:
+        if X.shape[1] != mats[0].shape[0] - 1:
+            raise ValueError("newx has the wrong number of features")
+        link = device_link(mats, X, device)
+    else:
+        link = [np.asarray(X @ m[1:, :]) + m[0:1, :] for m in mats]            # cbind2(1, newx) %*% beta
     if not multi:
         f = link[0]
         if fam == "binomial":

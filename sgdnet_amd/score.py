@@ -1,7 +1,7 @@
 """score(): prediction error along the lambda path; host mirror of the reference's R/score.R."""
 import numpy as np
 
-from .predict import predict
+from .predict import predict, coef, _stacked_coefficients
 
 _MEASURES = {"gaussian": ("deviance", "mse", "mae"), "mgaussian": ("deviance", "mse", "mae"),
              "binomial": ("deviance", "mse", "mae", "class", "auc"),
@@ -38,13 +38,73 @@ def auc(y01, prob, weights=None, tie_break=None):
     return float(np.exp(wauc - np.log(sumw1) - np.log(sumw2)))
 
 
-def score(fit, x, y, type_measure="deviance", s=None):
-    """score.sgdnet_<family>: one value per lambda (or per entry of s)."""
+def _score_device(fit, x, y, type_measure, s, device):
+    """sgdnet_score_* (score.hip): linear predictors, per-sample losses and their means in one
+    kernel on the GPU; x never leaves sample-major form and no (n, n_lambda) array is built."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from . import _lib
+    from ._lib import FAMILIES, MEASURES, check, dptr
+    fam = fit.family
+    nb = coef(fit, s)
+    nb = nb if isinstance(nb, list) else [nb]
+    a0, beta, K, p, L = _stacked_coefficients(nb)
+    y = np.asarray(y)
+    if fam in ("binomial", "multinomial"):
+        # diag(K)[as.numeric(y), ] with the factor levels of the fit (a held-out fold may miss one)
+        uniq, inv = np.unique(y.ravel(), return_inverse=True)
+        names = [str(v) for v in uniq]
+        if fit.classnames is not None and all(nm in fit.classnames for nm in names):
+            pos = np.array([list(fit.classnames).index(nm) for nm in names])
+        else:
+            pos = np.arange(uniq.size)
+        yy = pos[inv].astype(np.float64).reshape(1, -1)
+    elif fam == "mgaussian":
+        yy = np.ascontiguousarray(np.asarray(y, dtype=np.float64))            # (n, K): K fastest per sample
+    else:
+        yy = np.asarray(y, dtype=np.float64).reshape(1, -1)
+    yy = np.ascontiguousarray(yy)
+    y_rows = K if fam == "mgaussian" else 1
+    out = np.empty(L)
+    Lh = _lib.load()
+    common = (dptr(yy), C.c_int(y_rows), C.c_int(FAMILIES[fam]), C.c_int(K), dptr(a0), dptr(beta), C.c_int(L),
+              C.c_int(MEASURES[type_measure]), C.c_int(device), dptr(out))
+    if sp.issparse(x):
+        X = sp.csr_matrix(x, dtype=np.float64)
+        X.sort_indices()
+        if X.shape[1] != p:
+            raise ValueError("x has the wrong number of features")
+        ptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        idx = np.ascontiguousarray(X.indices, dtype=np.int32)
+        val = np.ascontiguousarray(X.data, dtype=np.float64)
+        check(Lh.sgdnet_score_sparse(C.c_int64(X.shape[0]), C.c_int64(p), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                     idx.ctypes.data_as(C.POINTER(C.c_int32)), dptr(val), *common))
+    else:
+        X = np.ascontiguousarray(x, dtype=np.float64)
+        if X.shape[1] != p:
+            raise ValueError("x has the wrong number of features")
+        check(Lh.sgdnet_score_dense(dptr(X), C.c_int64(X.shape[0]), C.c_int64(p), *common))
+    return out
+
+
+def score(fit, x, y, type_measure="deviance", s=None, device=None):
+    """score.sgdnet_<family>: one value per lambda (or per entry of s).
+    device: evaluate on that GPU (every measure except "auc", which needs a sort of the
+    probabilities and stays in numpy on device-computed predictions)."""
     fam = fit.family
     if type_measure not in _MEASURES[fam]:
         raise ValueError("'arg' should be one of " + ", ".join(f"'{m}'" for m in _MEASURES[fam]))
     s = fit.lambda_ if s is None else s
     y = np.asarray(y)
+    if device is not None:
+        if type_measure == "auc":
+            ph = predict(fit, x, s, type="response", device=device)
+            levels = np.unique(y)
+            Y = (y.reshape(-1, 1) == levels.reshape(1, -1)).astype(np.float64)
+            return np.array([auc(Y, ph[:, i]) for i in range(ph.shape[1])])
+        if type_measure == "deviance" and fam in ("gaussian", "mgaussian"):
+            type_measure = "mse"                                  # R/score.R:63, 180: the same number
+        return _score_device(fit, x, y, type_measure, s, device)
     if fam == "gaussian":                                         # R/score.R:55-70
         yh = predict(fit, x, s)
         d = yh - y.reshape(-1, 1)

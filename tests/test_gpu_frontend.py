@@ -116,3 +116,58 @@ def test_nas_in_new_data_propagate(sa):
     x[10, :] = np.nan
     out = sa.predict(fit, x)
     assert np.all(np.isnan(out[10])) and np.all(np.isfinite(np.delete(out, 10, axis=0)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("family,sparse", [("gaussian", True), ("gaussian", False), ("binomial", True),
+                                           ("binomial", False), ("multinomial", True), ("mgaussian", False)])
+def test_device_predict_and_score_match_the_host_mirror(sa, family, sparse):
+    # score.hip: linear predictors + every measure of R/score.R on the GPU
+    # against the numpy mirror of the R code, on held-out rows, for the whole lambda path
+    import scipy.sparse as sp
+    from sgdnet_amd.score import _MEASURES
+    rng = np.random.default_rng(12)
+    n, p, K = 700, 40, 3
+    X = rng.standard_normal((n, p)) * (rng.random((n, p)) < 0.3)
+    B = rng.standard_normal((p, K)) * (rng.random((p, K)) < 0.4)
+    eta = X @ B
+    if family == "gaussian":
+        y = eta[:, 0] + 0.3 * rng.standard_normal(n)
+    elif family == "binomial":
+        y = (rng.random(n) < 1 / (1 + np.exp(-eta[:, 0]))).astype(int)
+    elif family == "multinomial":
+        y = np.argmax(eta + rng.gumbel(size=eta.shape), axis=1)
+    else:
+        y = eta + 0.3 * rng.standard_normal(eta.shape)
+    Xin = sp.csc_matrix(X) if sparse else X
+    fit = sa.sgdnet(Xin[:500], y[:500], family=family, alpha=0.7, nlambda=30, thresh=1e-6, standardize=False)
+    xt, yt = Xin[500:], y[500:]
+    for typ in ("link", "response"):
+        a = sa.predict(fit, xt, type=typ)
+        b = sa.predict(fit, xt, type=typ, device=0)
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-11, atol=1e-12)
+    s = fit.lambda_[[0, 3, 7]] * 0.9                             # interpolated lambdas too
+    for measure in _MEASURES[family]:
+        for sel in (None, s):
+            host = sa.score(fit, xt, yt, measure, s=sel)
+            dev = sa.score(fit, xt, yt, measure, s=sel, device=0)
+            assert host.shape == dev.shape
+            assert np.allclose(host, dev, rtol=1e-10, atol=1e-12), (measure, host, dev)
+    with pytest.raises(ValueError):
+        sa.score(fit, xt[:, :5], yt, device=0)
+
+
+@pytest.mark.gpu
+def test_device_score_with_many_lambdas_and_classes_is_chunked(sa):
+    # more (lambda, class) pairs than one launch holds: the C entry point walks the path in chunks
+    rng = np.random.default_rng(13)
+    n, p, K = 400, 12, 7
+    X = rng.standard_normal((n, p))
+    y = rng.integers(0, K, n)
+    y[:K] = np.arange(K)
+    fit = sa.sgdnet(X, y, family="multinomial", alpha=0.5, nlambda=20, thresh=1e-5, standardize=False)
+    s = np.geomspace(fit.lambda_[0], fit.lambda_[-1], 400)       # 400 x 7 pairs
+    host = sa.score(fit, X, y, "deviance", s=s)
+    dev = sa.score(fit, X, y, "deviance", s=s, device=0)
+    assert np.allclose(host, dev, rtol=1e-10)
+    assert np.allclose(sa.predict(fit, X, s=s), sa.predict(fit, X, s=s, device=0), rtol=1e-11, atol=1e-12)
