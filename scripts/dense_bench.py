@@ -28,3 +28,18 @@ if n <= 200_000:
     t = time.time(); po.saga(x, y, st, family="binomial", penalty="elasticnet", gamma=gamma, alpha=0.5 / n, beta=0.5 / n,
                              max_iter=1, tol=0.0, stream=stream[:n]); dt = time.time() - t
     print(f"  CPU oracle {dt*1e3:.1f} ms/epoch = {n/dt/1e6:.2f} M draws/s", flush=True)
+# virtual shards: V replicas over sample ranges, one launch per batch of all shards
+for V in [int(v) for v in os.environ.get("DENSE_VSHARDS", "2,4,8").split(",") if v]:
+    if 2 * V * 100 * p > n * 2:
+        continue
+    S.set_virtual_shards(V)
+    for k, z in (("w", np.zeros((1, p))), ("g_sum", np.zeros((1, p))), ("g_sum_intercept", np.zeros(1)),
+                 ("g_memory", np.zeros((1, n))), ("intercept", np.zeros(1))):
+        S.set(k, z)
+    draws = (n // V) * V
+    S.upload_stream(S.sharded_stream([sa.RRng(1 + v) for v in range(V)], 4))
+    S.run(mode="batched", batch=batch, draws_per_epoch=draws, max_epochs=1, tol=0.0)
+    t = time.time(); S.run(mode="batched", batch=batch, draws_per_epoch=draws, max_epochs=3, tol=0.0, stream_offset=draws)
+    dt = (time.time() - t) / 3
+    print(f"  {V} virtual shards: {dt*1e3:.2f} ms/epoch = {n/dt/1e6:.1f} M draws/s, {8*p*n/dt/1e9:.0f} GB/s of rows",
+          flush=True)

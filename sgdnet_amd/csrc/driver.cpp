@@ -453,7 +453,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   // one response runs as up to 8 locally normalised replicas over sample ranges, averaged on the
   // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
   // at the benchmark shapes.  SGDNET_VSHARDS=0 switches it off, =V forces V.
-  if (mode == SGDNET_MODE_BATCHED && X.sparse && K == 1 && !(ctl->standardize && X.sparse)) {
+  if (mode == SGDNET_MODE_BATCHED && K == 1 && !(ctl->standardize && X.sparse)) {
     int V = 1;
     while (V < 8 && (int64_t)(2 * V) * 100 * p <= n) V *= 2;
     if (const char* e = getenv("SGDNET_VSHARDS")) V = atoi(e);

@@ -1041,28 +1041,33 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
 // --------------------------------------------------------------------------
 constexpr int kDenseBlock = 256;
 
-template <int KMAX>
-__global__ __launch_bounds__(kDenseBlock) void saga_batch_gather_dense_kernel(SagaDev d, const LamParams* lamp,
-                                                                              int64_t t0_in_epoch, int m,
-                                                                              int batch_id_offset,
-                                                                              int draws_per_block) {
+// kVS (K == 1): virtual shards as in the sparse LDS gather -- workgroup b works for shard
+// b / d.v_bps on that shard's replica of (w, b) and its region of the sample stream.
+template <int KMAX, int kThreads = kDenseBlock, bool kVS = false>
+__global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaDev d, const LamParams* lamp,
+                                                                           int64_t t0_in_epoch, int m,
+                                                                           int batch_id_offset,
+                                                                           int draws_per_block) {
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   const int K = KMAX == 1 ? 1 : d.K;
   const int64_t p = d.p, KP = (int64_t)K * p;
-  for (int64_t i = threadIdx.x; i < KP; i += kDenseBlock) Dl[i] = 0.0;
+  const int vsh = kVS ? (int)blockIdx.x / d.v_bps : 0;
+  const int vblk = kVS ? (int)blockIdx.x - vsh * d.v_bps : (int)blockIdx.x;
+  const double* w_src = kVS ? d.vw + (int64_t)vsh * KP : d.w;
+  for (int64_t i = threadIdx.x; i < KP; i += kThreads) Dl[i] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch + (kVS ? (int64_t)vsh * d.v_dps : 0);
   const int batch_id = lamp->batch_seq + batch_id_offset;
-  const int lo = blockIdx.x * draws_per_block;
+  const int lo = vblk * draws_per_block;
   const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
   double bk[KMAX], gct[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
-    bk[k] = k < K ? d.b[k] : 0.0;
+    bk[k] = k < K ? (kVS ? d.vb[vsh] : d.b[k]) : 0.0;
     gct[k] = 0.0;
   }
-  for (int i = lo + wave; i < hi; i += kDenseBlock / 64) {
+  for (int i = lo + wave; i < hi; i += kThreads / 64) {
     const uint32_t s = d.stream[t0 + i];
     const double* xs = d.xd + (int64_t)s * p;
     int prev = batch_id;
@@ -1090,7 +1095,7 @@ __global__ __launch_bounds__(kDenseBlock) void saga_batch_gather_dense_kernel(Sa
       for (int r = 0; r < kRowU; ++r) {
         const int64_t j = j0 + 64 * r;
         if (j < p) {
-          const double* wj = d.w + j * K;
+          const double* wj = w_src + j * K;
 #pragma unroll
           for (int k = 0; k < KMAX; ++k)
             if (k < K) acc[k] += xv[r] * wj[k];
@@ -1172,8 +1177,19 @@ __global__ __launch_bounds__(kDenseBlock) void saga_batch_gather_dense_kernel(Sa
   }
   __syncthreads();
   double* slab = d.slab + (int64_t)blockIdx.x * KP;
-  for (int64_t i = threadIdx.x; i < KP; i += kDenseBlock) slab[i] = Dl[i];
-  if (d.fit_intercept) store_d0_partial<KMAX, kDenseBlock>(d, K, batch_id, gct);
+  for (int64_t i = threadIdx.x; i < KP; i += kThreads) slab[i] = Dl[i];
+  if (kVS) {                                    // one partial per workgroup, summed per shard by the sweep
+    __shared__ double vpart[kThreads / 64];
+    if (lane == 0) vpart[wave] = gct[0];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double tot = 0.0;
+      for (int wv = 0; wv < kThreads / 64; ++wv) tot += vpart[wv];
+      d.vd0[blockIdx.x] = tot;
+    }
+  } else if (d.fit_intercept) {
+    store_d0_partial<KMAX, kThreads>(d, K, batch_id, gct);
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -1986,8 +2002,9 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
 // Virtual shards need the K == 1 LDS gather with w staged in LDS and a grid that splits evenly.
 bool vs_eligible(const SagaDev& d, int m) {
   (void)m;
-  if (d.V < 2 || d.K != 1 || d.standardize || d.force_global || d.xd || !d.vw) return false;
+  if (d.V < 2 || d.K != 1 || d.standardize || d.force_global || !d.vw) return false;
   const size_t table = sizeof(double) * (size_t)d.p;
+  if (d.xd) return table <= 80 * 1024;                           // dense x: only the accumulator is staged
   return 2 * table + 16 + kLdsStaticReserve <= kLdsPerCu;     // accumulator + coefficient snapshot in LDS
 }
 
@@ -2021,6 +2038,25 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
   if (grid / d.V != d.v_bps || grid > kD0Slots) {
     set_error("internal: virtual-shard geometry (%d workgroups, %d per shard)", grid, d.v_bps);
     return SGDNET_EINVAL;
+  }
+  if (d.xd) {
+    constexpr int kDenseVsBlock = 1024;           // 16 wavefronts share one LDS copy of the accumulator
+    const int waves = kDenseVsBlock / 64;
+    int dpb = (m + d.v_bps - 1) / d.v_bps;
+    dpb = (dpb + waves - 1) / waves * waves;
+    static bool dense_vs_attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!dense_vs_attr_done[dev & 63]) {
+      SGD_HIP_TRY(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<1, kDenseVsBlock, true>),
+          hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      dense_vs_attr_done[dev & 63] = true;
+    }
+    hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<1, kDenseVsBlock, true>), dim3(grid), dim3(kDenseVsBlock),
+                          sizeof(double) * (size_t)d.p, st, ev0, ev1, 0, d, lam, t0_in_epoch, m, 0, dpb);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
   }
   int dpb = (m + d.v_bps - 1) / d.v_bps;
   const int per_round = kLdsBlock / kGroup;

@@ -1304,8 +1304,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   d.V = 0;
   d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = nullptr;
   if (n_shards < 2) return SGDNET_OK;
-  if (!s->sparse || d.K != 1 || d.standardize) {
-    set_error("virtual shards: sparse x, one class, no centring");
+  if (d.K != 1 || d.standardize) {
+    set_error("virtual shards: one class, no implicit centring");
     return SGDNET_EUNSUPPORTED;
   }
   const int64_t KP = d.p;
@@ -1336,6 +1336,14 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   // shard v owns the samples [v * base + min(v, rem), ...): sgdnet_amd/parallel.py shard_bounds
   const int64_t base = d.n / n_shards, rem = d.n % n_shards;
   for (int v = 0; v < 8; ++v) d.v_size[v] = v < n_shards ? (double)(base + (v < rem ? 1 : 0)) : 0.0;
+  if (!vs_eligible(d, 0)) {   // the gather forms that carry shards keep their tables in LDS
+    for (void* q : s->vs_owned) (void)hipFree(q);
+    s->vs_owned.clear();
+    d.V = 0;
+    d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = nullptr;
+    set_error("virtual shards: n_features too large for the LDS-resident gather");
+    return SGDNET_EUNSUPPORTED;
+  }
   return SGDNET_OK;
 }
 

@@ -867,10 +867,21 @@ def _oracle_virtual_shards(oracle, x, y, V, batch, stream, epochs, kw):
 @pytest.mark.parametrize("V,n,p,batch,family", [(2, 4000, 60, 64, "binomial"), (4, 6002, 90, 100, "gaussian"),
                                                 (4, 40000, 64, 2500, "binomial")])
 def test_virtual_shards_match_their_oracle_restatement(sa, oracle, V, n, p, batch, family):
-    x, y = make_problem(family, 1, n, p, 0.1, seed=29)
+    _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense=False)
+
+
+@pytest.mark.parametrize("V,n,p,batch,family", [(2, 3000, 40, 50, "binomial"), (8, 8003, 70, 90, "gaussian")])
+def test_virtual_shards_on_dense_x(sa, oracle, V, n, p, batch, family):
+    # the dense batched gather carries virtual shards too (16 wavefronts per workgroup, one LDS
+    # copy of the accumulator); the restatement is the same as for sparse x
+    _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense=True)
+
+
+def _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense):
+    x, y = make_problem(family, 1, n, p, 0.5 if dense else 0.1, seed=29)
     kw = dict(family=family, penalty="elasticnet", gamma=0.005, alpha=1e-4, beta=1e-4)
     epochs = 3
-    S = sa.SagaSolver(x, y, family=family, n_classes=1)
+    S = sa.SagaSolver(np.asfortranarray(x.toarray()) if dense else x, y, family=family, n_classes=1)
     S.set_penalty("elasticnet", kw["gamma"], kw["alpha"], kw["beta"])
     S.set_virtual_shards(V)
     stream = S.sharded_stream([sa.RRng(60 + v) for v in range(V)], epochs)
