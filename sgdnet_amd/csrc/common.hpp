@@ -148,6 +148,7 @@ int launch_delta_export(const SagaDev& d, const double* ref, double* out, double
 int launch_delta_apply(const SagaDev& d, double* ref, const double* merged, double w_weight, hipStream_t st);
 int batched_max_classes();
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
-                    int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr);
+                    int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,
+                    int gens = 1);
 
 }  // namespace sgdnet

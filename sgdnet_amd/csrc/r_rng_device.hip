@@ -50,10 +50,20 @@ __device__ __forceinline__ uint32_t word_to_draw(uint32_t y, double n) {
 // (Three barriers per block and the conversion inside the loop: 10.3 ms per 10M draws.)
 constexpr int kRngBlock = 256;
 
+// Several independent generators (batched mode, solver.cpp: solver_rng_open): workgroup g carries
+// generator g (state g of st_in / st_out) and fills the g-th segment of `seg` words.
 __global__ __launch_bounds__(kRngBlock) void r_mt_state_kernel(const uint32_t* st_in, uint32_t* st_out,
-                                                               uint32_t* out, int64_t count) {
+                                                               uint32_t* out, int64_t count, int64_t seg) {
   __shared__ uint32_t buf[2][kN + 1];
   const int t = threadIdx.x;
+  {
+    const int64_t g = blockIdx.x;
+    st_in += g * (kN + 1);
+    st_out += g * (kN + 1);
+    out += g * seg;
+    const int64_t left = count - g * seg;
+    count = left < 0 ? 0 : (left < seg ? left : seg);
+  }
   for (int i = t; i < kN; i += kRngBlock) buf[0][i] = st_in[1 + i];
   uint32_t mti = st_in[0];
   __syncthreads();
@@ -122,7 +132,7 @@ __global__ __launch_bounds__(256) void r_mt_convert_kernel(uint32_t* out, int64_
 
 // state_in -> state_out (may alias); raw words then draws into out[0, count)
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
-                    int64_t count, hipStream_t st, int n_shards, const double* shard_size) {
+                    int64_t count, hipStream_t st, int n_shards, const double* shard_size, int gens) {
   RngShards sh{};
   sh.V = n_shards;
   if (n_shards > 1) {
@@ -134,7 +144,9 @@ int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_sa
       lo += shard_size[v];
     }
   }
-  hipLaunchKernelGGL(r_mt_state_kernel, dim3(1), dim3(kRngBlock), 0, st, state_in, state_out, out, count);
+  if (gens < 1) gens = 1;
+  const int64_t seg = (count + gens - 1) / gens;
+  hipLaunchKernelGGL(r_mt_state_kernel, dim3(gens), dim3(kRngBlock), 0, st, state_in, state_out, out, count, seg);
   int grid = (int)((count + 256 * 8 - 1) / (256 * 8));
   if (grid < 1) grid = 1;
   if (grid > 2048) grid = 2048;

@@ -936,3 +936,26 @@ def test_compact_records_row_length_boundaries(sa, oracle, V, batch, family):
         assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
     S.set_virtual_shards(0)
     S.close()
+
+
+def test_parallel_generators_reach_the_same_optimum(sa, oracle, monkeypatch):
+    # batched fits with long epochs cut the sample stream into 8 segments with their own MT19937
+    # (driver.cpp); forced on here for a small problem: same optimum as with the single R stream,
+    # reproducible for a given seed, and the caller's generator ends in a defined state
+    rng = np.random.default_rng(55)
+    n, p = 6000, 30
+    X = sp.csc_matrix(rng.standard_normal((n, p)) * (rng.random((n, p)) < 0.3))
+    y = (rng.random(n) < 1 / (1 + np.exp(-np.asarray(X @ rng.standard_normal(p)).ravel()))).astype(float)
+    kw = dict(family="binomial", alpha=0.5, lambda_=[0.002], standardize=False, thresh=1e-10, maxit=3000,
+              mode="batched", batch=500)
+    one = sa.sgdnet(X, y, seed=4, **kw)
+    monkeypatch.setenv("SGDNET_RNG_GENERATORS", "8")
+    st_a, st_b = sa.RRng(4), sa.RRng(4)
+    a = sa.sgdnet(X, y, rng=st_a, **kw)
+    b = sa.sgdnet(X, y, rng=st_b, **kw)
+    assert a.return_codes[0] == 0 and a.npasses == b.npasses
+    assert np.allclose(a.beta, b.beta, rtol=0, atol=1e-12)            # same streams, same fit
+    assert np.abs(a.beta - one.beta).max() < 1e-6                     # another order, same optimum
+    assert np.array_equal(st_a.stream(n, 50), st_b.stream(n, 50))
+    ref = sa.RRng(4)
+    assert not np.array_equal(st_a.stream(n, 50), ref.stream(n, 50))  # the caller's generator moved
