@@ -449,17 +449,23 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   rc = sgdnet_solver_set_state(S, 1, b0.data());
   if (rc) return rc;
 
+  int vshards = 0;
   // Virtual shards (include/sgdnet_hip.h): with enough samples per feature the batched fit of
   // one response runs as up to 8 locally normalised replicas over sample ranges, averaged on the
   // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
   // at the benchmark shapes.  SGDNET_VSHARDS=0 switches it off, =V forces V.
   if (mode == SGDNET_MODE_BATCHED && K == 1 && !(ctl->standardize && X.sparse)) {
     int V = 1;
-    while (V < 8 && (int64_t)(2 * V) * 100 * p <= n) V *= 2;
+    // at least 100 samples per feature in every shard, and a problem large enough for the
+    // per-launch cost to matter (small correlated data, e.g. abalone 4177 x 9, converges slower
+    // or not at all when its replicas are averaged)
+    if (n >= 200000)
+      while (V < 8 && (int64_t)(2 * V) * 100 * p <= n) V *= 2;
     if (const char* e = getenv("SGDNET_VSHARDS")) V = atoi(e);
     if (V >= 2 && V <= 8) {
       rc = sgdnet_solver_set_virtual_shards(S, V);
       if (rc && rc != SGDNET_EUNSUPPORTED) return rc;
+      if (!rc) vshards = V;
     }
   }
 
@@ -529,20 +535,47 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
         if (rc) return rc;
       }
       epochs += ran;
-      if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && batch > 64) {
+      if (mode == SGDNET_MODE_BATCHED) {
         // guard of the automatic window: the stale-sum step is only stable below ~L_max/L_F
         // draws, and the bound used by sgdnet_auto_batch is optimistic for correlated
         // features.  A change ratio that keeps growing (or stops being finite) halves it.
         double ch = 0.0, sz = 0.0;
         sgdnet_solver_last_change(S, &ch, &sz);
         const double ratio = sz > 0.0 ? ch / sz : 0.0;
-        if (!std::isfinite(ratio) || !std::isfinite(sz)) {
-          set_error("batched mode diverged (non-finite coefficients); pass a smaller control.batch");
-          return SGDNET_EUNSUPPORTED;
+        // the soft threshold maps a NaN coefficient to 0, so a blown-up run can look converged
+        // (max|w| = 0): the intercept keeps the evidence
+        bool finite = std::isfinite(ratio) && std::isfinite(sz);
+        if (finite && fit_intercept) {
+          rc = sgdnet_solver_get_state(S, 1, b.data());
+          if (rc) return rc;
+          for (int k = 0; k < K; ++k) finite = finite && std::isfinite(b[(size_t)k]);
+        }
+        if (!finite) {
+          // restart this lambda from the null model: first without virtual shards (their
+          // averaging assumes shards that look alike), then with a quarter of the window
+          if (ctl->batch > 0 && vshards <= 1) {
+            set_error("batched mode diverged (non-finite coefficients); pass a smaller control.batch");
+            return SGDNET_EUNSUPPORTED;
+          }
+          if (vshards > 1) {
+            vshards = 0;
+            rc = sgdnet_solver_set_virtual_shards(S, 0);
+          } else if (batch > 64) {
+            batch = std::max<int64_t>(64, batch / 4);
+          } else {
+            set_error("batched mode diverged (non-finite coefficients) at the smallest window; use mode = exact");
+            return SGDNET_EUNSUPPORTED;
+          }
+          if (!rc) rc = solver_reset_state(S, b0.data());
+          if (rc) return rc;
+          worse = 0;
+          best_ratio = HUGE_VAL;
+          converged = 0;
+          continue;
         }
         if (ratio > 4.0 * best_ratio) ++worse; else worse = 0;
         best_ratio = std::min(best_ratio, ratio);
-        if (worse >= 2) {
+        if (worse >= 2 && ctl->batch <= 0 && batch > 64) {
           batch = std::max<int64_t>(64, batch / 2);
           worse = 0;
           best_ratio = ratio;

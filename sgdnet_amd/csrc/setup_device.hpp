@@ -40,6 +40,7 @@ int solver_create_adopting(const sgdnet_problem* pb, DeviceSetup& S, sgdnet_solv
 // solver.cpp: sample-order pipeline of the fit driver (the next epoch's draws are generated on a
 // side stream while the current epoch runs)
 int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators = 1);
+int solver_reset_state(sgdnet_solver* s, const double* b0);
 int solver_rng_prefetch(sgdnet_solver* s);
 int solver_rng_acquire(sgdnet_solver* s, int64_t* offset);
 int solver_rng_release(sgdnet_solver* s);

@@ -830,6 +830,23 @@ int sgdnet_solver_generate_stream(sgdnet_solver* s, sgdnet_rng* rng, int64_t cou
 
 }  // extern "C"
 
+// w = g_sum = g_memory = g_sum_intercept = 0, intercept = b0 (K values): the state a fit starts
+// from (driver.cpp restarts a lambda from here when the automatic staleness window diverged)
+int solver_reset_state(sgdnet_solver* s, const double* b0) {
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  const SagaDev& d = s->d;
+  const size_t K = (size_t)d.K;
+  SGD_HIP_TRY(hipMemsetAsync(d.w, 0, sizeof(double) * K * (size_t)d.p, s->st));
+  SGD_HIP_TRY(hipMemsetAsync(d.G, 0, sizeof(double) * K * (size_t)d.p, s->st));
+  SGD_HIP_TRY(hipMemsetAsync(d.M, 0, sizeof(double) * K * (size_t)d.n, s->st));
+  SGD_HIP_TRY(hipMemsetAsync(d.gb, 0, sizeof(double) * K, s->st));
+  SGD_HIP_TRY(hipMemcpyAsync(d.b, b0, sizeof(double) * K, hipMemcpyHostToDevice, s->st));
+  SGD_HIP_TRY(hipMemsetAsync(d.lag, 0, sizeof(unsigned) * (size_t)d.p, s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  s->w_prev_valid = false;
+  return SGDNET_OK;
+}
+
 // ---- sample-order pipeline (driver.cpp) -------------------------------------------------------
 // The stream buffer holds two epochs; epoch e reads half e & 1 while the side stream fills the
 // other half with the draws of epoch e + 1.  The generator state ping-pongs between two device

@@ -171,3 +171,25 @@ def test_device_score_with_many_lambdas_and_classes_is_chunked(sa):
     dev = sa.score(fit, X, y, "deviance", s=s, device=0)
     assert np.allclose(host, dev, rtol=1e-10)
     assert np.allclose(sa.predict(fit, X, s=s), sa.predict(fit, X, s=s, device=0), rtol=1e-11, atol=1e-12)
+
+
+def test_small_correlated_data_in_batched_mode(sa):
+    # abalone (4177 x 9, strongly collinear columns): the automatic mode must neither diverge nor
+    # use virtual shards here, and a run forced onto shards recovers by restarting without them
+    import os as _os
+    ab = np.load(os.path.join(GOLD, "abalone.npz"))
+    x, y = ab["x"], ab["y"]
+    ref = sa.sgdnet(x, y, lambda_=[0.01], thresh=1e-9, maxit=20000, seed=1)
+    for forced in (None, "2", "4"):
+        if forced is None:
+            _os.environ.pop("SGDNET_VSHARDS", None)
+        else:
+            _os.environ["SGDNET_VSHARDS"] = forced
+        try:
+            fit = sa.sgdnet(x, y, lambda_=[0.01], thresh=1e-9, maxit=20000, seed=1, mode="batched")
+        finally:
+            _os.environ.pop("SGDNET_VSHARDS", None)
+        assert fit.return_codes[0] == 0 and np.all(np.isfinite(fit.beta))
+        assert np.abs(fit.beta - ref.beta).max() < 1e-5 * max(1.0, np.abs(ref.beta).max())
+    path = sa.sgdnet(x, y, mode="auto", seed=1)
+    assert len(path.lambda_) == 100 and np.all(np.isfinite(path.beta)) and np.all(path.return_codes == 0)
