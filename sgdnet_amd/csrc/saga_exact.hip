@@ -339,10 +339,21 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
   const int64_t KP = (int64_t)K * p;
   const bool lds_only = ctl.use_lds != 0;
 
-  // LDS carve: [slp K][sgc K][xs p][w KP][G KP]
+  // LDS carve: [slp K][sgc K][sb K][sgb K][sy Ky][xs p][w KP][G KP]
+  // (intercept and g_sum_intercept live in LDS for the whole launch and the next sample's
+  // response and gradient memory are requested one iteration ahead, as in the sparse kernel:
+  // with them in global memory every iteration was a chain of three dependent round trips)
   double* slp = reinterpret_cast<double*>(smem);
   double* sgc = slp + K;
-  double* xs = sgc + K;
+  double* sb = sgc + K;
+  double* sgb = sb + K;
+  double* sy = sgb + K;
+  double* xs = sy + d.Ky;
+  const bool small_k = K <= kWave && d.Ky <= kWave;       // lane k owns class k in the prefetch
+  for (int k = lane; k < K; k += kWave) {
+    sb[k] = d.b[k];
+    sgb[k] = d.gb[k];
+  }
   double* w = d.w;
   double* G = d.G;
   if (ctl.use_lds) {
@@ -369,12 +380,17 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
   // software prefetch of the next sample's row (the stream is known in advance)
   constexpr int kPf = 4;
   double xn[kPf];
+  double yn = 0.0, mn = 0.0;
   {
     const uint32_t s0 = d.stream[t];
 #pragma unroll
     for (int c = 0; c < kPf; ++c) {
       const int64_t j = lane + (int64_t)c * kWave;
       xn[c] = j < p ? d.xd[(int64_t)s0 * p + j] : 0.0;
+    }
+    if (small_k) {
+      yn = lane < d.Ky ? d.y[(int64_t)s0 * d.Ky + lane] : 0.0;
+      mn = lane < K ? d.M[lane + (int64_t)s0 * K] : 0.0;
     }
   }
   const int64_t t_end = ctl.stream_off + (int64_t)ctl.max_epochs * nit;
@@ -387,12 +403,20 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
         if (j < p) xs[j] = xn[c];
       }
       for (int64_t j = lane + (int64_t)kPf * kWave; j < p; j += kWave) xs[j] = d.xd[(int64_t)s * p + j];
-      if (t + 1 < t_end) {
-        const uint32_t s1 = d.stream[t + 1];
+      const double m_cur = mn;
+      if (small_k && lane < d.Ky) sy[lane] = yn;
+      const bool has_next = t + 1 < t_end;
+      uint32_t s1 = s;
+      if (has_next) {
+        s1 = d.stream[t + 1];
 #pragma unroll
         for (int c = 0; c < kPf; ++c) {
           const int64_t j = lane + (int64_t)c * kWave;
           xn[c] = j < p ? d.xd[(int64_t)s1 * p + j] : 0.0;
+        }
+        if (small_k) {
+          yn = lane < d.Ky ? d.y[(int64_t)s1 * d.Ky + lane] : 0.0;
+          mn = lane < K ? d.M[lane + (int64_t)s1 * K] : 0.0;     // stale if s1 == s: replaced below
         }
       }
       wave_sync(lds_only);
@@ -400,15 +424,16 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
       for (int k = lane; k < K; k += kWave) {                        // :154
         double acc = 0.0;
         for (int64_t j = 0; j < p; ++j) acc += w[k + j * K] * xs[j];
-        slp[k] = acc * wscale + d.b[k];
+        slp[k] = acc * wscale + sb[k];
       }
       wave_sync(lds_only);
 
       for (int k = lane; k < K; k += kWave) {                        // :156-159
-        const double g = family_gradient_k(d.family, K, k, slp, d.y + (int64_t)s * d.Ky);
+        const double g = family_gradient_k(d.family, K, k, slp, small_k ? sy : d.y + (int64_t)s * d.Ky);
         const int64_t mi = k + (int64_t)s * K;
-        sgc[k] = g - d.M[mi];
+        sgc[k] = g - (small_k ? m_cur : d.M[mi]);
         d.M[mi] = g;
+        if (small_k && has_next && s1 == s) mn = g;                  // k == lane here
       }
 
       if (wscale < kSmall) {                                         // :162-166
@@ -421,9 +446,9 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
       if (d.fit_intercept) {                                         // :170-173
         for (int k = lane; k < K; k += kWave) {
           const double gck = sgc[k] / n_d;
-          const double gbk = d.gb[k] + gck;
-          d.gb[k] = gbk;
-          d.b[k] -= gamma * (gbk + gck);
+          const double gbk = sgb[k] + gck;
+          sgb[k] = gbk;
+          sb[k] -= gamma * (gbk + gck);
         }
       }
 
@@ -456,6 +481,10 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
       d.G[i] = G[i];
     }
   }
+  for (int k = lane; k < K; k += kWave) {
+    d.b[k] = sb[k];
+    d.gb[k] = sgb[k];
+  }
   if (lane == 0) {
     ctl.out[0] = (int)it_outer;
     ctl.out[1] = converged;
@@ -469,7 +498,7 @@ size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state) {
 }
 
 size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state) {
-  size_t b = sizeof(double) * (2 * (size_t)d.K + (size_t)d.p);
+  size_t b = sizeof(double) * (4 * (size_t)d.K + (size_t)d.Ky + (size_t)d.p);
   if (stage_state) b += sizeof(double) * 2 * (size_t)d.K * (size_t)d.p;
   return (b + 15) & ~size_t(15);
 }
