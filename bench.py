@@ -18,6 +18,11 @@ grows ("strong" scaling).  --merge selects the exchange (sgdnet_amd/parallel.py)
         all-reduced before the sweep: exactly the single-GPU iterates, one collective per
         batch, no speed-up (reported as `alt_merge` when avg is the headline, and vice versa).
 
+Inside every GPU the same averaging runs over up to 8 *virtual* shards (replicas over sample
+ranges, one launch per batch of all shards, merged on the device; --vshards): the
+per-GPU count follows the library's rule (every shard keeps 100 samples per feature), so the job
+is an 8-way average at C4 for every N, and `convergence` reports its epochs to tolerance.
+
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel
 (the batched gather kernel) by the algorithmic bytes of SURVEY.md 8d divided by
 its average dispatch duration (HIP events bound to every launch); `cpu_baseline` times the CPU
