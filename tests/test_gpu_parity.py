@@ -403,6 +403,51 @@ def test_full_size_invariants(sa, workload):
     S2.close()
 
 
+@pytest.mark.parametrize("workload,V", [("C3", 4), ("C4", 8)])
+def test_full_size_invariants_with_virtual_shards(sa, workload, V):
+    # the bench.py configuration (compact records, 8-lane gather, virtual shards, automatic
+    # window) at BASELINE's full sizes: the merged state satisfies the same invariants
+    from sgdnet_amd import data as D
+    n, p, dens, seed = {"C3": (1_000_000, 1_000, 0.01, 3), "C4": (10_000_000, 10_000, 0.001, 4)}[workload]
+    pr = D.make_sparse_glm(n, p, dens, family="binomial", seed=seed)
+    X = D.as_scipy(pr)
+    epochs = 2
+    row_sq = np.add.reduceat(pr["val"] ** 2, pr["ptr"][:-1])
+    col_sq = np.bincount(pr["idx"], weights=pr["val"] ** 2, minlength=p)
+    a_l2 = b_l1 = 0.5 / n
+    gamma = D.step_size(row_sq.max(), a_l2, True, "binomial", n)
+    batch = sa.auto_batch(float(row_sq.max()), float(col_sq.max()) / n)
+    draws = V * (n // V)
+
+    def run():
+        S = sa.SagaSolver(X, pr["y"], family="binomial", n_classes=1)
+        S.set_penalty("elasticnet", gamma, a_l2, b_l1)
+        S.set_virtual_shards(V)
+        stream = S.sharded_stream([sa.RRng(seed + v) for v in range(V)], epochs)
+        S.upload_stream(stream)
+        dev0 = S.deviance()
+        S.enqueue_epochs(epochs, batch=batch, draws_per_epoch=draws)
+        S.sync()
+        return S, stream, dev0
+
+    S, stream, dev0 = run()
+    err_g, err_gb = _gradient_average_invariant(S, X, n)
+    assert err_g < 1e-9 and err_gb < 1e-12
+    M = S.get("g_memory")[0]
+    touched = np.zeros(n, dtype=bool)
+    touched[stream[:epochs * draws]] = True
+    assert np.all(M[~touched] == 0.0) and np.all(np.abs(M) < 1.0)
+    assert np.count_nonzero(M) == np.count_nonzero(touched)
+    assert S.deviance() < dev0
+    w1 = S.get("w")
+    S.set_virtual_shards(0)
+    S.close()
+    S2, _, _ = run()                                              # reproducible to rounding
+    assert relerr(S2.get("w"), w1) < 1e-9
+    S2.set_virtual_shards(0)
+    S2.close()
+
+
 @pytest.mark.parametrize("family,K,penalty", [("binomial", 1, "elasticnet"), ("multinomial", 3, "elasticnet"),
                                               ("mgaussian", 2, "grouplasso"), ("multinomial", 10, "ridge")])
 def test_lds_privatised_gather_matches_batched_oracle(sa, oracle, family, K, penalty):
