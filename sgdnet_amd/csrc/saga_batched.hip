@@ -930,16 +930,13 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   if (d.standardize) cw_clear_next(d, batch_id);
   constexpr int kGroups = kLdsBlock / kGroup;
   if (KMAX == 1) {
-    // Two half-passes of U draws per group, software-pipelined: a wave's loads and returning
-    // atomics come back in issue order, so the order below keeps the second half's records
-    // and the first half's exchanges in flight together (chip-wide, every phase of this
-    // kernel is a burst on one resource -- HBM for the records, the memory-side atomic units
-    // for the exchange -- and the bursts of the two halves now overlap instead of queueing):
-    //   load A, load B | gradient A (+exchange A) | gradient B (+exchange B) | scatter A | scatter B
-#ifndef SGDNET_PIPE
-#define SGDNET_PIPE 4
-#endif
-    constexpr int U = SGDNET_PIPE;
+    // K == 1.  8-lane form (both tables in LDS): compact records when the problem has them.
+    // 16-lane form: one pass of U = 4 draws per group; the sample ids of the NEXT pass are
+    // requested before this pass's records are waited for (a pass is a chain of dependent round
+    // trips, ids -> records -> gradient-memory exchange, and this takes the first one off it).
+    // (Two software-pipelined half-passes of 2 draws were 2 us slower once the gradient was
+    // evaluated once per pass; records one pass ahead as well: DESIGN.md 5, item 9.)
+    constexpr int U = 4;
     const double* wv = kWLds ? Dl + KP + (KP & 1) : d.w;
     const uint32_t* sp = d.stream + t0;
     if constexpr (kLanes == kLanes8) {
@@ -947,16 +944,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
         gct[0] = k1_lanes8_compact(d, sp, m, vblk, kVS ? d.v_bps : (int)gridDim.x, bk[0], wv, Dl);
       else
         gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
-    } else {
-#ifndef SGDNET_TWO_HALVES
-    // one pass of U draws per group (two software-pipelined half-passes of U/2 measured 2 us
-    // slower once the gradient was evaluated once per pass: the kernel is bound by the vector
-    // instructions it issues as much as by the memory system)
-#ifndef SGDNET_NO_IDS_AHEAD
-    // the sample ids of the NEXT pass are requested before this pass's records are waited for:
-    // a pass is a chain of dependent round trips (ids -> records -> gradient-memory exchange)
-    // and this takes the first one off it
-    if (lo + group < hi) {
+    } else if (lo + group < hi) {
       K1Draws<U> A;
       A.load_ids(d, sp, lo + group, hi, kGroups, gl, lo + group);
       for (int i = lo + group; i < hi; i += kGroups * U) {
@@ -969,26 +957,6 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
         gct[0] += A.scatter(d, gl, Dl);
         if (N.valid_any) A.take_ids(N);
       }
-    }
-#else
-    for (int i = lo + group; i < hi; i += kGroups * U) {
-      K1Draws<U> A;
-      A.load(d, sp, i, hi, kGroups, gl, i);
-      A.gradient(d, gl, bk[0], wv);
-      gct[0] += A.scatter(d, gl, Dl);
-    }
-#endif
-#else
-    for (int i = lo + group; i < hi; i += 2 * kGroups * U) {
-      K1Draws<U> A, B;
-      A.load(d, sp, i, hi, kGroups, gl, i);
-      B.load(d, sp, i + kGroups * U, hi, kGroups, gl, i);
-      A.gradient(d, gl, bk[0], wv);
-      B.gradient(d, gl, bk[0], wv);
-      gct[0] += A.scatter(d, gl, Dl);
-      gct[0] += B.scatter(d, gl, Dl);
-    }
-#endif
     }
   } else {
     for (int i = lo + group; i < hi; i += kGroups) {
