@@ -638,15 +638,19 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
     }
   }
   if (s->sparse && compact_eligible(d)) {
+    // an optimisation, not a requirement: without the memory for the planes the K = 1 gather
+    // reads the 256-B records
     char *cP = nullptr, *cQ = nullptr;
     uint32_t* lm = nullptr;
-    TRY(dev_alloc(s, &cP, (n + 1) * 128, false));
-    TRY(dev_alloc(s, &cQ, (n + 1) * 128, false));
-    TRY(dev_alloc(s, &lm, (n + 31) / 32 + 1, false));
-    TRY(launch_pack_compact(d, cP, cQ, lm, s->st));
-    d.cP = cP;
-    d.cQ = cQ;
-    d.clong = lm;
+    if (dev_alloc(s, &cP, (n + 1) * 128, false) == SGDNET_OK && dev_alloc(s, &cQ, (n + 1) * 128, false) == SGDNET_OK &&
+        dev_alloc(s, &lm, (n + 31) / 32 + 1, false) == SGDNET_OK) {
+      TRY(launch_pack_compact(d, cP, cQ, lm, s->st));
+      d.cP = cP;
+      d.cQ = cQ;
+      d.clong = lm;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   TRY(dev_alloc(s, &d.w, K * p, true));
   TRY(dev_alloc(s, &d.G, K * p, true));
