@@ -554,32 +554,42 @@ __device__ __forceinline__ void row_tail_compact(const SagaDev& d, uint32_t sid,
 #endif
 constexpr int kLdsBlock = SGDNET_LDS_BLOCK;
 
-// Work distribution: a wavefront works through tickets of 32 consecutive draws (one pass:
-// 8 groups x 4 draws, one 128-B line of the sample stream); ticket t of wave w in workgroup b
-// is the fixed position ((b * T + t) * 16 + w) * 32.
-// Tried and removed: handing the last 6-20 % of a launch out dynamically from a per-shard
-// counter, because the slowest workgroup of a launch needs ~20 % longer than the mean (CUs see
-// different memory latencies, differently in every launch).  The tickets serialise on one L2
-// atomic unit (5-10 ns each): C4 with 8 shards 1256 -> 1141..1186 epochs/s, with 4 shards
-// 1016 -> 729; all tickets from the counter: 160 us per 131 072-draw launch.
+// Work distribution: a ticket is 32 consecutive draws (one wavefront pass: 8 groups x 4 draws,
+// one 128-B line of the sample stream).  A workgroup owns a fixed range of the launch, and its
+// 16 wavefronts draw tickets of that range from a counter in LDS: identical shares per
+// wavefront left the workgroup waiting for its slowest wavefront (per-pass times vary by tens of
+// per cent with the memory system's queues), and a workgroup's time is then the MAXIMUM of 16
+// sums of 8 passes instead of their mean.  The LDS counter costs one ds_add_rtn per pass; it is
+// used from 4 passes per wavefront (C4 with 8 shards: 0.83 -> 0.79..0.81 ms/epoch, with one shard
+// and a single pass per wavefront it only adds latency: 2.08 -> 2.22).
+// Tried and removed: handing the last 6-20 % of a launch out ACROSS workgroups from a per-shard
+// counter in global memory.  Those tickets serialise on one L2 atomic unit (5-10 ns each) and
+// every wavefront reserves three ahead: C4 with 8 shards 1256 -> 1141..1186 epochs/s, with 4
+// shards 1016 -> 729; all tickets from a global counter: 160 us per 131 072-draw launch.
 constexpr int kTicket = 32;           // draws per wavefront pass
 
 struct TicketSource {
-  int t, T;            // next ticket, number of tickets
-  int fixed_base;      // position of this wavefront's ticket 0
-  int m;
+  int* counter;        // LDS, zeroed before the workgroup's barrier
+  int lo, hi, m;       // the workgroup's range; m: end of the launch (sentinel)
+  int t = 0;
+  bool dynamic;
   __device__ __forceinline__ int next() {
-    const int b = t < T ? fixed_base + t * (kLdsBlock / 64) * kTicket : m;
-    ++t;
-    return b < m ? b : m;
+    if (!dynamic) {                             // a pass or two per wavefront: nothing to balance
+      const int b = lo + (t++ * (kLdsBlock / 64) + (int)(threadIdx.x >> 6)) * kTicket;
+      return b < hi ? b : m;
+    }
+    int b = 0;
+    if ((threadIdx.x & 63) == 0)
+      b = __hip_atomic_fetch_add(counter, kTicket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    b = lo + __builtin_amdgcn_readfirstlane(b);
+    return b < hi ? b : m;
   }
 };
 
 __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint32_t* sp, int m, int blk, int nblk,
-                                                    double b0, const double* wv, double* Dl) {
+                                                    int* ticket_counter, double b0, const double* wv, double* Dl) {
   typedef double dpair_t __attribute__((ext_vector_type(2)));
   constexpr int U = 4;
-  constexpr int kWgPass = (kLdsBlock / 64) * kTicket;   // draws of one pass of a whole workgroup
   const int gl = threadIdx.x & (kLanes8 - 1);
   const int g = (threadIdx.x & 63) >> 3;        // group inside the wavefront
   const int q = gl >> 1;
@@ -591,10 +601,12 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
   double gct = 0.0;
   TicketSource tk;
   {
-    tk.T = (m + nblk * kWgPass - 1) / (nblk * kWgPass);
-    tk.t = 0;
-    tk.fixed_base = blk * tk.T * kWgPass + (int)(threadIdx.x >> 6) * kTicket;
+    const int share = ((m + nblk - 1) / nblk + kTicket - 1) / kTicket * kTicket;
+    tk.counter = ticket_counter;
+    tk.lo = blk * share;
+    tk.hi = tk.lo + share < m ? tk.lo + share : m;
     tk.m = m;
+    tk.dynamic = share >= 4 * (kLdsBlock / 64) * kTicket;
   }
   // this lane's own draw of the pass whose ticket is `base` (positions past the end stand in with
   // the ticket's first draw and are discarded)
@@ -875,6 +887,8 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   const int K = KMAX == 1 ? 1 : d.K;
   const int64_t KP = (int64_t)K * d.p;
+  __shared__ int ticket_counter;             // work tickets of the compact K == 1 form
+  if (threadIdx.x == 0) ticket_counter = 0;
   const int vsh = kVS ? (int)blockIdx.x / d.v_bps : 0;          // this workgroup's shard
   const int vblk = kVS ? (int)blockIdx.x - vsh * d.v_bps : (int)blockIdx.x;
   const double* w_src = kVS ? d.vw + (int64_t)vsh * KP : d.w;
@@ -941,7 +955,8 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     const uint32_t* sp = d.stream + t0;
     if constexpr (kLanes == kLanes8) {
       if (d.cP)
-        gct[0] = k1_lanes8_compact(d, sp, m, vblk, kVS ? d.v_bps : (int)gridDim.x, bk[0], wv, Dl);
+        gct[0] = k1_lanes8_compact(d, sp, m, vblk, kVS ? d.v_bps : (int)gridDim.x, &ticket_counter, bk[0], wv,
+                                   Dl);
       else
         gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
     } else if (lo + group < hi) {
