@@ -1143,6 +1143,8 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
     if (getenv("SGDNET_PHASE_DUMP")) {
       fprintf(stderr, "[phase-dump] draw loop us by workgroup:");
       for (int b = 0; b < 256; ++b) fprintf(stderr, " %.1f", (double)(t[b * 16 + 2] - t[b * 16 + 1]) / 100.0);
+      fprintf(stderr, "\n[phase-dump] draw loop + barrier us by workgroup:");
+      for (int b = 0; b < 256; ++b) fprintf(stderr, " %.1f", (double)(t[b * 16 + 3] - t[b * 16 + 1]) / 100.0);
       fprintf(stderr, "\n[phase-dump] start offset us by workgroup:");
       for (int b = 0; b < 256; ++b) fprintf(stderr, " %.1f", (double)(t[b * 16 + 1] - first) / 100.0);
       fprintf(stderr, "\n");
