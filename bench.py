@@ -293,7 +293,11 @@ def main():
             "sweep_avg_launch_us": 1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]),
             # other ceilings for this access pattern (GB/s): the guide's measured float4 copy, and
             # random 256-B records streamed by scripts/microbench/gather_rate (profiles/)
-            "ceilings": {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0},
+            # ... and one returning device-scope exchange per draw on the gradient memory: the
+            # memory-side atomic units sustain 21.7 G/s alone (profiles/r01_microbench.txt), i.e.
+            # 21.7e9 x bytes-per-draw with nothing else on the fabric
+            "ceilings": {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0,
+                         "one_returning_exchange_per_draw": 21.72 * alg_bytes_epoch / max(1, n_local)},
         },
     }
 
