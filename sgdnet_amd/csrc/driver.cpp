@@ -265,6 +265,39 @@ int64_t auto_batch(const Features& X, double max_sample_sqnorm) {
     }
     diag = std::max(diag, s / (double)X.n);
   }
+  // The diagonal only bounds the largest eigenvalue of X'X/n from below; strongly collinear
+  // columns (abalone: 8 size measurements of one animal) have an L_F several times their
+  // diagonal and the window comes out that many times too long.  For small dense x the Gram
+  // matrix is cheap: power iteration gives the eigenvalue itself.
+  if (!X.sparse && (double)X.n * (double)X.p * (double)X.p <= 2e8 && X.p > 1) {
+    const size_t p = (size_t)X.p, n = (size_t)X.n;
+    std::vector<double> G(p * p, 0.0), v(p, 1.0), u(p);
+    for (size_t j = 0; j < p; ++j)
+      for (size_t k = 0; k <= j; ++k) {
+        const double *a = X.xd.data() + j * n, *b = X.xd.data() + k * n;
+        double s = 0.0;
+        for (size_t i = 0; i < n; ++i) s += a[i] * b[i];
+        G[j * p + k] = G[k * p + j] = s / (double)n;
+      }
+    double lmax = 0.0;
+    for (int it = 0; it < 200; ++it) {
+      double nu = 0.0;
+      for (size_t j = 0; j < p; ++j) {
+        double s = 0.0;
+        for (size_t k = 0; k < p; ++k) s += G[j * p + k] * v[k];
+        u[j] = s;
+        nu += s * s;
+      }
+      nu = std::sqrt(nu);
+      if (!(nu > 0.0)) break;
+      const double prev = lmax;
+      lmax = nu;                                   // |G v| with |v| = 1
+      for (size_t j = 0; j < p; ++j) v[j] = u[j] / nu;
+      if (it > 5 && std::fabs(lmax - prev) <= 1e-6 * lmax) break;
+      if (it == 0) lmax = 0.0;                     // v was not normalised yet
+    }
+    diag = std::max(diag, lmax);
+  }
   return sgdnet_auto_batch(max_sample_sqnorm, diag);
 }
 
@@ -480,13 +513,13 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     ~PipeGuard() { if (on) (void)solver_rng_close(s, rng); }
   } pipe_guard{S, &draws.rng, false};
   if (pipe) {
-    // batched mode with epochs of a million draws or more: 8 generators side by side (one makes
+    // batched mode with epochs of 200 000 draws or more: 8 generators side by side (one makes
     // 10M draws in 5.3 ms, six epochs of the batched kernels at C4).  Smaller problems and exact
     // mode keep the single R stream.  SGDNET_RNG_GENERATORS overrides.
     int gens = 1;
     if (mode == SGDNET_MODE_BATCHED) {
       const char* e = getenv("SGDNET_RNG_GENERATORS");
-      gens = e ? atoi(e) : (n >= (1 << 20) ? 8 : 1);
+      gens = e ? atoi(e) : (n >= 200000 ? 8 : 1);
     }
     rc = solver_rng_open(S, &draws.rng, n, gens);
     if (rc) return rc;
@@ -498,6 +531,12 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   std::vector<double> w((size_t)(K * p)), b((size_t)K), xbb((size_t)K);
   std::vector<double> losses(ctl->debug ? (size_t)ctl->max_iter : 0);
   double n_iter = 0.0;
+  int64_t auto_window = batch;
+  double t_rng = 0.0, t_run = 0.0, t_chk = 0.0, t_dev = 0.0;   // SGDNET_TRACE: where the path's time goes
+  auto now = [] { return std::chrono::steady_clock::now(); };
+  auto since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double>(now() - t0).count();
+  };      // shrinks for good only when a run really blew up
 
   for (int li = 0; li < n_lambda; ++li) {                                        // sgdnet.cpp:217-273
     // StepSize: utils.h:31-51
@@ -509,12 +548,15 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
     unsigned epochs = 0;
     int converged = 0;
+    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0) batch = auto_window;   // a new lambda: a new step size
+    if (li == 0 && getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet]   window %lld draws\n", (long long)batch);
     double best_ratio = HUGE_VAL;
     int worse = 0;
     // one epoch per launch: exactly the draws the reference would consume are taken
     // from the source (R's RNG state after the call matches, SURVEY.md 8b "RNG")
     while (epochs < ctl->max_iter && !converged) {
       int64_t stream_off = 0;
+      auto t0 = now();
       if (pipe) {
         rc = solver_rng_prefetch(S);               // next epoch's draws, concurrently
         if (rc) return rc;
@@ -526,6 +568,8 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
         rc = sgdnet_solver_upload_stream(S, chunk.data(), n);
       }
       if (rc) return rc;
+      t_rng += since(t0);
+      t0 = now();
       unsigned ran = 0;
       rc = sgdnet_solver_run(S, mode, batch, stream_off, n, 1, ctl->tol, &ran, &converged,
                              ctl->debug ? losses.data() + epochs : nullptr);
@@ -534,6 +578,8 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
         rc = solver_rng_release(S);
         if (rc) return rc;
       }
+      t_run += since(t0);
+      t0 = now();
       epochs += ran;
       if (mode == SGDNET_MODE_BATCHED) {
         // guard of the automatic window: the stale-sum step is only stable below ~L_max/L_F
@@ -562,6 +608,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
             rc = sgdnet_solver_set_virtual_shards(S, 0);
           } else if (batch > 64) {
             batch = std::max<int64_t>(64, batch / 4);
+            auto_window = batch;
           } else {
             set_error("batched mode diverged (non-finite coefficients) at the smallest window; use mode = exact");
             return SGDNET_EUNSUPPORTED;
@@ -573,16 +620,29 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
           converged = 0;
           continue;
         }
-        if (ratio > 4.0 * best_ratio) ++worse; else worse = 0;
+        // a run on its way out changes the coefficients by a growing, LARGE fraction of their size
+        // per epoch; near convergence the ratio is noise around the tolerance and means nothing
+        // (without the second condition a 100-lambda path halved its way down to 64 draws)
+        // ... and at lambda_max, where the solution is exactly 0, max|w| is rounding noise and the
+        // ratio means nothing either (a C3 path spent 54 epochs there halving down to 78 draws)
+        if (ratio > 4.0 * best_ratio && ratio > 0.05 && sz > 1e-9 && epochs > 2) ++worse; else worse = 0;
         best_ratio = std::min(best_ratio, ratio);
         if (worse >= 2 && ctl->batch <= 0 && batch > 64) {
+          if (getenv("SGDNET_TRACE"))
+            fprintf(stderr, "[sgdnet]   lambda %d epoch %u: change ratio %.3g after best %.3g -> window %lld halved\n", li,
+                    epochs, ratio, best_ratio, (long long)batch);
           batch = std::max<int64_t>(64, batch / 2);
+          // what made the window too long (correlated features) does not depend on lambda: keep
+          // it -- except at lambda_max, where a handful of coefficients flicker around zero
+          if (li > 0) auto_window = batch;
           worse = 0;
           best_ratio = ratio;
         }
       }
+      t_chk += since(t0);
     }
     n_iter += (double)epochs;
+    auto t1 = now();
     out->return_codes[li] = (epochs == ctl->max_iter) ? 1.0 : 0.0;               // saga-sparse.h:376-382
     if (ctl->debug) {
       memcpy(out->losses + (size_t)li * ctl->max_iter, losses.data(), sizeof(double) * epochs);
@@ -612,7 +672,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     for (int k = 0; k < K; ++k)
       ao[k] = fit_intercept ? b[(size_t)k] * y_scale[(size_t)k] + y_center[(size_t)k] - xbb[(size_t)k]
                             : b[(size_t)k];
+    t_dev += since(t1);
   }
+  if (getenv("SGDNET_TRACE"))
+    fprintf(stderr, "[sgdnet]   of which: sample order %.3f s, epochs %.3f s, per-epoch checks %.3f s, per-lambda deviance + rescale %.3f s\n",
+            t_rng, t_run, t_chk, t_dev);
   pt.mark("lambda path (SAGA + deviance)");
   out->npasses = n_iter;
   out->draws_used = draws.pos;

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "common.hpp"
@@ -94,6 +95,10 @@ struct sgdnet_solver {
 };
 
 namespace {
+// SGDNET_TRACE: host-side split of a batched epoch (development aid)
+double g_trace_launch = 0.0, g_trace_conv = 0.0, g_trace_graph = 0.0;
+long g_trace_epochs = 0;
+
 
 template <typename T>
 int dev_alloc(sgdnet_solver* s, T** out, size_t count, bool zero) {
@@ -694,6 +699,13 @@ int sgdnet_solver_create(const sgdnet_problem* pb, sgdnet_solver** out) {
 
 void sgdnet_solver_destroy(sgdnet_solver* s) {
   if (!s) return;
+  if (getenv("SGDNET_TRACE") && g_trace_epochs) {
+    fprintf(stderr, "[sgdnet]   batched epochs %ld: graph launch calls %.3f s, waiting for the epoch + ConvergenceCheck %.3f s, epoch graphs on the device %.3f s\n",
+            g_trace_epochs, g_trace_launch, g_trace_conv, g_trace_graph);
+    g_trace_graph = 0.0;
+    g_trace_epochs = 0;
+    g_trace_launch = g_trace_conv = 0.0;
+  }
   (void)hipSetDevice(s->device);
   if (s->st) (void)hipStreamSynchronize(s->st);
   drop_graph(s);
@@ -1028,7 +1040,17 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     while (done < max_epochs && !converged) {
       rc = check_stream(s, s->lam.stream_base, draws_per_epoch);
       if (rc) return rc;
+      const auto tl0 = std::chrono::steady_clock::now();
+      static hipEvent_t tev0 = nullptr, tev1 = nullptr;
+      const bool tr = getenv("SGDNET_TRACE") != nullptr;
+      if (tr && !tev0) {
+        (void)hipEventCreate(&tev0);
+        (void)hipEventCreate(&tev1);
+      }
+      if (tr) (void)hipEventRecord(tev0, s->st);
       SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
+      if (tr) (void)hipEventRecord(tev1, s->st);
+      g_trace_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
       s->lam.stream_base += draws_per_epoch;  // mirrors saga_epoch_end_kernel
       s->lam.batch_seq += nb;
       if (losses) {
@@ -1037,8 +1059,15 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         if (rc) return rc;
         losses[done] = sum / (double)s->d.n;
       }
+      const auto tc0 = std::chrono::steady_clock::now();
       rc = device_convergence(s, tol, &converged);
       if (rc) return rc;
+      g_trace_conv += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
+      if (tr) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, tev0, tev1) == hipSuccess) g_trace_graph += ms * 1e-3;
+      }
+      ++g_trace_epochs;
       ++done;
     }
     s->w_prev_valid = true;
