@@ -625,8 +625,10 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
         // (without the second condition a 100-lambda path halved its way down to 64 draws)
         // ... and at lambda_max, where the solution is exactly 0, max|w| is rounding noise and the
         // ratio means nothing either (a C3 path spent 54 epochs there halving down to 78 draws)
-        if (ratio > 4.0 * best_ratio && ratio > 0.05 && sz > 1e-9 && epochs > 2) ++worse; else worse = 0;
-        best_ratio = std::min(best_ratio, ratio);
+        const bool at_lambda_max = li == 0 && ctl->n_lambda_user == 0;   // solution exactly 0: no signal
+        if (ratio > 4.0 * best_ratio && ratio > 0.05 && sz > 1e-9 && epochs > 2 && !at_lambda_max) ++worse;
+        else worse = 0;
+        if (ratio > 0.0) best_ratio = std::min(best_ratio, ratio);
         if (worse >= 2 && ctl->batch <= 0 && batch > 64) {
           if (getenv("SGDNET_TRACE"))
             fprintf(stderr, "[sgdnet]   lambda %d epoch %u: change ratio %.3g after best %.3g -> window %lld halved\n", li,
