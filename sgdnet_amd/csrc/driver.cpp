@@ -396,6 +396,15 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     static const int align = [] { const char* e = getenv("SGDNET_REC_ALIGN"); return e ? atoi(e) : 128; }();
     int rcd = device_setup_finish(*X.dev, yt.data(), Ky, ctl->standardize ? 1 : 0, align, X.st, &norm_max);
     if (rcd) return rcd;
+    if (ctl->mode != SGDNET_MODE_EXACT && ctl->batch <= 0 && !getenv("SGDNET_NO_LMAX")) {   // the automatic window needs L_F itself
+      double lmax = 0.0;
+      rcd = device_gram_lmax(*X.dev, ctl->standardize ? 1 : 0, X.st, &lmax);
+      if (rcd) return rcd;
+      if (getenv("SGDNET_TRACE"))
+        fprintf(stderr, "[sgdnet]   L_F: largest eigenvalue of X'X/n %.4g, its diagonal bound %.4g\n", lmax,
+                X.dev_max_mean_sq);
+      X.dev_max_mean_sq = std::max(X.dev_max_mean_sq, lmax);
+    }
   } else if (X.sparse) {    double csq = 0.0;
     if (ctl->standardize)
       for (int64_t j = 0; j < p; ++j) csq += X.x_center_scaled[(size_t)j] * X.x_center_scaled[(size_t)j];
@@ -531,12 +540,14 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   std::vector<double> w((size_t)(K * p)), b((size_t)K), xbb((size_t)K);
   std::vector<double> losses(ctl->debug ? (size_t)ctl->max_iter : 0);
   double n_iter = 0.0;
-  int64_t auto_window = batch;
+  int64_t auto_window = batch;      // shrinks for good when a run blew up or a fit got worse
+  double prev_dev = HUGE_VAL;
+  int retries = 0;
   double t_rng = 0.0, t_run = 0.0, t_chk = 0.0, t_dev = 0.0;   // SGDNET_TRACE: where the path's time goes
   auto now = [] { return std::chrono::steady_clock::now(); };
   auto since = [&](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double>(now() - t0).count();
-  };      // shrinks for good only when a run really blew up
+  };
 
   for (int li = 0; li < n_lambda; ++li) {                                        // sgdnet.cpp:217-273
     // StepSize: utils.h:31-51
@@ -654,6 +665,30 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     double dev = 0.0;
     rc = sgdnet_solver_deviance(S, &dev);                                        // sgdnet.cpp:246-256
     if (rc) return rc;
+    // Safety net of the automatic window: along a decreasing lambda path the deviance of the
+    // training data can only fall.  A window that is too long for the data does not have to blow
+    // up -- it can settle into a bounded oscillation that the change-ratio guard never sees and
+    // that returns a useless fit (deviance above the null model's).  Then: a quarter of the window
+    // for the rest of the path, and this lambda again from the null model.
+    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && li > 0 && lambda[(size_t)li] < lambda[(size_t)li - 1] &&
+        dev > prev_dev * (1.0 + 1e-3) && batch > 64 && retries < 8) {
+      if (getenv("SGDNET_TRACE"))
+        fprintf(stderr, "[sgdnet]   lambda %d: deviance %.6g after %.6g at the previous lambda -> window %lld / 4, again\n",
+                li, dev, prev_dev, (long long)batch);
+      if (vshards > 1) {
+        vshards = 0;
+        rc = sgdnet_solver_set_virtual_shards(S, 0);
+        if (rc) return rc;
+      }
+      auto_window = std::max<int64_t>(64, batch / 4);
+      rc = solver_reset_state(S, b0.data());
+      if (rc) return rc;
+      ++retries;
+      --li;
+      continue;
+    }
+    retries = 0;
+    prev_dev = dev;
     out->dev_ratio[li] = 1.0 - dev / null_dev_scaled;                            // :258
     out->lambda[li] = lambda[(size_t)li];
 

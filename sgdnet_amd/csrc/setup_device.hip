@@ -11,6 +11,9 @@
 //   pack_records_kernel  the batched gather's packed records (saga_batched.hip)
 // All of it is streaming / segmented-reduction work bound by HBM bandwidth; none of it is on
 // the per-epoch path.
+#include <cmath>
+#include <vector>
+
 #include <hipcub/hipcub.hpp>
 
 #include "device_math.hpp"
@@ -265,6 +268,69 @@ int device_xt_times(const DeviceSetup& S, const double* ymap_host, int cols, dou
   SGD_HIP_TRY(hipStreamSynchronize(st));
   (void)hipFree(ymap);
   (void)hipFree(out);
+  return SGDNET_OK;
+}
+
+// out += sum over the sampled rows i of x_i (x_i . v): one application of X'X restricted to every
+// stride-th sample (thread per row; rows are short)
+__global__ __launch_bounds__(kTB) void gram_apply_kernel(const int64_t* sptr, const int32_t* sidx,
+                                                        const double* sval, int64_t n, int64_t stride,
+                                                        const double* v, double* out) {
+  for (int64_t r = (int64_t)blockIdx.x * kTB + threadIdx.x; r * stride < n; r += (int64_t)gridDim.x * kTB) {
+    const int64_t i = r * stride;
+    const int64_t q0 = sptr[i], q1 = sptr[i + 1];
+    double u = 0.0;
+    for (int64_t q = q0; q < q1; ++q) u += sval[q] * v[sidx[q]];
+    if (u != 0.0)
+      for (int64_t q = q0; q < q1; ++q) atomicAdd(out + sidx[q], sval[q] * u);
+  }
+}
+
+// Largest eigenvalue of X'X / n (of the centred features when standardize) by power iteration
+// over at most ~2M evenly spaced samples.  The batched mode's window is 2 L_max / L_F and L_F is
+// this eigenvalue; its diagonal lower bound is only good for features without a common
+// component -- non-negative sparse data (counts, tf-idf, uniform(0,1) values) has one, worth
+// (p - 1) * density^2 * mean^2 on top of the diagonal, and a window 8x too long then oscillates
+// into a useless fit at small lambda without ever producing a non-finite number.
+int device_gram_lmax(const DeviceSetup& S, int standardize, hipStream_t st, double* lmax) {
+  const int64_t n = S.n, p = S.p;
+  const int64_t stride = (n + 2000000 - 1) / 2000000;
+  const int64_t m = (n + stride - 1) / stride;
+  double *v_dev = nullptr, *out_dev = nullptr;
+  int rc;
+  if ((rc = dmalloc(&v_dev, (size_t)p)) || (rc = dmalloc(&out_dev, (size_t)p))) return rc;
+  std::vector<double> v((size_t)p, 1.0 / std::sqrt((double)p)), w((size_t)p), c;
+  if (standardize) {
+    c.resize((size_t)p);
+    SGD_HIP_TRY(hipMemcpy(c.data(), S.center_scaled, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost));
+  }
+  double lam = 0.0;
+  for (int it = 0; it < 30; ++it) {
+    SGD_HIP_TRY(hipMemcpyAsync(v_dev, v.data(), sizeof(double) * (size_t)p, hipMemcpyHostToDevice, st));
+    SGD_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(double) * (size_t)p, st));
+    hipLaunchKernelGGL(gram_apply_kernel, dim3(grid_for(m)), dim3(kTB), 0, st, S.sptr, S.sidx, S.sval, n, stride,
+                       v_dev, out_dev);
+    SGD_HIP_TRY(hipGetLastError());
+    SGD_HIP_TRY(hipMemcpyAsync(w.data(), out_dev, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, st));
+    SGD_HIP_TRY(hipStreamSynchronize(st));
+    double cv = 0.0;
+    if (standardize)
+      for (int64_t j = 0; j < p; ++j) cv += c[(size_t)j] * v[(size_t)j];
+    double nrm = 0.0;
+    for (int64_t j = 0; j < p; ++j) {
+      w[(size_t)j] = w[(size_t)j] / (double)m - (standardize ? c[(size_t)j] * cv : 0.0);
+      nrm += w[(size_t)j] * w[(size_t)j];
+    }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0.0)) break;
+    const double prev = lam;
+    lam = nrm;                                     // |A v| with |v| = 1: a lower bound that grows to lambda_max
+    for (int64_t j = 0; j < p; ++j) v[(size_t)j] = w[(size_t)j] / nrm;
+    if (it >= 3 && std::fabs(lam - prev) <= 2e-3 * lam) break;
+  }
+  (void)hipFree(v_dev);
+  (void)hipFree(out_dev);
+  *lmax = lam;
   return SGDNET_OK;
 }
 

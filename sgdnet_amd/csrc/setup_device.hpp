@@ -28,6 +28,7 @@ struct DeviceSetup {
 int device_setup_begin(DeviceSetup& S, const sgdnet_csc* x, int standardize, hipStream_t st,
                        std::vector<double>& x_center, std::vector<double>& x_scale, double* max_mean_sq);
 int device_xt_times(const DeviceSetup& S, const double* ymap_host, int cols, double* xty_host, hipStream_t st);
+int device_gram_lmax(const DeviceSetup& S, int standardize, hipStream_t st, double* lmax);
 int device_setup_finish(DeviceSetup& S, const double* y_host, int y_rows, int standardize, int rec_align,
                         hipStream_t st, double* max_sqnorm);
 

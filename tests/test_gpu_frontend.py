@@ -193,3 +193,27 @@ def test_small_correlated_data_in_batched_mode(sa):
         assert np.abs(fit.beta - ref.beta).max() < 1e-5 * max(1.0, np.abs(ref.beta).max())
     path = sa.sgdnet(x, y, mode="auto", seed=1)
     assert len(path.lambda_) == 100 and np.all(np.isfinite(path.beta)) and np.all(path.return_codes == 0)
+
+
+@pytest.mark.parametrize("no_lmax", [False, True])
+def test_nonnegative_sparse_features_keep_the_automatic_window_stable(sa, monkeypatch, no_lmax):
+    # non-negative sparse data (counts, tf-idf; here uniform(0, 1) values) has a common component:
+    # the largest eigenvalue of X'X/n is ~8x its diagonal and a window sized by the diagonal settles
+    # into a bounded oscillation at small lambda -- finite numbers, deviance above the null
+    # model's.  The driver sizes the window by the eigenvalue (device power iteration) and, as a
+    # safety net, redoes a lambda with a shorter window when the deviance rises along the path.
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2)
+    n, p = 200_000, 2_000
+    X = sp.random(n, p, density=0.005, format="csc", random_state=3)
+    b = rng.standard_normal(p) * (rng.random(p) < 0.1)
+    y = (rng.random(n) < 1 / (1 + np.exp(-np.asarray(X @ b).ravel()))).astype(int)
+    if no_lmax:
+        monkeypatch.setenv("SGDNET_NO_LMAX", "1")                 # only the safety net
+    fit = sa.sgdnet(X, y, family="binomial", alpha=1.0, nlambda=20, thresh=1e-5, standardize=False, mode="auto",
+                    maxit=300, seed=3)
+    assert np.all(fit.return_codes == 0)
+    assert np.all(np.diff(fit.dev_ratio) > -1e-6) and fit.dev_ratio[-1] > 0.05
+    ref = sa.sgdnet(X, y, family="binomial", alpha=1.0, lambda_=fit.lambda_, thresh=1e-5, standardize=False,
+                    mode="batched", batch=500, maxit=300, seed=3)
+    assert np.allclose(fit.dev_ratio, ref.dev_ratio, atol=2e-5)
