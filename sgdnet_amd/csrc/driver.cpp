@@ -297,6 +297,37 @@ int64_t auto_batch(const Features& X, double max_sample_sqnorm) {
       if (it == 0) lmax = 0.0;                     // v was not normalised yet
     }
     diag = std::max(diag, lmax);
+  } else if (!X.sparse && X.p > 1) {
+    // larger dense x: the same power iteration through X itself, over evenly spaced rows
+    // (rows x features <= 2e6 per step)
+    const size_t p = (size_t)X.p, n = (size_t)X.n;
+    const size_t m_max = std::max<size_t>(1000, (size_t)2000000 / p);
+    const size_t stride = (n + m_max - 1) / m_max, m = (n + stride - 1) / stride;
+    std::vector<double> v(p, 1.0 / std::sqrt((double)p)), w(p), u(m);
+    double lmax = 0.0;
+    for (int it = 0; it < 30; ++it) {
+      std::fill(u.begin(), u.end(), 0.0);
+      for (size_t j = 0; j < p; ++j) {
+        const double* col = X.xd.data() + j * n;
+        const double vj = v[j];
+        for (size_t r = 0; r < m; ++r) u[r] += col[r * stride] * vj;
+      }
+      double nrm = 0.0;
+      for (size_t j = 0; j < p; ++j) {
+        const double* col = X.xd.data() + j * n;
+        double s = 0.0;
+        for (size_t r = 0; r < m; ++r) s += col[r * stride] * u[r];
+        w[j] = s / (double)m;
+        nrm += w[j] * w[j];
+      }
+      nrm = std::sqrt(nrm);
+      if (!(nrm > 0.0)) break;
+      const double prev = lmax;
+      lmax = nrm;
+      for (size_t j = 0; j < p; ++j) v[j] = w[j] / nrm;
+      if (it >= 3 && std::fabs(lmax - prev) <= 2e-3 * lmax) break;
+    }
+    diag = std::max(diag, lmax);
   }
   return sgdnet_auto_batch(max_sample_sqnorm, diag);
 }
