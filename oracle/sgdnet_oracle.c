@@ -964,7 +964,7 @@ static int fit_common(const orc_xmat* X,            /* feature-major, preprocess
   int k, li;
   double* y_center = (double*)calloc((size_t)K, sizeof(double));
   double* y_scale = (double*)malloc(sizeof(double) * (size_t)K);
-  double* yt = (double*)malloc(sizeof(double) * (size_t)(n * Ky));
+  double* yt = (double*)calloc((size_t)(n * Ky), sizeof(double));
   double* lambda = (double*)malloc(sizeof(double) * (size_t)n_lambda);
   double* alpha = (double*)malloc(sizeof(double) * (size_t)n_lambda);
   double* beta = (double*)malloc(sizeof(double) * (size_t)n_lambda);
