@@ -44,6 +44,7 @@ struct SagaDev {
   double* vG;            // V x K*p
   double* vb;            // V
   double* vgb;           // V
+  double* vcw;           // V: c . w of every replica (implicit centring)
   double* vd0;           // one intercept partial per gather workgroup
   double* vref;          // snapshot [g_sum | w | g_sum_b | b] the replicas started from
   unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
@@ -139,6 +140,7 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
 int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);
 int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st);
+int launch_vs_cw(const SagaDev& d, hipStream_t st);
 bool vs_eligible(const SagaDev& d, int m);
 bool compact_eligible(const SagaDev& d);
 int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* longmap, hipStream_t st);

@@ -527,7 +527,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   // one response runs as up to 8 locally normalised replicas over sample ranges, averaged on the
   // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
   // at the benchmark shapes.  SGDNET_VSHARDS=0 switches it off, =V forces V.
-  if (mode == SGDNET_MODE_BATCHED && K == 1 && !(ctl->standardize && X.sparse)) {
+  if (mode == SGDNET_MODE_BATCHED && K == 1) {
     int V = 1;
     // at least 100 samples per feature in every shard, and a problem large enough for the
     // per-launch cost to matter (small correlated data, e.g. abalone 4177 x 9, converges slower

@@ -939,9 +939,11 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     gct[k] = 0.0;
-    bk[k] = k < K ? (kVS ? d.vb[vsh] : d.b[k]) - (d.standardize ? cw_sum(d, batch_id, k) : 0.0) : 0.0;
+    bk[k] = k < K ? (kVS ? d.vb[vsh] - (d.standardize ? d.vcw[vsh] : 0.0)
+                         : d.b[k] - (d.standardize ? cw_sum(d, batch_id, k) : 0.0))
+                  : 0.0;
   }
-  if (d.standardize) cw_clear_next(d, batch_id);
+  if (d.standardize && !kVS) cw_clear_next(d, batch_id);
   constexpr int kGroups = kLdsBlock / kGroup;
   if (KMAX == 1) {
     // K == 1.  8-lane form (both tables in LDS): compact records when the problem has them.
@@ -1575,23 +1577,24 @@ __global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamPar
     for (; bidx < d.v_bps; bidx += kSlabGroups) acc += sp[(int64_t)bidx * KP];
   }
   part[g][e] = acc;
-  if (fb == 0) {                                 // the shard's intercept accumulator
+  const bool need_d0 = fb == 0 || d.standardize;  // the shard's intercept accumulator = sum of gc
+  if (need_d0) {
     double a = 0.0;
     for (int i = threadIdx.x; i < d.v_bps; i += kBlock) a += d.vd0[v * d.v_bps + i];
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   }
   __syncthreads();
-  if (fb == 0 && threadIdx.x == 0) {
-    double tot = 0.0;
-    for (int wv = 0; wv < kBlock / 64; ++wv) tot += red[wv];
-    d0_s = tot;
-  }
+  double d0_all = 0.0;
+  if (need_d0)
+    for (int wv = 0; wv < kBlock / 64; ++wv) d0_all += red[wv];
+  if (fb == 0 && threadIdx.x == 0) d0_s = d0_all;
   if ((int)threadIdx.x < kSlabElems) {
     const int64_t jj = (int64_t)fb * kSlabElems + threadIdx.x;
     if (jj < KP) {
       double dj = 0.0;
       for (int gg = 0; gg < kSlabGroups; ++gg) dj += part[gg][threadIdx.x];
+      if (d.standardize) dj -= d.c[jj] * d0_all;   // implicit centring: D_j -= c_j * sum(gc)
       double* wj = d.vw + (int64_t)v * KP + jj;
       double* gj = d.vG + (int64_t)v * KP + jj;
       const double gls = q.gamma * q.ls_m;
@@ -1607,6 +1610,24 @@ __global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamPar
     const double gbk = d.vgb[v] + dk;
     d.vgb[v] = gbk;
     d.vb[v] -= q.gamma * (gbk * 0.01 * q.m_d + dk);
+  }
+}
+
+// implicit centring with virtual shards: c . w of every replica, recomputed after each sweep and
+// merge (one block per shard; the single-replica path keeps this sum incrementally in slots)
+__global__ __launch_bounds__(kBlock) void saga_vs_cw_kernel(SagaDev d) {
+  __shared__ double red[kBlock / 64];
+  const int v = blockIdx.x;
+  const double* wv = d.vw + (int64_t)v * d.p;
+  double a = 0.0;
+  for (int64_t j = threadIdx.x; j < d.p; j += kBlock) a += d.c[j] * wv[j];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int wvi = 0; wvi < kBlock / 64; ++wvi) t += red[wvi];
+    d.vcw[v] = t;
   }
 }
 
@@ -2003,7 +2024,7 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
 // Virtual shards need the K == 1 LDS gather with w staged in LDS and a grid that splits evenly.
 bool vs_eligible(const SagaDev& d, int m) {
   (void)m;
-  if (d.V < 2 || d.K != 1 || d.standardize || d.force_global || !d.vw) return false;
+  if (d.V < 2 || d.K != 1 || (d.standardize && !(d.vcw && d.c)) || d.force_global || !d.vw) return false;
   const size_t table = sizeof(double) * (size_t)d.p;
   if (d.xd) return table <= 80 * 1024;                           // dense x: only the accumulator is staged
   return 2 * table + 16 + kLdsStaticReserve <= kLdsPerCu;     // accumulator + coefficient snapshot in LDS
@@ -2021,6 +2042,13 @@ int launch_vs_broadcast(const SagaDev& d, hipStream_t st) {
   int grid = (int)((2 * d.p + 2 + kBlock - 1) / kBlock);
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(saga_vs_broadcast_kernel, dim3(grid), dim3(kBlock), 0, st, d);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_vs_cw(const SagaDev& d, hipStream_t st) {
+  if (!d.standardize) return SGDNET_OK;
+  hipLaunchKernelGGL(saga_vs_cw_kernel, dim3(d.V), dim3(kBlock), 0, st, d);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

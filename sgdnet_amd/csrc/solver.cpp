@@ -232,6 +232,8 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
   const int every = vs_merge_batches(s, batch);
   int rc = launch_vs_broadcast(d, s->st);
   if (rc) return rc;
+  rc = launch_vs_cw(d, s->st);
+  if (rc) return rc;
   for (int k = 0; k < nb; ++k) {
     const int64_t t0 = (int64_t)k * batch;
     const int64_t m = (dps - t0 < batch) ? dps - t0 : batch;
@@ -253,6 +255,10 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
     const bool last = k + 1 == nb;
     if (last || (k + 1) % every == 0) {
       rc = launch_vs_merge(d, last ? 1 : 0, s->st);
+      if (rc) return rc;
+    }
+    if (!last) {
+      rc = launch_vs_cw(d, s->st);                // c . w of the replicas the next gather reads
       if (rc) return rc;
     }
   }
@@ -1371,10 +1377,10 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   s->vs_owned.clear();
   SagaDev& d = s->d;
   d.V = 0;
-  d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = nullptr;
+  d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = nullptr;
   if (n_shards < 2) return SGDNET_OK;
-  if (d.K != 1 || d.standardize) {
-    set_error("virtual shards: one class, no implicit centring");
+  if (d.K != 1) {
+    set_error("virtual shards: one class");
     return SGDNET_EUNSUPPORTED;
   }
   const int64_t KP = d.p;
@@ -1390,6 +1396,7 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   if (!rc) rc = alloc(&d.vG, (size_t)n_shards * KP);
   if (!rc) rc = alloc(&d.vb, 8);
   if (!rc) rc = alloc(&d.vgb, 8);
+  if (!rc) rc = alloc(&d.vcw, 8);
   if (!rc) rc = alloc(&d.vd0, 256);
   if (!rc) rc = alloc(&d.vref, (size_t)(2 * KP + 2));
   if (rc) {
@@ -1409,7 +1416,7 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
     for (void* q : s->vs_owned) (void)hipFree(q);
     s->vs_owned.clear();
     d.V = 0;
-    d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = nullptr;
+    d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = nullptr;
     set_error("virtual shards: n_features too large for the LDS-resident gather");
     return SGDNET_EUNSUPPORTED;
   }

@@ -922,11 +922,22 @@ def test_virtual_shards_on_dense_x(sa, oracle, V, n, p, batch, family):
     _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense=True)
 
 
-def _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense):
+@pytest.mark.parametrize("V,n,p,batch,family", [(2, 4000, 60, 64, "binomial"), (8, 8005, 50, 120, "gaussian")])
+def test_virtual_shards_with_implicit_centring(sa, oracle, V, n, p, batch, family):
+    # sparse standardize=TRUE (the package default) on shards: lp -= c.w_v per replica, recomputed
+    # after every sweep and merge, and D_j -= c_j * sum(gc) of the shard in its sweep
+    _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense=False,
+                         c=np.random.default_rng(4).normal(0.05, 0.1, p))
+
+
+def _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense, c=None):
     x, y = make_problem(family, 1, n, p, 0.5 if dense else 0.1, seed=29)
     kw = dict(family=family, penalty="elasticnet", gamma=0.005, alpha=1e-4, beta=1e-4)
+    if c is not None:
+        kw["x_center_scaled"] = c
     epochs = 3
-    S = sa.SagaSolver(np.asfortranarray(x.toarray()) if dense else x, y, family=family, n_classes=1)
+    S = sa.SagaSolver(np.asfortranarray(x.toarray()) if dense else x, y, family=family, n_classes=1,
+                      x_center_scaled=c)
     S.set_penalty("elasticnet", kw["gamma"], kw["alpha"], kw["beta"])
     S.set_virtual_shards(V)
     stream = S.sharded_stream([sa.RRng(60 + v) for v in range(V)], epochs)
