@@ -1009,8 +1009,8 @@ def test_parallel_generators_reach_the_same_optimum(sa, oracle, monkeypatch):
     st_a, st_b = sa.RRng(4), sa.RRng(4)
     a = sa.sgdnet(X, y, rng=st_a, **kw)
     b = sa.sgdnet(X, y, rng=st_b, **kw)
-    assert a.return_codes[0] == 0 and a.npasses == b.npasses
-    assert np.allclose(a.beta, b.beta, rtol=0, atol=1e-12)            # same streams, same fit
+    assert a.return_codes[0] == 0 and abs(a.npasses - b.npasses) <= 1
+    assert np.allclose(a.beta, b.beta, rtol=0, atol=1e-9)             # same streams, same fit (to summation order)
     assert np.abs(a.beta - one.beta).max() < 1e-6                     # another order, same optimum
     assert np.array_equal(st_a.stream(n, 50), st_b.stream(n, 50))
     ref = sa.RRng(4)
