@@ -1012,6 +1012,7 @@ def test_parallel_generators_reach_the_same_optimum(sa, oracle, monkeypatch):
     assert a.return_codes[0] == 0 and abs(a.npasses - b.npasses) <= 1
     assert np.allclose(a.beta, b.beta, rtol=0, atol=1e-9)             # same streams, same fit (to summation order)
     assert np.abs(a.beta - one.beta).max() < 1e-6                     # another order, same optimum
-    assert np.array_equal(st_a.stream(n, 50), st_b.stream(n, 50))
+    if a.npasses == b.npasses:                                        # then the generators ended in the same state
+        assert np.array_equal(st_a.stream(n, 50), st_b.stream(n, 50))
     ref = sa.RRng(4)
     assert not np.array_equal(st_a.stream(n, 50), ref.stream(n, 50))  # the caller's generator moved
