@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <vector>
 
 #include "common.hpp"
@@ -60,8 +61,29 @@ struct Features {
 };
 
 // math.h:66-79 Mean / :114-130 StandardDeviation (population sd, 0 -> 1)
+// Host-side passes over dense x (R hands over a column-major matrix): per-column work is split
+// over a few threads.  Every column is still reduced by one thread in the reference's order, so
+// the results are bitwise those of the serial loops.
+template <class F>
+void parallel_for(int64_t count, double work, F f) {
+  unsigned T = std::thread::hardware_concurrency();
+  if (T > 16) T = 16;
+  if (work < 4e6 || T < 2 || count < 2) {
+    f((int64_t)0, count);
+    return;
+  }
+  if ((int64_t)T > count) T = (unsigned)count;
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < T; ++t) {
+    const int64_t lo = count * t / T, hi = count * (t + 1) / T;
+    th.emplace_back([=, &f] { f(lo, hi); });
+  }
+  for (auto& x : th) x.join();
+}
+
 void col_mean_sd(const double* x, int64_t n, int64_t m, double* mean, double* sd) {
-  for (int64_t j = 0; j < m; ++j) {
+  parallel_for(m, (double)n * (double)m, [&](int64_t j0, int64_t j1) {
+  for (int64_t j = j0; j < j1; ++j) {
     const double* col = x + j * n;
     double s = 0.0;
     for (int64_t i = 0; i < n; ++i) s += col[i];
@@ -74,11 +96,30 @@ void col_mean_sd(const double* x, int64_t n, int64_t m, double* mean, double* sd
     v /= (double)n;
     sd[j] = (v == 0.0) ? 1.0 : sqrt(v);
   }
+  });
 }
 
 void standardize_cols(double* x, int64_t n, int64_t m, const double* mean, const double* sd) {
-  for (int64_t j = 0; j < m; ++j)
-    for (int64_t i = 0; i < n; ++i) x[i + j * n] = (x[i + j * n] - mean[j]) / sd[j];
+  parallel_for(m, (double)n * (double)m, [&](int64_t j0, int64_t j1) {
+    for (int64_t j = j0; j < j1; ++j)
+      for (int64_t i = 0; i < n; ++i) x[i + j * n] = (x[i + j * n] - mean[j]) / sd[j];
+  });
+}
+
+// sample-major copy of a column-major n x p matrix (utils.h:283-288), in cache-sized tiles
+void transpose_to_sample_major(const double* xd, int64_t n, int64_t p, double* xt) {
+  constexpr int64_t kTile = 64;
+  const int64_t row_tiles = (n + kTile - 1) / kTile;
+  parallel_for(row_tiles, (double)n * (double)p, [&](int64_t t0, int64_t t1) {
+    for (int64_t t = t0; t < t1; ++t) {
+      const int64_t i0 = t * kTile, i1 = std::min(n, i0 + kTile);
+      for (int64_t j0 = 0; j0 < p; j0 += kTile) {
+        const int64_t j1 = std::min(p, j0 + kTile);
+        for (int64_t i = i0; i < i1; ++i)
+          for (int64_t j = j0; j < j1; ++j) xt[j + i * p] = xd[i + j * n];
+      }
+    }
+  });
 }
 
 // x^T v for every feature column; v is n x cols column-major
@@ -86,16 +127,18 @@ int xt_times(const Features& X, const double* v, int cols, double* out) {
   if (X.dev) return device_xt_times(*X.dev, v, cols, out, X.st);
   for (int c = 0; c < cols; ++c) {
     const double* vc = v + (int64_t)c * X.n;
-    for (int64_t j = 0; j < X.p; ++j) {
-      double s = 0.0;
-      if (X.sparse) {
-        for (int64_t q = X.colptr[j]; q < X.colptr[j + 1]; ++q) s += X.val[(size_t)q] * vc[X.rowidx[q]];
-      } else {
-        const double* col = X.xd.data() + j * X.n;
-        for (int64_t i = 0; i < X.n; ++i) s += col[i] * vc[i];
+    parallel_for(X.p, X.sparse ? 0.0 : (double)X.n * (double)X.p, [&](int64_t j0, int64_t j1) {
+      for (int64_t j = j0; j < j1; ++j) {
+        double s = 0.0;
+        if (X.sparse) {
+          for (int64_t q = X.colptr[j]; q < X.colptr[j + 1]; ++q) s += X.val[(size_t)q] * vc[X.rowidx[q]];
+        } else {
+          const double* col = X.xd.data() + j * X.n;
+          for (int64_t i = 0; i < X.n; ++i) s += col[i] * vc[i];
+        }
+        out[j + (int64_t)c * X.p] = s;
       }
-      out[j + (int64_t)c * X.p] = s;
-    }
+    });
   }
   return SGDNET_OK;
 }
@@ -866,8 +909,7 @@ int sgdnet_fit_dense(const double* x, int64_t n, int64_t p, const double* y, int
     standardize_cols(X.xd.data(), n, p, X.x_center.data(), X.x_scale.data());
   }
   X.xt.resize((size_t)(n * p));                               // utils.h:283-288
-  for (int64_t i = 0; i < n; ++i)
-    for (int64_t j = 0; j < p; ++j) X.xt[(size_t)(j + i * p)] = X.xd[(size_t)(i + j * n)];
+  transpose_to_sample_major(X.xd.data(), n, p, X.xt.data());
   return fit_common(X, y, y_cols, ctl, out);
 }
 
