@@ -596,13 +596,16 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     ~PipeGuard() { if (on) (void)solver_rng_close(s, rng); }
   } pipe_guard{S, &draws.rng, false};
   if (pipe) {
-    // batched mode with epochs of 200 000 draws or more: 8 generators side by side (one makes
+    // batched mode with epochs of 200 000 draws or more: 8-32 generators side by side (one makes
     // 10M draws in 5.3 ms, six epochs of the batched kernels at C4).  Smaller problems and exact
     // mode keep the single R stream.  SGDNET_RNG_GENERATORS overrides.
     int gens = 1;
     if (mode == SGDNET_MODE_BATCHED) {
       const char* e = getenv("SGDNET_RNG_GENERATORS");
-      gens = e ? atoi(e) : (n >= 200000 ? 8 : 1);
+      // a generator's workgroup cannot share a CU with a gather workgroup (LDS and registers are
+      // taken), so a long-running generator costs every overlapping gather launch a second round:
+      // C4 epochs 1.07 / 0.93 / 0.86 ms with 8 / 16 / 32 generators (0.85 with the stream resident)
+      gens = e ? atoi(e) : (n >= 200000 ? (int)std::min<int64_t>(32, std::max<int64_t>(8, n / 300000)) : 1);
     }
     rc = solver_rng_open(S, &draws.rng, n, gens);
     if (rc) return rc;

@@ -71,7 +71,7 @@ struct sgdnet_solver {
     uint32_t* state[2] = {nullptr, nullptr};    // generation g reads state[g & 1], writes state[(g + 1) & 1]
     int64_t n = 0;
     int64_t gens = 0, used = 0;
-    static constexpr int kMaxGen = 16;
+    static constexpr int kMaxGen = 64;
     int G = 1;                                  // independent generators (segments of an epoch's stream)
   } pipe;
   int64_t nnz = 0;
