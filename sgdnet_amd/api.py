@@ -43,6 +43,23 @@ def _stop(msg):
     raise ValueError(msg)
 
 
+def _levels(y):
+    """(levels, counts, codes) of a class vector (R: factor levels, table(), as.numeric(y) - 1)."""
+    y = np.asarray(y).reshape(-1)
+    levels, counts = np.unique(y, return_counts=True)
+    return levels, counts, np.searchsorted(levels, y).astype(np.float64)
+
+
+def _has_nan(a):
+    """any(is.na(.)): the sum is NaN (or +-inf) iff something is off; only then look closer."""
+    a = np.asarray(a)
+    if a.dtype.kind != "f" or a.size == 0:
+        return False
+    with np.errstate(invalid="ignore", over="ignore"):
+        t = a.sum()
+    return bool(np.isnan(t) and np.isnan(a).any())
+
+
 def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None, lambda_=None,
            maxit=1000, standardize=True, intercept=True, thresh=0.001,
            standardize_response=False, *, debug=False, seed=0, rng=None, sample_stream=None,
@@ -92,7 +109,7 @@ def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None,
     if np.any(lam < 0):
         _stop("penalty strengths (lambdas) must be positive.")
     xvals = x.data if is_sparse else x
-    if np.any(np.isnan(xvals)) or (y_arr.dtype.kind == "f" and np.any(np.isnan(y_arr))):
+    if _has_nan(xvals) or _has_nan(y_arr):
         _stop("NA values are not allowed.")
     if thresh < 0:
         _stop("threshold for stopping criteria cannot be negative.")
@@ -113,7 +130,7 @@ def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None,
         n_classes = 1
         y_enc = y_arr.astype(np.float64).reshape(-1)
     elif family == "binomial":
-        levels, counts = np.unique(y_arr, return_counts=True)
+        levels, counts, codes = _levels(y_arr)
         if levels.size > 2:
             _stop("more than two classes in response. Are you looking for family = 'multinomial'?")
         if levels.size == 1:
@@ -122,9 +139,9 @@ def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None,
         if counts.min() <= 1:
             _stop(f"one class only has {counts.min()} observations.")
         class_names = [str(v) for v in levels]
-        y_enc = np.searchsorted(levels, y_arr.reshape(-1)).astype(np.float64)
+        y_enc = codes
     elif family == "multinomial":
-        levels, counts = np.unique(y_arr, return_counts=True)
+        levels, counts, codes = _levels(y_arr)
         class_names = [str(v) for v in levels]
         n_classes = levels.size
         if n_classes == 2:
@@ -133,7 +150,7 @@ def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None,
             _stop("only one class in response.")
         if counts.min() <= 1:
             _stop(f"one class only has {counts.min()} observations.")
-        y_enc = np.searchsorted(levels, y_arr.reshape(-1)).astype(np.float64)
+        y_enc = codes
     else:
         if n_targets == 1:
             _stop("response for multivariate Gaussian regression must not be one-dimensional; "
