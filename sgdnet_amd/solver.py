@@ -15,7 +15,12 @@ STATE = {"w": 0, "intercept": 1, "g_memory": 2, "g_sum": 3, "g_sum_intercept": 4
 class RRng:
     """R-compatible Mersenne-Twister: RRng(seed) draws what set.seed(seed) draws."""
 
-    def __init__(self, seed):
+    def __init__(self, seed, sample_kind="Rejection"):
+        """sample_kind: R's RNGkind(sample.kind = ...): "Rejection" (R >= 3.6.0, the default) or
+        "Rounding" (what sample() did up to R 3.5.x, the R that printed the reference's docs)."""
+        if sample_kind not in ("Rejection", "Rounding"):
+            raise ValueError("sample_kind must be 'Rejection' or 'Rounding'")
+        self.sample_kind = sample_kind
         self._L = _lib.load()
         self.state = _lib.Rng()
         self._L.sgdnet_rng_seed(C.byref(self.state), C.c_uint32(seed))
@@ -38,6 +43,8 @@ class RRng:
         return v & ((1 << bits) - 1) if bits < 64 else v
 
     def unif_index(self, dn):
+        if self.sample_kind == "Rounding":         # R < 3.6.0: floor(dn * unif_rand())
+            return int(np.floor(dn * self.unif()[0]))
         if dn <= 0:
             return 0
         bits = int(np.ceil(np.log2(dn)))

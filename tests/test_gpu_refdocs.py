@@ -1,0 +1,53 @@
+"""libsgdnet_hip.so (exact mode, through sgdnet()/cv_sgdnet() and the C ABI) against the numbers a
+real build of the reference printed (tests/golden/refdocs.npz; see tests/test_refdocs_oracle.py
+for what they are).  Same flows, same tolerances = the precision of the printed output: the HIP
+path reproduces the reference's documented results digit for digit, including the
+random-number accounting of every fit inside the cross-validation loops."""
+import numpy as np
+import pytest
+
+import refdocs_flow as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def d():
+    return F.load()
+
+
+@pytest.fixture(scope="module")
+def be():
+    return F.HipBackend("exact")
+
+
+def test_gaussian_lasso_path_coefficients_as_printed(be, d):
+    c = F.example_coef(be, d)
+    want = d["coef_gaussian"]
+    assert np.array_equal(c == 0, want == 0)
+    assert np.abs(c - want).max() <= 5.1e-9
+
+
+def test_binomial_cv_predictions_and_the_multinomial_fit_that_follows(be, d):
+    r = F.example_cv_heart_then_deviance(be, d)
+    assert r["alpha_min"] == 0.0
+    assert np.abs(r["link"] - d["cv_heart_link"]).max() <= 5.1e-11
+    want = d["deviance_wine"]
+    assert abs(r["nulldev"] - want[0]) <= 5.1e-7
+    assert np.abs(r["deviance"] - want).max() <= 5.1e-7
+
+
+def test_predict_print_chain(be, d):
+    r = F.example_predict_chain(be, d, student_lambda0_nudge=1e-13)
+    assert (r["iris_class"] == d["cv_iris_class"]).all()
+    assert (r["heart_class"] == d["predict_heart_class"]).all()
+    assert np.array_equal(r["student_nonzero"], d["predict_student_nonzero"])
+    assert np.array_equal(F.signif_round(r["print_cv"], 7), d["print_cv_mtcars"])
+    assert np.array_equal(r["mtcars_df"], d["print_mtcars_df"])
+    assert np.array_equal(np.round(r["mtcars_lambda"], 2), d["print_mtcars_lambda"])
+    assert np.array_equal(F.signif_round(r["mtcars_dev"], 1), d["print_mtcars_dev"])
+
+
+def test_multinomial_cv_score_as_printed(be, d):
+    got = F.example_score_wine(be, d)
+    assert abs(got - float(d["score_wine_deviance"])) <= 5.1e-8

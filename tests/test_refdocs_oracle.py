@@ -1,0 +1,74 @@
+"""The CPU oracle against numbers PRINTED BY A REAL BUILD OF THE REFERENCE: the example outputs
+of its pkgdown site (/root/reference/docs/reference/*.html), committed as data in
+tests/golden/refdocs.npz.  This is the pin of the oracle: every comparison is at
+the precision the reference printed, over whole cross-validation flows whose later numbers
+depend on every earlier fit having consumed exactly the reference's number of random draws.
+
+Families / code paths pinned: gaussian dense lasso path (300 coefficients, 8 decimals),
+binomial dense ridge (54 link predictions, 10 decimals, after 16 fits), multinomial dense lasso
+(100 deviances, 9 significant digits; 0.2717494), binomial sparse standardize = TRUE (54
+classes), mgaussian group lasso (100 active sets), lambda paths, Df and %Dev of a gaussian fit.
+"""
+import numpy as np
+import pytest
+
+import refdocs_flow as F
+
+
+@pytest.fixture(scope="module")
+def d():
+    return F.load()
+
+
+@pytest.fixture(scope="module")
+def be():
+    return F.OracleBackend()
+
+
+def test_gaussian_lasso_path_coefficients_as_printed(be, d):
+    c = F.example_coef(be, d)                      # docs/reference/coef.sgdnet.html
+    want = d["coef_gaussian"]
+    assert np.array_equal(c == 0, want == 0)       # "." entries of the sparse print
+    # printed with 7 significant digits per block of five columns: |error| <= half a unit of the
+    # last printed decimal (8 decimals; 9-10 for the smallest entries)
+    assert np.abs(c - want).max() <= 5.1e-9
+
+
+def test_binomial_cv_predictions_and_the_multinomial_fit_that_follows(be, d):
+    r = F.example_cv_heart_then_deviance(be, d)    # docs/reference/cv_sgdnet.html, deviance.sgdnet.html
+    assert r["alpha_min"] == 0.0
+    assert np.abs(r["link"] - d["cv_heart_link"]).max() <= 5.1e-11          # 10 decimals printed
+    want = d["deviance_wine"]
+    assert abs(r["nulldev"] - want[0]) <= 5.1e-7
+    assert np.abs(r["deviance"] - want).max() <= 5.1e-7                     # 6 decimals printed
+
+
+def test_predict_print_chain(be, d):
+    r = F.example_predict_chain(be, d, student_lambda0_nudge=1e-13)
+    assert (r["iris_class"] == d["cv_iris_class"]).all()                    # docs/reference/predict.cv_sgdnet.html
+    assert (r["heart_class"] == d["predict_heart_class"]).all()             # docs/reference/predict.sgdnet.html
+    assert np.array_equal(r["student_nonzero"], d["predict_student_nonzero"])
+    # docs/reference/print.cv_sgdnet.html: 7 significant digits, after 7 + 3 more fits
+    got, want = r["print_cv"], d["print_cv_mtcars"]
+    assert np.array_equal(F.signif_round(got, 7), want)
+    # docs/reference/print.sgdnet.html: print(fit, digits = 1)
+    assert np.array_equal(r["mtcars_df"], d["print_mtcars_df"])
+    assert np.array_equal(np.round(r["mtcars_lambda"], 2), d["print_mtcars_lambda"])
+    assert np.array_equal(F.signif_round(r["mtcars_dev"], 1), d["print_mtcars_dev"])
+
+
+def test_student_active_sets_without_the_lambda_max_nudge(be, d):
+    """Unmodified example: at lambda_max itself the group-lasso test `f < 1` (src/penalties.h:72)
+    is decided by the last bits of LambdaMax, which the reference computes with an Eigen GEMM;
+    the oracle keeps feature 7 at 1.7e-13 there, runs 12 epochs fewer, and the stream shift moves
+    three borderline entries further down the path.  Everything else is identical."""
+    r = F.example_predict_chain(be, d)
+    same = (r["student_nonzero"] == d["predict_student_nonzero"]).all(axis=1)
+    assert same.sum() >= 95
+    assert (r["student_nonzero"] != d["predict_student_nonzero"]).sum() <= 6
+    assert (r["heart_class"] == d["predict_heart_class"]).all()
+
+
+def test_multinomial_cv_score_as_printed(be, d):
+    got = F.example_score_wine(be, d)              # docs/reference/score.html
+    assert abs(got - float(d["score_wine_deviance"])) <= 5.1e-8
