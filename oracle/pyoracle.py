@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
 and bench.py's cpu_baseline leg may import this module; sgdnet_amd/ never does.
-See oracle/sgdnet_oracle.h for the parity status ("bitwise parity unpinned").
+See oracle/sgdnet_oracle.h for the parity status (pinned to the reference's printed outputs).
 """
 import ctypes as C
 import os

@@ -7,13 +7,27 @@
  * checker / timed CPU baseline.  Nothing under sgdnet_amd/ may link, import or
  * call this.
  *
- * Parity status: the reference cannot be compiled here (needs R, Rcpp and
- * Eigen, none present) and stores no golden vectors; this restatement is
- * pinned by the reference's own known-answer tests (closed-form ridge, OLS,
- * logistic MLE, lambda_max formulas, null deviances, sparse==dense, ...;
- * tests/test_oracle_properties.py) at the tolerances those tests
- * state (1e-3 .. 1e-6).  BITWISE PARITY WITH A REAL BUILD OF THE REFERENCE IS
- * UNPINNED (Eigen reduction order, R's libm).
+ * Parity status: PINNED to outputs of a real build of the reference.  The
+ * reference cannot be compiled here (needs R, Rcpp and Eigen, none present),
+ * but its tree ships the console output of its documented examples
+ * (docs/reference/(any).html, pkgdown 1.1.0 / R 3.5).  tests/test_refdocs_oracle.py
+ * replays those examples through this restatement -- R's Mersenne-Twister,
+ * rnorm and sample() included, whole cross-validation loops whose later
+ * numbers depend on every earlier fit having run exactly the reference's
+ * number of epochs -- and reproduces what the reference printed at print
+ * precision: 300 gaussian lasso coefficients (8 decimals), 54 binomial ridge
+ * link predictions after 16 fits (10 decimals), 100 multinomial deviances (9
+ * significant digits), a multinomial CV score (7 digits), CV summary
+ * statistics of a gaussian fit (7 digits), 104 predicted classes, and the
+ * active sets of a 100-lambda mgaussian group-lasso path (all 100 once the
+ * first lambda is raised by 1e-13: at lambda_max itself the group-lasso
+ * threshold test is decided by the last bits of an Eigen GEMM).  Fixtures:
+ * tests/golden/refdocs.npz (tests/golden/make_refdocs_fixtures.py).
+ * Beyond that it is checked against the reference's own known-answer tests
+ * (closed-form ridge, OLS, logistic MLE, lambda_max formulas, null deviances,
+ * sparse==dense, ...; tests/test_oracle_properties.py).
+ * Not pinned: bit-level equality of intermediate state (Eigen's packetised
+ * reductions, the libm of the machine that built the docs).
  */
 #ifndef SGDNET_ORACLE_H_
 #define SGDNET_ORACLE_H_
