@@ -48,6 +48,20 @@ WORKLOADS = {
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def self_launch(n_gpus):
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,13 +85,15 @@ def main():
                          "per-batch all-reduce of the scatter accumulator (exact single-GPU iterates)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # Called as plain `python bench.py --gpus N`: start one process per GPU ourselves.  This
+        # process has not touched the GPU (no torch import yet), the ranks are CHILD processes, and
+        # their stdout (rank 0's one JSON line) is relayed.
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N > 1 must be launched with torch.distributed.run "
-                     "(one process per GPU)")
         args.gpus = world
 
     import torch
@@ -261,11 +277,15 @@ def main():
         dist.all_reduce(alg_all, op=dist.ReduceOp.SUM)
     job_gbps = float(alg_all[0]) / (elapsed / args.steps) / 1e9
 
+    seen = torch.ones(1, dtype=torch.float64, device=red_dev)
+    if world > 1:
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)   # how many ranks really took part in the collectives
     out = {
         "metric": "saga_epochs_per_sec",
         "value": args.steps / elapsed,
         "unit": "epochs/s",
         "n_gpus": world,
+        "n_ranks_seen": int(seen[0]),
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,

@@ -264,7 +264,8 @@ int sgdnet_solver_sync_gather(sgdnet_solver* s, int64_t t0_local, int64_t m_loca
 int sgdnet_solver_sync_sweep(sgdnet_solver* s, int64_t m_global, int64_t m_local, int round);
 int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds);
 
-/* Virtual shards (batched mode, sparse x, one class, no centring): the samples are
+/* Virtual shards (batched mode, one response; sparse x with or without implicit centring, or
+ * dense x): the samples are
  * split into n_shards contiguous ranges (sizes as shard_bounds of sgdnet_amd/parallel.py), every
  * range runs the batched iteration on its own replica of (w, g_sum, intercept) with local
  * normalisation, one launch carries the same batch of all shards, and the replicas are averaged

@@ -6,6 +6,15 @@
 
 #include "sgdnet_hip.h"
 
+// Timing-only variants of the gather (no gradient-memory exchange, no scatter, ...) exist for the
+// ablation tables of DESIGN.md 5.  They compute wrong results, so the shipped library does not
+// contain them: build with EXTRA_FLAGS=-DSGDNET_EXPERIMENTS to get the SGDNET_ABLATE switch.
+#ifdef SGDNET_EXPERIMENTS
+#define SGD_ABLATE(d, bits) (((d).ablate & (bits)) != 0)
+#else
+#define SGD_ABLATE(d, bits) false
+#endif
+
 namespace sgdnet {
 
 void set_error(const char* fmt, ...);
@@ -49,7 +58,7 @@ struct SagaDev {
   double* vref;          // snapshot [g_sum | w | g_sum_b | b] the replicas started from
   unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
   int force_global;  // synchronous sharded mode: always the global-atomic gather (D must be one array)
-  int ablate;      // SGDNET_ABLATE bit mask: timing-only builds of the gather (results are wrong)
+  int ablate;      // -DSGDNET_EXPERIMENTS builds only: SGDNET_ABLATE bit mask, timing-only variants of the gather (results are wrong)
   // data, sample-major (SURVEY.md 8a "x")
   const int64_t* ptr;
   const int32_t* idx;

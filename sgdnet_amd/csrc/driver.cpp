@@ -3,9 +3,10 @@
 // Mirrors SetupSgdnet (reference src/sgdnet.cpp:119-285): preprocess, lambda
 // path, step sizes, then for every lambda {SAGA loop, deviance, rescale} with
 // the solver state kept resident in HBM across the path (warm starts,
-// src/sgdnet.cpp:187-198).  The per-fit setup passes are O(nnz) host loops in
-// this round (SURVEY.md 8 row f1 moves them onto the device); the SAGA loop and
-// the per-lambda deviance pass run on the GPU and there is no CPU fallback.
+// src/sgdnet.cpp:187-198).  For sparse x the per-fit O(nnz) setup passes run on
+// the device (setup_device.hip; SGDNET_HOST_SETUP=1 keeps the host loops below for
+// A/B checks); the SAGA loop and the per-lambda deviance pass run on the GPU and
+// there is no CPU fallback.
 #include <math.h>
 #include <string.h>
 
@@ -270,23 +271,50 @@ struct DrawSource {
     if (internal() && ctl->rng_state) *ctl->rng_state = rng;
   }
   bool internal() const { return !ctl->sample_stream && !ctl->unif; }
-  int fill(uint32_t n, uint32_t* out, int64_t count) {
+  // an explicit stream names samples of the whole data set: it cannot be laid out per shard
+  bool shardable() const { return !ctl->sample_stream; }
+  double next_unif() {
+    if (!ctl->unif) return sgdnet_rng_unif(&rng);
+    double u;
+    do {
+      u = ctl->unif(ctl->unif_ctx);
+    } while (u <= 0.0 || u >= 1.0);
+    return u;
+  }
+  // One epoch of `count` draws over n samples.  shards > 1: the layout the virtual-shard kernels
+  // read (include/sgdnet_hip.h: sgdnet_solver_set_virtual_shards) -- count / shards entries per
+  // shard, shard after shard, entry t of shard v drawn uniformly from shard v's sample range; the
+  // generator is still advanced by exactly `count` uniforms, like the reference's epoch.
+  int fill(uint32_t n, uint32_t* out, int64_t count, int shards = 1) {
     if (ctl->sample_stream) {
       if (pos + count > ctl->sample_stream_len) {
         set_error("explicit sample stream exhausted: %lld draws requested, %lld supplied",
                   (long long)(pos + count), (long long)ctl->sample_stream_len);
         return SGDNET_ESTREAM;
       }
-      memcpy(out, ctl->sample_stream + pos, sizeof(uint32_t) * (size_t)count);
+      for (int64_t i = 0; i < count; ++i) {
+        const uint32_t v = ctl->sample_stream[pos + i];
+        if (v >= n) {
+          set_error("sample_stream[%lld] = %u is not a sample index (n_samples = %u)", (long long)(pos + i), v, n);
+          return SGDNET_EINVAL;
+        }
+        out[i] = v;
+      }
+    } else if (shards > 1) {
+      const int64_t dps = count / shards, base = (int64_t)n / shards, rem = (int64_t)n % shards;
+      int64_t i = 0;
+      for (int v = 0; v < shards; ++v) {
+        const int64_t lo = (int64_t)v * base + std::min<int64_t>(v, rem);
+        const double size = (double)(base + (v < rem ? 1 : 0));
+        for (int64_t t = 0; t < dps; ++t) out[i++] = (uint32_t)(lo + (int64_t)floor(size * next_unif()));
+      }
+      for (; i < count; ++i) {       // positions no shard consumes
+        (void)next_unif();
+        out[i] = 0;
+      }
     } else if (ctl->unif) {
       const double nd = (double)n;
-      for (int64_t i = 0; i < count; ++i) {
-        double u;
-        do {
-          u = ctl->unif(ctl->unif_ctx);
-        } while (u <= 0.0 || u >= 1.0);
-        out[i] = (uint32_t)floor(nd * u);
-      }
+      for (int64_t i = 0; i < count; ++i) out[i] = (uint32_t)floor(nd * next_unif());
     } else {
       sgdnet_rng_fill(&rng, n, out, count);
     }
@@ -402,6 +430,18 @@ int validate(const sgdnet_control* c, const sgdnet_result* out, int y_cols) {
     set_error("control.debug needs result.losses and result.losses_len");
     return SGDNET_EINVAL;
   }
+  return SGDNET_OK;
+}
+
+// class codes are used as array indices (FitNullModel, LambdaMax, the gradient kernels)
+int validate_response(const sgdnet_control* c, const double* y, int64_t n) {
+  if (c->family != SGDNET_BINOMIAL && c->family != SGDNET_MULTINOMIAL) return SGDNET_OK;
+  const double top = c->family == SGDNET_BINOMIAL ? 1.0 : (double)(c->n_classes - 1);
+  for (int64_t i = 0; i < n; ++i)
+    if (!(y[i] >= 0.0 && y[i] <= top && y[i] == floor(y[i]))) {
+      set_error("response[%lld] = %g is not a class code in 0..%d", (long long)i, y[i], (int)top);
+      return SGDNET_EINVAL;
+    }
   return SGDNET_OK;
 }
 
@@ -565,12 +605,15 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   rc = sgdnet_solver_set_state(S, 1, b0.data());
   if (rc) return rc;
 
+  DrawSource draws(ctl);
   int vshards = 0;
   // Virtual shards (include/sgdnet_hip.h): with enough samples per feature the batched fit of
   // one response runs as up to 8 locally normalised replicas over sample ranges, averaged on the
   // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
   // at the benchmark shapes.  SGDNET_VSHARDS=0 switches it off, =V forces V.
-  if (mode == SGDNET_MODE_BATCHED && K == 1) {
+  // The shard kernels read a per-shard layout of the sample order: the built-in generator and
+  // the unif callback produce it (DrawSource::fill), an explicit sample_stream cannot.
+  if (mode == SGDNET_MODE_BATCHED && K == 1 && draws.shardable()) {
     int V = 1;
     // at least 100 samples per feature in every shard, and a problem large enough for the
     // per-launch cost to matter (small correlated data, e.g. abalone 4177 x 9, converges slower
@@ -585,7 +628,6 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     }
   }
 
-  DrawSource draws(ctl);
   // built-in generator: the draws are produced in HBM (r_rng_device.hip), one epoch ahead of
   // the epoch that consumes them, on a side stream (solver.cpp: solver_rng_*)
   const bool pipe = draws.internal();
@@ -651,7 +693,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
         rc = solver_rng_acquire(S, &stream_off);   // this epoch's
         draws.pos += n;
       } else {
-        rc = draws.fill((uint32_t)n, chunk.data(), n);
+        rc = draws.fill((uint32_t)n, chunk.data(), n, vshards > 1 ? vshards : 1);
         if (rc) return rc;
         rc = sgdnet_solver_upload_stream(S, chunk.data(), n);
       }
@@ -731,7 +773,6 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       }
       t_chk += since(t0);
     }
-    n_iter += (double)epochs;
     auto t1 = now();
     out->return_codes[li] = (epochs == ctl->max_iter) ? 1.0 : 0.0;               // saga-sparse.h:376-382
     if (ctl->debug) {
@@ -766,6 +807,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     }
     retries = 0;
     prev_dev = dev;
+    n_iter += (double)epochs;          // epochs of the accepted run of this lambda only
     out->dev_ratio[li] = 1.0 - dev / null_dev_scaled;                            // :258
     out->lambda[li] = lambda[(size_t)li];
 
@@ -822,6 +864,17 @@ int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols, const sg
   X.colptr = x->colptr;
   X.rowidx = x->rowidx;
   const int64_t n = X.n, p = X.p, nnz = x->colptr[p];
+  if (x->colptr[0] != 0) {
+    set_error("colptr[0] must be 0");
+    return SGDNET_EINVAL;
+  }
+  for (int64_t j = 0; j < p; ++j)
+    if (x->colptr[j + 1] < x->colptr[j]) {
+      set_error("colptr is not non-decreasing at column %lld", (long long)j);
+      return SGDNET_EINVAL;
+    }
+  rc = validate_response(ctl, y, n);
+  if (rc) return rc;
   for (int64_t q = 0; q < nnz; ++q) {
     const int32_t r = x->rowidx[q];
     if (r < 0 || r >= n) {
@@ -899,6 +952,8 @@ int sgdnet_fit_dense(const double* x, int64_t n, int64_t p, const double* y, int
     set_error("sgdnet_fit_dense: invalid matrix");
     return SGDNET_EINVAL;
   }
+  rc = validate_response(ctl, y, n);
+  if (rc) return rc;
   Features X;
   X.sparse = false;
   X.n = n;

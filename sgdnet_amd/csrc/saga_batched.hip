@@ -749,13 +749,13 @@ struct K1Draws {
       const int iu = i + u * step;
       valid[u] = iu < hi;
       s[u] = sp[valid[u] ? iu : safe];
-      if (d.ablate & 16) s[u] &= 1023u;         // timing only: records from a cache-resident set
+      if (SGD_ABLATE(d, 16)) s[u] &= 1023u;         // timing only: records from a cache-resident set
     }
     const int q = draw_of(gl);
     const int iq = i + q * step;
     v_own = q < U && iq < hi;
     s_own = sp[v_own ? iq : safe];
-    if (d.ablate & 16) s_own &= 1023u;
+    if (SGD_ABLATE(d, 16)) s_own &= 1023u;
   }
   __device__ __forceinline__ void load_records(const SagaDev& d, int gl) {
     const int cap = d.rec_cap;
@@ -801,7 +801,7 @@ struct K1Draws {
   __device__ __forceinline__ void gradient(const SagaDev& d, int gl, double b0, const double* wv) {
     double acc[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc[u] = in(d, u, gl) ? vf[u] * ((d.ablate & 8) ? 1.0 : wv[jf[u]]) : 0.0;
+    for (int u = 0; u < U; ++u) acc[u] = in(d, u, gl) ? vf[u] * (SGD_ABLATE(d, 8) ? 1.0 : wv[jf[u]]) : 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (tail(d, u)) {
@@ -838,7 +838,7 @@ struct K1Draws {
     const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y_sel - 1.0 / (1.0 + exp(lp_sel)) : lp_sel - y_sel;
     gcp = 0.0;
     if (is_owner(gl) && v_sel) {
-      if (d.ablate & 1) {                        // timing only: no gradient-memory exchange
+      if (SGD_ABLATE(d, 1)) {                        // timing only: no gradient-memory exchange
         gcp = g0;
       } else {
         // claim, read and update in ONE returning atomic: a repeated draw of the batch reads
@@ -854,7 +854,7 @@ struct K1Draws {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const double gc = __shfl(gcp, owner(u), kGroup);
-      if (gc != 0.0 && !(d.ablate & 4)) {
+      if (gc != 0.0 && !SGD_ABLATE(d, 4)) {
         if (in(d, u, gl)) scatter_add<true>(Dl + jf[u], vf[u] * gc);
         if (tail(d, u)) tail_for_each(d, u, gl, [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
       }
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   // flush the private copy as this workgroup's slab: plain coalesced stores (atomics would
   // cap the flush at the ~1.3 TB/s atomic rate); the sweep sums the slabs in a fixed order
   double* slab = d.slab + (int64_t)blockIdx.x * KP;
-  if (!(d.ablate & 2)) {
+  if (!SGD_ABLATE(d, 2)) {
     if ((KP & 1) == 0) {                        // slabs start at multiples of KP doubles: pairs stay aligned
       const pair_t* D2 = reinterpret_cast<const pair_t*>(Dl);
       pair_t* S2 = reinterpret_cast<pair_t*>(slab);
@@ -1865,7 +1865,7 @@ static bool lanes8_ok(const SagaDev& d) {
     const char* e = getenv("SGDNET_LANES8");
     return e ? atoi(e) : 1;
   }();
-  return allow && (d.cP || d.rec_cap >= kInReg8) && !d.ablate;
+  return allow && (d.cP || d.rec_cap >= kInReg8) && !SGD_ABLATE(d, ~0);
 }
 
 // Compact planes for a K == 1 sparse problem (d.ptr / d.idx / d.val / d.y resident).

@@ -40,12 +40,17 @@ __device__ __forceinline__ void wave_sync(bool lds_only) {
 __device__ __forceinline__ int convergence_check(const double* w, double* w_prev, int64_t len,
                                                  double tol, int lane) {
   double max_change = 0.0, max_size = 0.0;
+  bool finite = true;
   for (int64_t i = lane; i < len; i += kWave) {
     const double v = w[i];
+    finite = finite && (fabs(v) <= 1.79769313486231570815e+308);   // fmax below would drop a NaN
     max_change = fmax(max_change, fabs(v - w_prev[i]));
     max_size = fmax(max_size, fabs(v));
     w_prev[i] = v;
   }
+  // a run that blew up never satisfies the reference's test (comparisons with NaN are false):
+  // it goes on to max_iter and reports return_code 1
+  if (__ballot(!finite) != 0ull) return 0;
   max_change = wave_max(max_change);
   max_size = wave_max(max_size);
   const bool all_zero = (max_size == 0.0) && (max_change == 0.0);

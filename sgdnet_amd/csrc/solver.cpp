@@ -580,7 +580,11 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
   d.n = pb->n_samples;
   d.p = pb->n_features;
   d.n_total = (double)(pb->n_total > 0 ? pb->n_total : pb->n_samples);
+#ifdef SGDNET_EXPERIMENTS
   d.ablate = getenv("SGDNET_ABLATE") ? atoi(getenv("SGDNET_ABLATE")) : 0;
+#else
+  d.ablate = 0;
+#endif
 #ifdef SGDNET_PHASE_TIMING
   if (hipMalloc(&d.dbg, sizeof(unsigned long long) * 16 * 4096) != hipSuccess) d.dbg = nullptr;
   if (d.dbg) (void)hipMemset(d.dbg, 0, sizeof(unsigned long long) * 16 * 4096);
@@ -809,6 +813,15 @@ static int reserve_stream(sgdnet_solver* s, int64_t count) {
 int sgdnet_solver_upload_stream(sgdnet_solver* s, const uint32_t* host, int64_t count) {
   if (!s || !host || count <= 0) {
     set_error("sgdnet_solver_upload_stream: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  // the kernels use the entries as addresses (ptr[s + 1], g_memory[s * K]): reject anything
+  // that is not a sample index before it reaches the device
+  uint32_t top = 0;
+  for (int64_t i = 0; i < count; ++i) top = host[i] > top ? host[i] : top;
+  if ((int64_t)top >= s->d.n) {
+    set_error("sgdnet_solver_upload_stream: entry %u is not a sample index (n_samples = %lld)", top,
+              (long long)s->d.n);
     return SGDNET_EINVAL;
   }
   SGD_HIP_TRY(hipSetDevice(s->device));

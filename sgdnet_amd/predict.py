@@ -103,8 +103,10 @@ def predict(fit, newx=None, s=None, type="link", exact=False, device=None):
     nb = coef(fit, s)
     if type == "coefficients":
         return nb
-    if type == "nonzero":                                       # nonzero_coefs(bystep = TRUE), 0-based
-        b = fit.beta[0] if (multi and fit.grouped) else fit.beta
+    if type == "nonzero":                                       # nonzero_coefs(beta[-1, , drop = FALSE]) of the
+        b = [m[1:, :] for m in nb] if multi else nb[1:, :]      # coefficients AT s (R/predict.sgdnet.R), 0-based
+        if multi and fit.grouped:
+            b = b[0]
         mats = b if isinstance(b, list) else [b]
         out = [[np.flatnonzero(np.abs(m[:, i]) > 0) for i in range(m.shape[1])] for m in mats]
         return out if isinstance(b, list) else out[0]
