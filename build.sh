@@ -22,4 +22,8 @@ done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgdnet_hip.so" build/saga_exact.o build/saga_batched.o build/r_rng_device.o build/setup_device.o build/score.o build/solver.o build/driver.o build/r_rng.o
 make -s -C oracle liboracle.so
+# the .Call shim (shim/sgdnet_shim.c) compiled as it will be inside the R package, against the
+# mock of the R C API under tests/rmock (no R in this image): test infrastructure
+gcc -O2 -std=gnu11 -Wall -Wextra -Wno-cast-function-type -fPIC -shared -Itests/rmock/include -Iinclude -o tests/rmock/libsgdnet_shim_mock.so \
+    shim/sgdnet_shim.c tests/rmock/rmock.c -L"$OUT" -lsgdnet_hip -Wl,-rpath,'$ORIGIN/../../sgdnet_amd/lib' 
 echo "built $OUT/libsgdnet_hip.so"

@@ -76,6 +76,14 @@ typedef struct sgdnet_csc {
  * src/saga-sparse.h:261). */
 typedef double (*sgdnet_unif_fn)(void* ctx);
 
+/* Receiver of the per-epoch debug losses of one lambda (control.debug, options(sgdnet.debug = TRUE),
+ * src/saga-sparse.h:350-365 / src/utils.h:199-227): called once per lambda, on the calling thread,
+ * when that lambda's SAGA loop has ended, with the EpochLoss value of every epoch it ran.  The
+ * reference grows a std::vector (src/saga-sparse.h:364); a sink lets the caller do the same instead
+ * of reserving n_lambda x max_iter doubles (80 GB per path at the reference's benchmark setting
+ * maxit = 1e8, data-raw/benchmarks.R). */
+typedef void (*sgdnet_losses_fn)(void* ctx, int lambda_index, const double* losses, int count);
+
 /* State of R's default generator (Mersenne-Twister): 625 words = mti + mt[624]. */
 typedef struct sgdnet_rng { uint32_t mti; uint32_t mt[624]; } sgdnet_rng;
 
@@ -111,6 +119,8 @@ typedef struct sgdnet_control {
   int           mode;                 /* SGDNET_MODE_* */
   int64_t       batch;                /* batched mode: staleness window; 0 = automatic */
   int           device;               /* HIP device ordinal */
+  sgdnet_losses_fn losses_sink;       /* debug: receives each lambda's losses (result.losses may then be NULL) */
+  void*         losses_ctx;
 } sgdnet_control;
 
 /* Caller-allocated mirror of the list returned by src/sgdnet.cpp:275-284. */
@@ -120,7 +130,8 @@ typedef struct sgdnet_result {
   double*  lambda;        /* n_lambda                                                    */
   double*  dev_ratio;     /* n_lambda                                                    */
   double*  return_codes;  /* n_lambda, 0 converged / 1 max_iter reached                  */
-  double*  losses;        /* n_lambda * max_iter or NULL; filled when control.debug      */
+  double*  losses;        /* n_lambda * max_iter or NULL; filled when control.debug (or use
+                             control.losses_sink, which needs no max_iter-sized block)   */
   int32_t* losses_len;    /* n_lambda or NULL                                            */
   double   nulldev;
   double   npasses;

@@ -36,6 +36,7 @@ PENALTIES = {"ridge": 0, "elasticnet": 1, "grouplasso": 2}
 MODES = {"exact": 0, "batched": 1, "auto": 2}
 
 UNIF_FN = C.CFUNCTYPE(C.c_double, C.c_void_p)
+LOSSES_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int)
 
 
 class Csc(C.Structure):
@@ -59,7 +60,8 @@ class Control(C.Structure):
                 ("sample_stream", C.POINTER(C.c_uint32)), ("sample_stream_len", C.c_int64),
                 ("unif", UNIF_FN), ("unif_ctx", C.c_void_p), ("seed", C.c_uint32),
                 ("rng_state", C.POINTER(Rng)),
-                ("mode", C.c_int), ("batch", C.c_int64), ("device", C.c_int)]
+                ("mode", C.c_int), ("batch", C.c_int64), ("device", C.c_int),
+                ("losses_sink", LOSSES_FN), ("losses_ctx", C.c_void_p)]
 
 
 class Result(C.Structure):

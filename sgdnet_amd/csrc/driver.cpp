@@ -426,8 +426,8 @@ int validate(const sgdnet_control* c, const sgdnet_result* out, int y_cols) {
               c->family == SGDNET_MGAUSSIAN ? c->n_classes : 1);
     return SGDNET_EINVAL;
   }
-  if (c->debug && (!out->losses || !out->losses_len)) {
-    set_error("control.debug needs result.losses and result.losses_len");
+  if (c->debug && !c->losses_sink && (!out->losses || !out->losses_len)) {
+    set_error("control.debug needs control.losses_sink, or result.losses and result.losses_len");
     return SGDNET_EINVAL;
   }
   return SGDNET_OK;
@@ -657,7 +657,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   }
   std::vector<uint32_t> chunk((size_t)n);
   std::vector<double> w((size_t)(K * p)), b((size_t)K), xbb((size_t)K);
-  std::vector<double> losses(ctl->debug ? (size_t)ctl->max_iter : 0);
+  std::vector<double> losses;        // debug: grows with the epochs run, like the reference's vector (saga-sparse.h:364)
   double n_iter = 0.0;
   int64_t auto_window = batch;      // shrinks for good when a run blew up or a fit got worse
   double prev_dev = HUGE_VAL;
@@ -701,6 +701,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       t_rng += since(t0);
       t0 = now();
       unsigned ran = 0;
+      if (ctl->debug && losses.size() < (size_t)epochs + 1) losses.resize(std::max<size_t>(64, 2 * losses.size()));
       rc = sgdnet_solver_run(S, mode, batch, stream_off, n, 1, ctl->tol, &ran, &converged,
                              ctl->debug ? losses.data() + epochs : nullptr);
       if (rc) return rc;
@@ -775,10 +776,14 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     }
     auto t1 = now();
     out->return_codes[li] = (epochs == ctl->max_iter) ? 1.0 : 0.0;               // saga-sparse.h:376-382
-    if (ctl->debug) {
-      memcpy(out->losses + (size_t)li * ctl->max_iter, losses.data(), sizeof(double) * epochs);
-      out->losses_len[li] = (int32_t)epochs;
-    }
+    auto report_losses = [&]() {
+      if (!ctl->debug) return;
+      if (ctl->losses_sink) ctl->losses_sink(ctl->losses_ctx, li, losses.data(), (int)epochs);
+      if (out->losses && out->losses_len) {
+        memcpy(out->losses + (size_t)li * ctl->max_iter, losses.data(), sizeof(double) * epochs);
+        out->losses_len[li] = (int32_t)epochs;
+      }
+    };
 
     double dev = 0.0;
     rc = sgdnet_solver_deviance(S, &dev);                                        // sgdnet.cpp:246-256
@@ -808,6 +813,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     retries = 0;
     prev_dev = dev;
     n_iter += (double)epochs;          // epochs of the accepted run of this lambda only
+    report_losses();
     out->dev_ratio[li] = 1.0 - dev / null_dev_scaled;                            // :258
     out->lambda[li] = lambda[(size_t)li];
 

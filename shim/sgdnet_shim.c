@@ -12,8 +12,9 @@
  * and forwards to the C ABI of libsgdnet_hip.so (include/sgdnet_hip.h).  Nothing
  * else of the reference's src/ is needed; R/ stays untouched.
  *
- * Build (on a machine that has R; neither this container nor the GPU box does,
- * so this file is compiled by nobody here -- see INTEGRATION.md):
+ * Build on a machine that has R.  Neither this container nor the GPU box has
+ * R, so here the file is compiled against tests/rmock (a small mock of the R C API) by build.sh
+ * and driven end to end by tests/test_shim_mock.py / tests/test_gpu_shim.py:
  *
  *     R CMD SHLIB -o sgdnet.so sgdnet_shim.c -I<repo>/include \
  *         -L<repo>/sgdnet_amd/lib -lsgdnet_hip -Wl,-rpath,<repo>/sgdnet_amd/lib
@@ -34,6 +35,7 @@
 #include <Rinternals.h>
 #include <R_ext/Random.h>
 #include <R_ext/Rdynload.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "sgdnet_hip.h"
@@ -90,8 +92,42 @@ static void fill_control(SEXP control, sgdnet_control* c) {
   if (opt != R_NilValue) c->device = Rf_asInteger(opt);
 }
 
+/* Debug losses (options(sgdnet.debug = TRUE)): the backend reports each lambda's per-epoch losses
+ * through control.losses_sink when that lambda is done; they are kept in malloc'ed blocks sized by
+ * the epochs actually run (the reference grows a std::vector, src/saga-sparse.h:364 -- reserving
+ * n_lambda x max_iter would be 80 GB at the reference's benchmark setting maxit = 1e8).  No R API
+ * is called from the sink: an R error there would longjmp through the library's C++ frames. */
+typedef struct {
+  int      n_lambda;
+  double** values;
+  int*     count;
+  int      failed;
+} loss_store;
+
+static void loss_sink(void* ctx, int li, const double* losses, int count) {
+  loss_store* st = (loss_store*)ctx;
+  if (li < 0 || li >= st->n_lambda) return;
+  free(st->values[li]);                       /* a lambda that was run again replaces its record */
+  st->values[li] = (double*)malloc(sizeof(double) * (size_t)(count > 0 ? count : 1));
+  if (!st->values[li]) {
+    st->failed = 1;
+    st->count[li] = 0;
+    return;
+  }
+  memcpy(st->values[li], losses, sizeof(double) * (size_t)count);
+  st->count[li] = count;
+}
+
+static void loss_store_free(loss_store* st) {
+  if (!st->values) return;
+  for (int i = 0; i < st->n_lambda; ++i) free(st->values[i]);
+  free(st->values);
+  free(st->count);
+  st->values = NULL;
+}
+
 /* builds the list of src/sgdnet.cpp:275-284 from a filled sgdnet_result */
-static SEXP wrap_result(const sgdnet_control* c, const sgdnet_result* r, int K, R_xlen_t p) {
+static SEXP wrap_result(const sgdnet_control* c, const sgdnet_result* r, const loss_store* ls, int K, R_xlen_t p) {
   const int nl = c->n_lambda;
   SEXP out = PROTECT(Rf_allocVector(VECSXP, 8));
   SEXP names = PROTECT(Rf_allocVector(STRSXP, 8));
@@ -114,8 +150,8 @@ static SEXP wrap_result(const sgdnet_control* c, const sgdnet_result* r, int K, 
   SEXP losses = PROTECT(Rf_allocVector(VECSXP, c->debug ? nl : 0));
   if (c->debug)
     for (int i = 0; i < nl; ++i) {
-      SEXP l = PROTECT(Rf_allocVector(REALSXP, r->losses_len[i]));
-      memcpy(REAL(l), r->losses + (size_t)i * c->max_iter, sizeof(double) * r->losses_len[i]);
+      SEXP l = PROTECT(Rf_allocVector(REALSXP, ls->count[i]));
+      if (ls->count[i]) memcpy(REAL(l), ls->values[i], sizeof(double) * (size_t)ls->count[i]);
       SET_VECTOR_ELT(losses, i, l);
       UNPROTECT(1);
     }
@@ -140,10 +176,13 @@ static SEXP wrap_result(const sgdnet_control* c, const sgdnet_result* r, int K, 
 static SEXP run_fit(SEXP x, SEXP y, SEXP control, int sparse) {
   sgdnet_control c;
   fill_control(control, &c);
-  SEXP ydim = Rf_getAttrib(y, R_DimSymbol);
-  const int y_cols = INTEGER(ydim)[1];
+  int nprot = 0;
+  /* Rcpp::as<Eigen::MatrixXd> coerces silently (integer matrices, integer responses): do the same */
+  y = PROTECT(Rf_coerceVector(y, REALSXP));
+  ++nprot;
   R_xlen_t n, p;
   sgdnet_csc csc;
+  memset(&csc, 0, sizeof(csc));
   if (sparse) {                                   /* dgCMatrix slots, R/sgdnet.R:226 */
     SEXP dim = R_do_slot(x, Rf_install("Dim"));
     n = INTEGER(dim)[0];
@@ -155,10 +194,17 @@ static SEXP run_fit(SEXP x, SEXP y, SEXP control, int sparse) {
     csc.values = REAL(R_do_slot(x, Rf_install("x")));
   } else {
     SEXP dim = Rf_getAttrib(x, R_DimSymbol);
+    if (dim == R_NilValue || XLENGTH(dim) != 2) Rf_error("x must be a matrix");
     n = INTEGER(dim)[0];
     p = INTEGER(dim)[1];
+    x = PROTECT(Rf_coerceVector(x, REALSXP));
+    ++nprot;
   }
+  SEXP ydim = Rf_getAttrib(y, R_DimSymbol);       /* as.matrix(y) in R/sgdnet.R:344; a bare vector is n x 1 */
+  const int y_cols = (ydim == R_NilValue || XLENGTH(ydim) != 2) ? 1 : INTEGER(ydim)[1];
+  if (XLENGTH(y) != (R_xlen_t)n * y_cols) Rf_error("the number of samples in 'x' and 'y' must match");
   const int K = c.n_classes, nl = c.n_lambda;
+  if (K <= 0 || nl <= 0) Rf_error("control$n_classes and control$n_lambda must be positive");
   sgdnet_result r;
   memset(&r, 0, sizeof(r));
   /* R_alloc memory is reclaimed by R at the end of .Call, also on error */
@@ -167,16 +213,35 @@ static SEXP run_fit(SEXP x, SEXP y, SEXP control, int sparse) {
   r.lambda = (double*)R_alloc(nl, sizeof(double));
   r.dev_ratio = (double*)R_alloc(nl, sizeof(double));
   r.return_codes = (double*)R_alloc(nl, sizeof(double));
+  loss_store ls;
+  memset(&ls, 0, sizeof(ls));
   if (c.debug) {
-    r.losses = (double*)R_alloc((size_t)nl * c.max_iter, sizeof(double));
-    r.losses_len = (int32_t*)R_alloc(nl, sizeof(int32_t));
+    ls.n_lambda = nl;
+    ls.values = (double**)calloc((size_t)nl, sizeof(double*));
+    ls.count = (int*)calloc((size_t)nl, sizeof(int));
+    if (!ls.values || !ls.count) {
+      free(ls.values);
+      free(ls.count);
+      Rf_error("cannot allocate the debug-loss table");
+    }
+    c.losses_sink = loss_sink;
+    c.losses_ctx = &ls;
   }
   GetRNGstate();                                  /* Rcpp::RNGScope */
   int rc = sparse ? sgdnet_fit_sparse(&csc, REAL(y), y_cols, &c, &r)
                   : sgdnet_fit_dense(REAL(x), n, p, REAL(y), y_cols, &c, &r);
   PutRNGstate();
-  if (rc != SGDNET_OK) Rf_error("sgdnet (HIP backend): %s", sgdnet_last_error());
-  return wrap_result(&c, &r, K, p);
+  if (rc != SGDNET_OK || ls.failed) {
+    loss_store_free(&ls);
+    Rf_error("sgdnet (HIP backend): %s", rc != SGDNET_OK ? sgdnet_last_error() : "out of memory for debug losses");
+  }
+  /* (an R allocation failure inside wrap_result would leak the malloc'ed loss blocks; everything
+   * else is R_alloc/PROTECT memory that R reclaims) */
+  SEXP out = PROTECT(wrap_result(&c, &r, &ls, K, p));
+  ++nprot;
+  loss_store_free(&ls);
+  UNPROTECT(nprot);
+  return out;
 }
 
 SEXP _sgdnet_SgdnetDense(SEXP x, SEXP y, SEXP control) { return run_fit(x, y, control, 0); }
