@@ -234,7 +234,9 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
                                 double* sweep_ms, int* sweep_launches);
 
 /* Which gather kernel a batch of `batch` draws uses: 0 = saga_batch_gather_kernel (global
- * atomics), 1 = saga_batch_gather_lds_kernel (LDS-privatised scatter). */
+ * atomics), 1 = saga_batch_gather_lds_kernel (LDS-privatised scatter), 2 = the binned form
+ * (saga_binned_gather_kernel + saga_binned_sweep_kernel: K x p tables that fit no LDS; valid after a
+ * run / enqueue with that batch has sized its scratch). */
 int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch);
 
 /* 2 * sum_i Loss_i (src/utils.h:304-329) over the resident samples. */

@@ -91,6 +91,17 @@ struct SagaDev {
   double* cw;       // 2 x 16 x K  slots of c.w (implicit centring in batched mode)
   int* claim;     // n     first-occurrence claims (K > 1)
   const uint32_t* stream;
+  // binned form of the batched iteration (saga_batched.hip "binned"): K x p tables that fit no
+  // LDS are split into R feature ranges; the gather bins every non-zero of the batch by range
+  // and one workgroup per range accumulates its slice of D in LDS and sweeps it.  R == 0: off.
+  int R;
+  const int64_t* bin_off;      // R + 1: first entry of every bin (capacity follows the range's non-zero mass)
+  const int32_t* range_lo;     // R + 1 feature boundaries
+  const uint16_t* feat_range;  // p: range of every feature
+  char* bins;                  // bin_off[R] entries {u32 draw, u32 feature, f64 value}
+  unsigned* bin_count;         // R entries used (reset by the range's sweep)
+  double* gcb;                 // batch x K: gradient change of every draw of the batch
+  int* bin_err;                // set when a bin overflowed (the epoch is then invalid)
 };
 
 // Per-lambda parameters; lives in device memory so captured graphs stay valid
@@ -158,6 +169,10 @@ int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
 int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st);
 int launch_delta_apply(const SagaDev& d, double* ref, const double* merged, double w_weight, hipStream_t st);
 int batched_max_classes();
+// binned form: is it the form launch_batch_gather / launch_batch_sweep would use for m draws?
+bool binned_active(const SagaDev& d, int m);
+int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_t st);
+size_t binned_max_range_features(int K);
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,
                     int gens = 1);

@@ -1791,6 +1791,269 @@ __global__ __launch_bounds__(kBlock) void saga_delta_apply_kernel(SagaDev d, dou
   }
 }
 
+// --------------------------------------------------------------------------
+// Binned form: K x p tables that fit no LDS (config 5: K = 10, p = 100 000 -> 8 MB).
+//
+// With the scatter accumulator in global memory every non-zero of every draw costs K fp64
+// atomics, and those execute at the memory side at a fixed chip-wide byte rate (~1.3 TB/s of
+// added bytes, MI355X_MICROARCH.md "Global float atomics"): 800 B per draw at K = 10, z = 10,
+// i.e. < 1.6 G draws/s whatever the kernel does.  Here the features are cut into R contiguous
+// ranges of equal non-zero mass whose K x width slice fits a workgroup's LDS, and a batch runs
+// as two kernels without a single global fp atomic:
+//
+//   gather+bin  (a workgroup per 512 draws, class-lane form): record, x.w from the L2-resident
+//               w, gradient, gradient-memory update; the draw's gradient change goes to
+//               gcb[t][0..K) and every non-zero becomes a 16-byte entry {t, j, x_tj} staged in
+//               LDS, counted per range, and written out behind ONE returning atomic per
+//               (workgroup, range) that reserves the run's place in the range's bin;
+//   range sweep (a workgroup per range): D[:, lo..hi) in LDS <- sum over the bin's entries of
+//               x_tj * gcb[t] (ds_add_f64), then the reference's per-feature update
+//               (saga-sparse.h:316-335 / penalties.h via sweep_feature) for its own features,
+//               the intercept and centring scalars exactly as in the other sweep kernels.
+//
+// The entries of a batch (~16 B x z per draw) are written and read once and stay in the
+// Infinity Cache between the two kernels; the sums are order-dependent in the last bits like
+// every other scatter of this file.
+// --------------------------------------------------------------------------
+struct __attribute__((aligned(16))) BinEntry {
+  uint32_t t;   // draw index inside the batch
+  uint32_t j;   // feature
+  double x;
+};
+static_assert(sizeof(BinEntry) == 16, "bin entries are 16 bytes");
+
+constexpr int kBinBlock = 1024;      // gather+bin: 64 draws in flight per workgroup
+constexpr int kBinDraws = 512;       // draws per gather workgroup
+constexpr int kBinEntCap = 7168;     // LDS staging capacity (entries); beyond it entries go out one by one
+constexpr int kRangeBlock = 512;     // range sweep
+constexpr size_t kRangeLdsBytes = 64 * 1024;
+
+size_t binned_max_range_features(int K) { return kRangeLdsBytes / (sizeof(double) * (size_t)K); }
+
+__global__ __launch_bounds__(256) void col_count_kernel(const int32_t* idx, int64_t nnz, unsigned* counts) {
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * 256)
+    atomicAdd(counts + idx[q], 1u);
+}
+
+int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_t st) {
+  SGD_HIP_TRY(hipMemsetAsync(counts, 0, sizeof(unsigned) * (size_t)d.p, st));
+  int64_t grid = (nnz + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(col_count_kernel, dim3((unsigned)grid), dim3(256), 0, st, d.idx, nnz, counts);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+// every lane of the group visits its share of the row: f(j, v) on the lanes that hold an entry
+template <class F>
+__device__ __forceinline__ void row_for_each_lane(const SagaDev& d, const char* base, int nnz, int ovf, int gl,
+                                                  F f) {
+  const int cap = d.rec_cap;
+  const int cnt0 = nnz < cap ? nnz : cap;
+  const int* ridx = reinterpret_cast<const int*>(base + 16);
+  const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
+  for (int e = gl; e < cnt0; e += kGroup) f((uint32_t)ridx[e], rval[e]);
+  int rem = nnz - cnt0;
+  while (rem > 0) {
+    const char* ob = d.ovf + (size_t)ovf * kOvfStride;
+    const int next = reinterpret_cast<const int*>(ob)[0];
+    const int c = reinterpret_cast<const int*>(ob)[1];
+    const int* oi = reinterpret_cast<const int*>(ob + 8);
+    const double* ov = reinterpret_cast<const double*>(ob + 8 + 4 * kOvfCap);
+    for (int e = gl; e < c; e += kGroup) f((uint32_t)oi[e], ov[e]);
+    rem -= c;
+    ovf = next;
+  }
+}
+
+// one entry straight into its bin (staging full, or the rare row longer than the staging)
+__device__ __forceinline__ void bin_push_global(const SagaDev& d, const BinEntry& en) {
+  const unsigned r = d.feat_range[en.j];
+  const unsigned pos = atomicAdd(d.bin_count + r, 1u);
+  const int64_t b0 = d.bin_off[r];
+  if ((int64_t)pos < d.bin_off[r + 1] - b0) reinterpret_cast<BinEntry*>(d.bins)[b0 + pos] = en;
+  else atomicExch(d.bin_err, 1);
+}
+
+__global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d, const LamParams* lamp,
+                                                                       int64_t t0_in_epoch, int m,
+                                                                       int batch_id_offset) {
+  extern __shared__ __attribute__((aligned(16))) char bsm[];
+  __shared__ double d0s[16];
+  __shared__ unsigned n_ent;
+  BinEntry* ent = reinterpret_cast<BinEntry*>(bsm);
+  unsigned* cnt = reinterpret_cast<unsigned*>(bsm + sizeof(BinEntry) * kBinEntCap);
+  unsigned* rbase = cnt + d.R;
+  const int K = d.K;
+  const int gl = threadIdx.x & (kGroup - 1);
+  const int group = threadIdx.x / kGroup;
+  const int lane = threadIdx.x & 63;
+  const bool lane_on = gl < K;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  for (int r = threadIdx.x; r < d.R; r += kBinBlock) cnt[r] = 0u;
+  if (threadIdx.x < 16) d0s[threadIdx.x] = 0.0;
+  if (threadIdx.x == 0) n_ent = 0u;
+  __syncthreads();
+  const double bl = lane_on ? d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0) : 0.0;
+  if (d.standardize) cw_clear_next(d, batch_id);
+
+  const int lo = blockIdx.x * kBinDraws;
+  const int hi = (lo + kBinDraws < m) ? lo + kBinDraws : m;
+  double gct = 0.0;
+  for (int i = lo + group; i < hi; i += kBinBlock / kGroup) {
+    const uint32_t s = d.stream[t0 + i];
+    const char* base = d.rec + (size_t)s * d.rec_stride;
+    int prev = batch_id;
+    if (gl == 0)
+      prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mold = lane_on ? d.M[gl + (int64_t)s * K] : 0.0;
+    const double y0 = *reinterpret_cast<const double*>(base);
+    const int nnz = *reinterpret_cast<const int*>(base + 8);
+    const int ovf = *reinterpret_cast<const int*>(base + 12);
+    double acc = 0.0;
+    row_for_each_uniform(d, base, nnz, ovf, [&](int64_t j, double v) {
+      if (lane_on) acc += v * d.w[j * K + gl];
+    });
+    const double lp = acc + bl;
+    double g;
+    if (d.family == SGDNET_MULTINOMIAL) {
+      const double mx = group_max(lane_on ? lp : -HUGE_VAL);
+      const double ssum = group_sum(lane_on ? exp(lp - mx) : 0.0);
+      const double lse = log(ssum) + mx;
+      g = exp(lp - lse);
+      if ((unsigned)gl == (unsigned)(y0 + 0.5)) g -= 1.0;
+    } else if (d.family == SGDNET_BINOMIAL) {
+      g = 1.0 - y0 - 1.0 / (1.0 + exp(lp));
+    } else {
+      g = lp - (lane_on ? d.y[(int64_t)s * d.Ky + gl] : 0.0);
+    }
+    const int first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
+    if (!first) continue;          // a repeat inside the batch: same snapshot, gradient change 0
+    double gc = 0.0;
+    if (lane_on) {
+      gc = g - mold;
+      d.M[gl + (int64_t)s * K] = g;
+      d.gcb[(int64_t)i * K + gl] = gc;
+    }
+    gct += gc;
+    // one entry per non-zero: lanes of the group take entries gl, gl + 16, ...; the slots of a
+    // wavefront's entries are reserved with one LDS atomic
+    row_for_each_lane(d, base, nnz, ovf, gl, [&](uint32_t j, double v) {
+      const unsigned long long mask = __ballot(1);
+      const int leader = __ffsll((long long)mask) - 1;
+      unsigned slot0 = 0u;
+      if (lane == leader) slot0 = atomicAdd(&n_ent, (unsigned)__popcll(mask));
+      slot0 = (unsigned)__shfl((int)slot0, leader, 64);
+      const unsigned slot = slot0 + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+      const BinEntry en{(uint32_t)i, j, v};
+      if (slot < (unsigned)kBinEntCap) {
+        ent[slot] = en;
+        atomicAdd(cnt + d.feat_range[j], 1u);
+      } else {
+        bin_push_global(d, en);
+      }
+    });
+  }
+  if (gct != 0.0) __hip_atomic_fetch_add(&d0s[gl], gct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();
+  // reserve this workgroup's run in every bin it has entries for, then place the entries
+  for (int r = threadIdx.x; r < d.R; r += kBinBlock) {
+    const unsigned c = cnt[r];
+    rbase[r] = c ? atomicAdd(d.bin_count + r, c) : 0u;
+    cnt[r] = 0u;
+  }
+  __syncthreads();
+  const unsigned staged = n_ent < (unsigned)kBinEntCap ? n_ent : (unsigned)kBinEntCap;
+  for (unsigned e = threadIdx.x; e < staged; e += kBinBlock) {
+    const BinEntry en = ent[e];
+    const unsigned r = d.feat_range[en.j];
+    const unsigned pos = rbase[r] + atomicAdd(cnt + r, 1u);
+    const int64_t b0 = d.bin_off[r];
+    if ((int64_t)pos < d.bin_off[r + 1] - b0) reinterpret_cast<BinEntry*>(d.bins)[b0 + pos] = en;
+    else atomicExch(d.bin_err, 1);
+  }
+  if ((d.fit_intercept || d.standardize) && (int)threadIdx.x < K)
+    d0_publish(d, batch_id, threadIdx.x, d0s[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
+                                                                        int n_parts, int batch_id_offset) {
+  extern __shared__ __attribute__((aligned(16))) double Dl[];
+  __shared__ double sh_d0[16];
+  const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
+  const int K = d.K;
+  const int r = blockIdx.x;
+  const int lo = d.range_lo[r], hi = d.range_lo[r + 1];
+  const int E = (hi - lo) * K;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
+  for (int i = threadIdx.x; i < E; i += kRangeBlock) Dl[i] = 0.0;
+  if (need_d0) block_d0<kRangeBlock>(d, n_parts, batch_id, sh_d0);
+  __syncthreads();
+  // ---- the bin's entries into the LDS slice: a 16-lane group per entry, lane = class ----
+  const int gl = threadIdx.x & (kGroup - 1);
+  const int group = threadIdx.x / kGroup;
+  constexpr int kGroups = kRangeBlock / kGroup;
+  unsigned cntb = d.bin_count[r];
+  const int64_t b0 = d.bin_off[r], bcap = d.bin_off[r + 1] - b0;
+  if ((int64_t)cntb > bcap) cntb = (unsigned)bcap;
+  const BinEntry* bin = reinterpret_cast<const BinEntry*>(d.bins) + b0;
+  const bool lane_on = gl < K;
+  unsigned e = group;
+  for (; e + 3 * kGroups < cntb; e += 4 * kGroups) {          // four entries in flight per group
+    const BinEntry e0 = bin[e], e1 = bin[e + kGroups], e2 = bin[e + 2 * kGroups], e3 = bin[e + 3 * kGroups];
+    if (lane_on) {
+      const double g0 = d.gcb[(int64_t)e0.t * K + gl], g1 = d.gcb[(int64_t)e1.t * K + gl];
+      const double g2 = d.gcb[(int64_t)e2.t * K + gl], g3 = d.gcb[(int64_t)e3.t * K + gl];
+      scatter_add<true>(Dl + ((int)e0.j - lo) * K + gl, e0.x * g0);
+      scatter_add<true>(Dl + ((int)e1.j - lo) * K + gl, e1.x * g1);
+      scatter_add<true>(Dl + ((int)e2.j - lo) * K + gl, e2.x * g2);
+      scatter_add<true>(Dl + ((int)e3.j - lo) * K + gl, e3.x * g3);
+    }
+  }
+  for (; e < cntb; e += kGroups) {
+    const BinEntry e0 = bin[e];
+    if (lane_on) scatter_add<true>(Dl + ((int)e0.j - lo) * K + gl, e0.x * d.gcb[(int64_t)e0.t * K + gl]);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) d.bin_count[r] = 0u;                 // the next batch fills the bin again
+  // ---- per-feature update of this range ----
+  double cwp[16];
+  for (int k = 0; k < K; ++k) cwp[k] = 0.0;
+  if (q.penalty == SGDNET_GROUPLASSO) {
+    for (int f = threadIdx.x; f < hi - lo; f += kRangeBlock) {
+      const int64_t j = lo + f;
+      double dj[16], wn[16];
+      const double cj = d.standardize ? d.c[j] : 0.0;
+      for (int k = 0; k < K; ++k) dj[k] = Dl[f * K + k] - (d.standardize ? cj * sh_d0[k] : 0.0);
+      sweep_feature(d, q, j, dj, wn);
+      for (int k = 0; k < K; ++k) cwp[k] += cj * wn[k];
+    }
+  } else {
+    const double tau = q.beta * q.gamma * q.ls_m, gls = q.gamma * q.ls_m;
+    for (int i = threadIdx.x; i < E; i += kRangeBlock) {
+      const int f = i / K, k = i - f * K;
+      const int64_t t = (int64_t)lo * K + i;
+      const double cj = d.standardize ? d.c[lo + f] : 0.0;
+      const double dk = Dl[i] - (d.standardize ? cj * sh_d0[k] : 0.0);
+      double v = q.r_m * d.w[t] - gls * d.G[t] - q.gamma * dk;
+      if (q.penalty == SGDNET_ELASTICNET) v = soft_threshold(v, tau);
+      d.w[t] = v;
+      if (dk != 0.0) d.G[t] += dk / q.n_d;
+      if (d.standardize)
+        for (int kk = 0; kk < K; ++kk) cwp[kk] += kk == k ? cj * v : 0.0;
+    }
+  }
+  if (d.standardize) cw_accumulate<kRangeBlock>(d, batch_id, cwp);
+  if (blockIdx.x == 0) {
+    if (d.fit_intercept) sweep_intercept(d, q, sh_d0);
+    double* nxt = d0_set(d, batch_id + 1);
+    for (int i = threadIdx.x; i < kD0Slots * K; i += kRangeBlock) nxt[i] = 0.0;
+  }
+}
+
 // ------------------------------ launchers ---------------------------------
 int batched_max_classes() { return 16; }
 
@@ -1798,6 +2061,7 @@ int batched_max_classes() { return 16; }
 // needs the dense K*p table in LDS twice per CU (2 workgroups per CU) and enough
 // draws per workgroup to amortise its flush.
 struct GatherPlan {
+  bool binned;  // range-binned form (tables that fit no LDS)
   bool lds;     // per-workgroup LDS copies of D flushed as slabs (sparse LDS form and dense form)
   bool dense;   // dense x: saga_batch_gather_dense_kernel
   bool w_lds;   // K == 1: the coefficient snapshot is staged in LDS as well
@@ -1835,6 +2099,14 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
   }
   // worthwhile once the batch's non-zeros outnumber the table ~48x: below that the fixed
   // cost of writing and re-reading one table per workgroup exceeds the atomics it saves
+  if (d.R > 0 && d.bins && !d.force_global && force != 2) {
+    g.binned = true;
+    g.draws_per_block = kBinDraws;
+    g.grid = (m + kBinDraws - 1) / kBinDraws;
+    if (g.grid < 1) g.grid = 1;
+    g.lds_bytes = sizeof(BinEntry) * (size_t)kBinEntCap + 2 * sizeof(unsigned) * (size_t)d.R;
+    return g;
+  }
   const bool pays = (double)m * (double)d.avg_nnz >= 48.0 * (double)d.K * (double)d.p;
   g.lds = d.slab != nullptr && !d.force_global && fits && force != 2 && (force == 1 || pays);
   if (g.lds) {
@@ -1856,6 +2128,7 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
 }
 
 int batch_gather_blocks(const SagaDev& d, int m) { return plan_gather(d, m).grid; }
+bool binned_active(const SagaDev& d, int m) { return !d.xd && plan_gather(d, m).binned; }
 
 // Doubles of slab storage the LDS-privatised gather needs for batches of m draws (0: the
 // global-atomic form is used).
@@ -1938,6 +2211,22 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;
   }
+  if (g.binned) {
+    static bool battr_done_dev[64] = {};
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (!battr_done_dev[cur & 63]) {
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_gather_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRangeLdsBytes));
+      battr_done_dev[cur & 63] = true;
+    }
+    hipExtLaunchKernelGGL(saga_binned_gather_kernel, dim3(g.grid), dim3(kBinBlock), g.lds_bytes, st, ev0, ev1, 0, d,
+                          lam, t0_in_epoch, m, batch_id_offset);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
+  }
   if (g.lds) {
     static bool attr_done_dev[64] = {};
     int cur_dev = 0;
@@ -2003,6 +2292,12 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
   // may differ by one workgroup, so all of them are read (unused slots are zero)
   const int n_parts = ov_m > 0.0 ? kD0Slots : (g.grid < kD0Slots ? g.grid : kD0Slots);
   const SweepOverride ov{ov_r, ov_ls, ov_m};
+  if (g.binned) {
+    hipExtLaunchKernelGGL(saga_binned_sweep_kernel, dim3(d.R), dim3(kRangeBlock), kRangeLdsBytes, st, ev0, ev1, 0,
+                          d, lam, tail, n_parts, batch_id_offset);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
+  }
   if (g.lds) {
     const int F = kSlabElems / d.K;
     const int grid = (int)((d.p + F - 1) / F);

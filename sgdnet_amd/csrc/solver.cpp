@@ -92,6 +92,11 @@ struct sgdnet_solver {
   std::vector<void*> vs_owned;  // virtual-shard replicas
   int64_t vs_period = 0;        // draws per shard between device-side merges (0: n / 32)
   double* own_d0 = nullptr;
+  // binned form (saga_batched.hip): ranges built once, bins sized for the current batch
+  bool bin_ranges_ready = false;
+  int64_t bin_batch = 0;        // the batch the bins and gcb were sized for
+  void* bin_bufs[3] = {nullptr, nullptr, nullptr};   // bins, gcb, bin_off
+  std::vector<double> bin_mass;  // non-zeros of every feature range
 };
 
 namespace {
@@ -157,6 +162,100 @@ void drop_graph(sgdnet_solver* s) {
   s->gexec = nullptr;
 }
 
+// Binned form of the batched iteration for K x p tables that fit no LDS (saga_batched.hip
+// "Binned form").  Ranges: contiguous features of equal non-zero mass, at most
+// binned_max_range_features(K) wide; built once per solver from a device histogram of the feature
+// ids.  Bins and the gradient-change buffer are sized for the batch.
+int ensure_binned(sgdnet_solver* s, int64_t batch) {
+  SagaDev& d = s->d;
+  static const int allow = [] { const char* e = getenv("SGDNET_BINNED"); return e ? atoi(e) : 1; }();
+  const bool want = allow && s->sparse && !d.xd && d.rec && d.idx && d.K <= 16 && !d.force_global &&
+                    sizeof(double) * (size_t)d.K * (size_t)d.p > 80 * 1024 && batch >= 4096 && d.p < (1ll << 31);
+  if (!want) {
+    if (d.R > 0 && d.bins) {             // e.g. a tiny batch after a large one: fall back to the atomic form
+      d.bins = nullptr;
+      drop_graph(s);
+    }
+    return SGDNET_OK;
+  }
+  if (!s->bin_ranges_ready) {
+    unsigned* counts = nullptr;
+    int rc = dev_alloc(s, &counts, (size_t)d.p, false);
+    if (rc) return rc;
+    rc = launch_col_count(d, s->nnz, counts, s->st);
+    if (rc) return rc;
+    std::vector<unsigned> h((size_t)d.p);
+    SGD_HIP_TRY(hipMemcpyAsync(h.data(), counts, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost, s->st));
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    const int64_t fmax = (int64_t)binned_max_range_features(d.K);
+    const int target = 256;                         // one range sweep workgroup per CU
+    const double per = std::max(1.0, (double)s->nnz / target);
+    std::vector<int32_t> lo{0};
+    std::vector<uint16_t> fr((size_t)d.p);
+    double mass = 0.0;
+    int64_t width = 0;
+    for (int64_t j = 0; j < d.p; ++j) {
+      if (width > 0 && (width >= fmax || mass + 0.5 * h[(size_t)j] >= per)) {
+        lo.push_back((int32_t)j);
+        mass = 0.0;
+        width = 0;
+      }
+      fr[(size_t)j] = (uint16_t)(lo.size() - 1);
+      mass += h[(size_t)j];
+      ++width;
+    }
+    lo.push_back((int32_t)d.p);
+    const int R = (int)lo.size() - 1;
+    s->bin_mass.assign((size_t)R, 0.0);
+    for (int64_t j = 0; j < d.p; ++j) s->bin_mass[fr[(size_t)j]] += h[(size_t)j];
+    if (R > 4096) return SGDNET_OK;                  // staging counters of the gather would not fit: atomic form
+    int32_t* lo_dev = nullptr;
+    uint16_t* fr_dev = nullptr;
+    rc = dev_upload(s, &lo_dev, lo.data(), lo.size());
+    if (!rc) rc = dev_upload(s, &fr_dev, fr.data(), fr.size());
+    unsigned* bc = nullptr;
+    int* be = nullptr;
+    if (!rc) rc = dev_alloc(s, &bc, (size_t)R, true);
+    if (!rc) rc = dev_alloc(s, &be, 1, true);
+    if (rc) return rc;
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));        // the uploads read host vectors that die here
+    d.R = R;
+    d.range_lo = lo_dev;
+    d.feat_range = fr_dev;
+    d.bin_count = bc;
+    d.bin_err = be;
+    s->bin_ranges_ready = true;
+    if (getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet]   binned form: %d feature ranges (<= %lld features each)\n", R, (long long)fmax);
+  }
+  if (d.R <= 0) return SGDNET_OK;
+  if (batch != s->bin_batch || !s->bin_bufs[0]) {
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    for (void*& q : s->bin_bufs) {
+      if (q) (void)hipFree(q);
+      q = nullptr;
+    }
+    // a batch's draws are distinct samples picked uniformly: range r receives about
+    // batch * mass_r / n entries; capacity = that mean + 8 standard deviations + slack (a range
+    // that holds one very frequent feature gets the room it needs)
+    std::vector<int64_t> off((size_t)d.R + 1, 0);
+    for (int r = 0; r < d.R; ++r) {
+      const double mean = (double)batch * s->bin_mass[(size_t)r] / (double)d.n;
+      off[(size_t)r + 1] = off[(size_t)r] + (int64_t)(mean + 8.0 * std::sqrt(mean) + 512.0);
+    }
+    SGD_HIP_TRY(hipMalloc(&s->bin_bufs[0], (size_t)16 * (size_t)off[(size_t)d.R]));
+    SGD_HIP_TRY(hipMalloc(&s->bin_bufs[1], sizeof(double) * (size_t)batch * (size_t)d.K));
+    SGD_HIP_TRY(hipMalloc(&s->bin_bufs[2], sizeof(int64_t) * off.size()));
+    SGD_HIP_TRY(hipMemcpy(s->bin_bufs[2], off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice));
+    s->bin_batch = batch;
+    drop_graph(s);
+  }
+  if (!d.bins) drop_graph(s);
+  d.bins = static_cast<char*>(s->bin_bufs[0]);
+  d.gcb = static_cast<double*>(s->bin_bufs[1]);
+  d.bin_off = static_cast<const int64_t*>(s->bin_bufs[2]);
+  return SGDNET_OK;
+}
+
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   if (s->d.V > 1 && vs_eligible(s->d, (int)batch)) {
@@ -182,6 +281,10 @@ int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
     return SGDNET_OK;
   }
   if (batch > draws) batch = draws;
+  {
+    const int rcb = ensure_binned(s, batch);
+    if (rcb) return rcb;
+  }
   // scratch must cover the full batches AND the tail batch, whose launch geometry (and even
   // its gather form) can differ
   const int64_t tail_m = draws - (draws / batch) * batch;
@@ -722,6 +825,8 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
   if (s->d.slab) (void)hipFree(s->d.slab);
+  for (void* q : s->bin_bufs)
+    if (q) (void)hipFree(q);
   for (void* q : s->vs_owned) (void)hipFree(q);
   if (s->lam_stage) (void)hipHostFree(s->lam_stage);
   for (hipEvent_t ev : s->lam_ev)
@@ -970,6 +1075,8 @@ int solver_rng_close(sgdnet_solver* s, sgdnet_rng* rng) {
 
 extern "C" {
 
+static int check_bins(sgdnet_solver* s);
+
 int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_offset,
                       int64_t draws_per_epoch, unsigned max_epochs, double tol, unsigned* epochs_run,
                       int* converged_out, double* losses) {
@@ -1081,6 +1188,8 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       const auto tc0 = std::chrono::steady_clock::now();
       rc = device_convergence(s, tol, &converged);
       if (rc) return rc;
+      rc = check_bins(s);
+      if (rc) return rc;
       g_trace_conv += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
       if (tr) {
         float ms = 0.f;
@@ -1132,11 +1241,26 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   return SGDNET_OK;
 }
 
+// binned form: a bin that overflowed dropped entries -- the epoch's result is not the algorithm's
+static int check_bins(sgdnet_solver* s) {
+  if (s->d.R <= 0 || !s->d.bins || !s->d.bin_err) return SGDNET_OK;
+  int flag = 0;
+  SGD_HIP_TRY(hipMemcpyAsync(&flag, s->d.bin_err, sizeof(int), hipMemcpyDeviceToHost, s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  if (flag) {
+    SGD_HIP_TRY(hipMemsetAsync(s->d.bin_err, 0, sizeof(int), s->st));
+    set_error("batched mode (binned form): a feature range received more entries in one batch than its bin holds; "
+              "set SGDNET_BINNED=0 or pass a smaller control.batch");
+    return SGDNET_EUNSUPPORTED;
+  }
+  return SGDNET_OK;
+}
+
 int sgdnet_solver_sync(sgdnet_solver* s) {
   if (!s) return SGDNET_EINVAL;
   SGD_HIP_TRY(hipSetDevice(s->device));
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
-  return SGDNET_OK;
+  return check_bins(s);
 }
 
 int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_offset,
@@ -1225,6 +1349,7 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
 
 int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch) {
   if (!s || batch < 1) return 0;
+  if (binned_active(s->d, (int)batch)) return 2;
   return batch_gather_slab_doubles(s->d, (int)batch) > 0 ? 1 : 0;
 }
 

@@ -205,8 +205,8 @@ class SagaSolver:
         form = self._L.sgdnet_solver_gather_form(self._h, min(batch, draws))
         return dict(gather_ms=g.value, gather_launches=ng.value, sweep_ms=w.value,
                     sweep_launches=nw.value,
-                    gather_kernel=("saga_batch_gather_lds_kernel" if form == 1
-                                   else "saga_batch_gather_kernel"))
+                    gather_kernel={1: "saga_batch_gather_lds_kernel", 2: "saga_binned_gather_kernel"}.get(
+                        form, "saga_batch_gather_kernel"))
 
     def deviance(self):
         out = C.c_double(0)
