@@ -43,6 +43,9 @@ WORKLOADS = {
     # name: (n, p, density, family, K, seed)
     "C4": (10_000_000, 10_000, 0.001, "binomial", 1, 4),
     "C3": (1_000_000, 1_000, 0.01, "binomial", 1, 3),
+    # BASELINE config 5 (one GPU holds it: ~25 GB resident) and a 25x smaller problem of the same shape
+    "C5": (50_000_000, 100_000, 0.0001, "multinomial", 10, 5),
+    "C5s": (2_000_000, 100_000, 0.0001, "multinomial", 10, 5),
     "tiny": (100_000, 1_000, 0.01, "binomial", 1, 7),
 }
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -142,18 +145,22 @@ def main():
     mix, lam = 0.5, 1.0 / n
     a_l2, b_l1 = (1.0 - mix) * lam, mix * lam
     row_sq = np.add.reduceat(prob["val"] ** 2, prob["ptr"][:-1])
-    stats = torch.tensor([float(row_sq.max()), float(prob["y"].sum())], dtype=torch.float64,
-                         device=red_dev)
+    # class counts (multinomial) or the sum of the 0/1 response (binomial)
+    ycount = (np.bincount(prob["y"].ravel().astype(np.int64), minlength=K) if family == "multinomial"
+              else np.array([prob["y"].sum()])).astype(np.float64)
+    mx = torch.tensor([float(row_sq.max())], dtype=torch.float64, device=red_dev)
+    sm = torch.tensor(ycount, dtype=torch.float64, device=red_dev)
     if world > 1:
-        mx = stats[:1].clone()
-        sm = stats[1:].clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(sm, op=dist.ReduceOp.SUM)
-        stats = torch.cat([mx, sm])
-    max_sq, ysum = float(stats[0]), float(stats[1])
+    max_sq = float(mx[0])
     gamma = D.step_size(max_sq, a_l2, True, family, n)          # src/utils.h:31-51
-    ybar = min(max(ysum / n, 1e-9), 1 - 1e-9)
-    b0 = np.array([np.log(ybar / (1 - ybar))])                  # families.h:190-201
+    if family == "multinomial":                                  # families.h:287-298
+        lpi = np.log(np.asarray(sm.cpu()) / n)
+        b0 = lpi - lpi.mean()
+    else:
+        ybar = min(max(float(sm[0]) / n, 1e-9), 1 - 1e-9)
+        b0 = np.array([np.log(ybar / (1 - ybar))])              # families.h:190-201
 
     # staleness window: the library's default rule, 2 * L_max / diag(X'X/n) clamped to 65536
     col_sq = np.bincount(prob["idx"], weights=prob["val"] ** 2, minlength=p)
@@ -317,7 +324,8 @@ def main():
             # memory-side atomic units sustain 21.7 G/s alone (profiles/r01_microbench.txt), i.e.
             # 21.7e9 x bytes-per-draw with nothing else on the fabric
             "ceilings": {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0,
-                         "one_returning_exchange_per_draw": 21.72 * alg_bytes_epoch / max(1, n_local)},
+                         "one_returning_exchange_per_draw": 21.72 * alg_bytes_epoch / max(1, n_local)} if K == 1 else
+                        {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0},
         },
     }
 
@@ -399,15 +407,25 @@ def main():
         st = po.new_state(K, p, n_local)
         st["intercept"][:] = b0
         ce = max(1, args.cpu_epochs)
+        # bounded sample (10-30 s of one core): at most 2e7 inner iterations of the reference loop;
+        # on config 5 that is a fraction of one epoch, run as the first draws of the same stream
+        cpu_draws = min(ce * n_local, 20_000_000)
         tc = time.perf_counter()
-        po.saga(X, prob["y"], st, family=family, penalty="elasticnet", gamma=gamma, alpha=a_l2,
-                beta=b_l1, fit_intercept=True, max_iter=ce, tol=0.0, stream=stream[:n_local * ce])
+        if cpu_draws == ce * n_local:
+            po.saga(X, prob["y"], st, family=family, penalty="elasticnet", gamma=gamma, alpha=a_l2,
+                    beta=b_l1, fit_intercept=True, max_iter=ce, tol=0.0, stream=stream[:cpu_draws])
+        else:
+            # the first cpu_draws inner iterations of the epoch, on the whole data set
+            po.saga(X, prob["y"], st, family=family, penalty="elasticnet", gamma=gamma, alpha=a_l2,
+                    beta=b_l1, fit_intercept=True, max_iter=1, tol=0.0, stream=stream[:cpu_draws],
+                    epoch_len=cpu_draws)
         tc = time.perf_counter() - tc
+        cpu_bytes = D.algorithmic_bytes(S.row_nnz, stream[:cpu_draws], K)
         out["cpu_baseline"] = {
-            "value": ce / tc, "unit": "epochs/s", "cores": 1, "kind": "port",
-            "sample": f"{ce} epochs ({ce * n_local} inner iterations) of the same workload and "
+            "value": cpu_draws / n_local / tc, "unit": "epochs/s", "cores": 1, "kind": "port",
+            "sample": f"{cpu_draws / n_local:.3g} epochs ({cpu_draws} inner iterations) of the same workload and "
                       f"sample stream, exact reference iteration, gcc -O2, {tc:.1f} s",
-            "algorithmic_gbps": alg_bytes_epoch * ce / tc / 1e9,
+            "algorithmic_gbps": cpu_bytes / tc / 1e9,
             "host_cpus": os.cpu_count(),
         }
     if rank == 0:

@@ -120,8 +120,13 @@ def batch_factors(alpha, gamma, m):
 
 def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True,
          standardize=False, x_center_scaled=None, max_iter=1, tol=0.0, stream=None, rng=None,
-         batch=0, debug=False, n_total=0):
+         batch=0, debug=False, n_total=0, epoch_len=None):
     """Run the SAGA loop for one (gamma, alpha, beta) on sample-major data.
+
+    epoch_len (timing only, bench.py's bounded cpu_baseline on config 5): the inner loop runs
+    epoch_len iterations per epoch instead of n_samples, drawing from the whole data set through an
+    explicit `stream`; the gradient average is then normalised by epoch_len, so the result is not a
+    SAGA iterate of the full problem -- the work per iteration is.
 
     x: scipy.sparse CSC of shape (p, n) (column i = sample i) or dense ndarray (p, n)
        in Fortran order (sample i contiguous).
@@ -136,8 +141,10 @@ def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True
     K = state["w"].shape[0]
     sparse = sp.issparse(x)
     p, n = x.shape
-    P = _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n, p, int(fit_intercept),
-                    int(standardize), gamma, alpha, beta, max_iter, tol, int(debug), n_total)
+    if epoch_len is not None:
+        assert stream is not None and not batch
+    P = _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n if epoch_len is None else int(epoch_len), p,
+                    int(fit_intercept), int(standardize), gamma, alpha, beta, max_iter, tol, int(debug), n_total)
     y = np.asfortranarray(y, dtype=np.float64)
     if y.ndim == 1:
         y = y.reshape(1, -1)

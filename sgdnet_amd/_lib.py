@@ -8,7 +8,8 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsgdnet_hip.so")
+# SGDNET_LIB_PATH: development aid (A/B of kernel variants built side by side); the product path is lib/
+LIB_PATH = os.environ.get("SGDNET_LIB_PATH") or os.path.join(_HERE, "lib", "libsgdnet_hip.so")
 
 # every symbol include/sgdnet_hip.h declares
 EXPORTS = [

@@ -95,12 +95,15 @@ struct SagaDev {
   // LDS are split into R feature ranges; the gather bins every non-zero of the batch by range
   // and one workgroup per range accumulates its slice of D in LDS and sweeps it.  R == 0: off.
   int R;
+  int range_max;               // features of the widest range (LDS of the range sweep)
   const int64_t* bin_off;      // R + 1: first entry of every bin (capacity follows the range's non-zero mass)
   const int32_t* range_lo;     // R + 1 feature boundaries
   const uint16_t* feat_range;  // p: range of every feature
   char* bins;                  // bin_off[R] entries {u32 draw, u32 feature, f64 value}
   unsigned* bin_count;         // R entries used (reset by the range's sweep)
-  double* gcb;                 // batch x K: gradient change of every draw of the batch
+  double* gcb;                 // batch x KS: gradient change of every draw of the batch
+  int KS;                      // K rounded up to a power of two: row stride of gcb and wpad (a K-vector never straddles a 128-B line)
+  double* wpad;                // p x KS copy of w read by the binned gather (== w when KS == K)
   int* bin_err;                // set when a bin overflowed (the epoch is then invalid)
 };
 
@@ -172,6 +175,7 @@ int batched_max_classes();
 // binned form: is it the form launch_batch_gather / launch_batch_sweep would use for m draws?
 bool binned_active(const SagaDev& d, int m);
 int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_t st);
+int launch_wpad_refresh(const SagaDev& d, hipStream_t st);
 size_t binned_max_range_features(int K);
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,

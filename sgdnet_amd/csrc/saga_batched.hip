@@ -29,6 +29,16 @@
 
 #include "device_math.hpp"
 
+#ifndef SGDNET_BIN_BLOCK
+#define SGDNET_BIN_BLOCK 1024
+#endif
+#ifndef SGDNET_BIN_W
+#define SGDNET_BIN_W 8
+#endif
+#ifndef SGDNET_RANGE_BLOCK
+#define SGDNET_RANGE_BLOCK 512
+#endif
+
 namespace sgdnet {
 
 namespace {
@@ -1822,10 +1832,11 @@ struct __attribute__((aligned(16))) BinEntry {
 };
 static_assert(sizeof(BinEntry) == 16, "bin entries are 16 bytes");
 
-constexpr int kBinBlock = 1024;      // gather+bin: 64 draws in flight per workgroup
-constexpr int kBinDraws = 512;       // draws per gather workgroup
-constexpr int kBinEntCap = 7168;     // LDS staging capacity (entries); beyond it entries go out one by one
-constexpr int kRangeBlock = 512;     // range sweep
+constexpr int kBinBlock = SGDNET_BIN_BLOCK;   // gather+bin threads: one 16-lane group per draw in flight
+constexpr int kBinDraws = kBinBlock / 2;      // draws per gather workgroup (8 passes)
+constexpr int kBinEntCap = 7 * kBinBlock;     // LDS staging capacity (entries); beyond it entries go out one by one
+constexpr int kBinW = SGDNET_BIN_W;           // reads of w requested together (8 or 16)
+constexpr int kRangeBlock = SGDNET_RANGE_BLOCK;   // range sweep threads (78 VGPRs: 24 waves per CU)
 constexpr size_t kRangeLdsBytes = 64 * 1024;
 
 size_t binned_max_range_features(int K) { return kRangeLdsBytes / (sizeof(double) * (size_t)K); }
@@ -1833,6 +1844,26 @@ size_t binned_max_range_features(int K) { return kRangeLdsBytes / (sizeof(double
 __global__ __launch_bounds__(256) void col_count_kernel(const int32_t* idx, int64_t nnz, unsigned* counts) {
   for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nnz; q += (int64_t)gridDim.x * 256)
     atomicAdd(counts + idx[q], 1u);
+}
+
+__global__ __launch_bounds__(256) void wpad_refresh_kernel(const double* w, double* wpad, int K, int KS, int64_t p) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < p * KS) {
+    const int64_t j = t / KS;
+    const int k = (int)(t - j * KS);
+    wpad[t] = k < K ? w[j * K + k] : 0.0;
+  }
+}
+
+// the padded copy of w the binned gather reads: refreshed at the start of every epoch (w may have
+// been set from the host, merged across GPUs or advanced by an exact-mode run in between)
+int launch_wpad_refresh(const SagaDev& d, hipStream_t st) {
+  if (!d.wpad || d.wpad == d.w) return SGDNET_OK;
+  const int64_t tot = d.p * d.KS;
+  hipLaunchKernelGGL(wpad_refresh_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d.w, d.wpad, d.K, d.KS,
+                     d.p);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
 }
 
 int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_t st) {
@@ -1845,15 +1876,44 @@ int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_
   return SGDNET_OK;
 }
 
-// every lane of the group visits its share of the row: f(j, v) on the lanes that hold an entry
+// one entry straight into its bin (staging full: a workgroup that drew unusually long rows)
+__device__ __forceinline__ void bin_push_global(const SagaDev& d, const BinEntry& en, unsigned r) {
+  const unsigned pos = atomicAdd(d.bin_count + r, 1u);
+  const int64_t b0 = d.bin_off[r];
+  if ((int64_t)pos < d.bin_off[r + 1] - b0) reinterpret_cast<BinEntry*>(d.bins)[b0 + pos] = en;
+  else atomicExch(d.bin_err, 1);
+}
+
+// Entries of the row beyond the 32 a group keeps in registers (record slots >= 32 and the overflow
+// chain).  Uniform form: every lane sees every entry (x.w); lane form: lane gl takes entries
+// gl, gl + 16, ... of every stretch (staging).
 template <class F>
-__device__ __forceinline__ void row_for_each_lane(const SagaDev& d, const char* base, int nnz, int ovf, int gl,
-                                                  F f) {
+__device__ __forceinline__ void row_rest_uniform(const SagaDev& d, const char* base, int nnz, int ovf, F f) {
   const int cap = d.rec_cap;
   const int cnt0 = nnz < cap ? nnz : cap;
   const int* ridx = reinterpret_cast<const int*>(base + 16);
   const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
-  for (int e = gl; e < cnt0; e += kGroup) f((uint32_t)ridx[e], rval[e]);
+  for (int e = 2 * kGroup; e < cnt0; ++e) f((uint32_t)ridx[e], rval[e]);
+  int rem = nnz - cnt0;
+  while (rem > 0) {
+    const char* ob = d.ovf + (size_t)ovf * kOvfStride;
+    const int next = reinterpret_cast<const int*>(ob)[0];
+    const int c = reinterpret_cast<const int*>(ob)[1];
+    const int* oi = reinterpret_cast<const int*>(ob + 8);
+    const double* ov = reinterpret_cast<const double*>(ob + 8 + 4 * kOvfCap);
+    for (int e = 0; e < c; ++e) f((uint32_t)oi[e], ov[e]);
+    rem -= c;
+    ovf = next;
+  }
+}
+
+template <class F>
+__device__ __forceinline__ void row_rest_lane(const SagaDev& d, const char* base, int nnz, int ovf, int gl, F f) {
+  const int cap = d.rec_cap;
+  const int cnt0 = nnz < cap ? nnz : cap;
+  const int* ridx = reinterpret_cast<const int*>(base + 16);
+  const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
+  for (int e = 2 * kGroup + gl; e < cnt0; e += kGroup) f((uint32_t)ridx[e], rval[e]);
   int rem = nnz - cnt0;
   while (rem > 0) {
     const char* ob = d.ovf + (size_t)ovf * kOvfStride;
@@ -1867,13 +1927,46 @@ __device__ __forceinline__ void row_for_each_lane(const SagaDev& d, const char* 
   }
 }
 
-// one entry straight into its bin (staging full, or the rare row longer than the staging)
-__device__ __forceinline__ void bin_push_global(const SagaDev& d, const BinEntry& en) {
-  const unsigned r = d.feat_range[en.j];
-  const unsigned pos = atomicAdd(d.bin_count + r, 1u);
-  const int64_t b0 = d.bin_off[r];
-  if ((int64_t)pos < d.bin_off[r + 1] - b0) reinterpret_cast<BinEntry*>(d.bins)[b0 + pos] = en;
-  else atomicExch(d.bin_err, 1);
+// What a 16-lane group holds of one draw before it works on it: requested one pass ahead, so the
+// record's round trip to HBM overlaps the previous draw's trip to the L2-resident w.
+struct BinDraw {
+  uint32_t s;
+  int i;              // draw index inside the batch, -1: none
+  double y0;
+  int nnz, ovf;
+  int j0;             // record slot gl (whatever the row length: slots past it hold 0)
+  double v0;
+  int prev;           // lane 0: the claim this draw's exchange returned
+};
+
+__device__ __forceinline__ BinDraw bin_fetch(const SagaDev& d, int i, uint32_t s, bool valid, int gl, int batch_id) {
+  BinDraw q;
+  q.s = s;
+  q.i = valid ? i : -1;
+  q.y0 = 0.0; q.nnz = 0; q.ovf = 0; q.j0 = 0; q.v0 = 0.0; q.prev = batch_id;
+  if (!valid) return q;
+  const char* base = d.rec + (size_t)s * d.rec_stride;
+  const int cap = d.rec_cap;
+  const int* ridx = reinterpret_cast<const int*>(base + 16);
+  const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
+  q.y0 = *reinterpret_cast<const double*>(base);
+  const int2 h = *reinterpret_cast<const int2*>(base + 8);
+  q.nnz = h.x;
+  q.ovf = h.y;
+  if (gl < cap) {
+    q.j0 = ridx[gl];
+    q.v0 = rval[gl];
+  }
+  if (gl == 0)
+    q.prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return q;
+}
+
+__device__ __forceinline__ double shfl_d(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __shfl((int)(b & 0xffffffffll), src, kGroup);
+  const int hi = __shfl((int)(b >> 32), src, kGroup);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
 __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d, const LamParams* lamp,
@@ -1885,37 +1978,107 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   BinEntry* ent = reinterpret_cast<BinEntry*>(bsm);
   unsigned* cnt = reinterpret_cast<unsigned*>(bsm + sizeof(BinEntry) * kBinEntCap);
   unsigned* rbase = cnt + d.R;
-  const int K = d.K;
+  int* rlo = reinterpret_cast<int*>(rbase + d.R);       // R + 1 range boundaries: the range of a feature
+  const int K = d.K, KS = d.KS;                          // is found by bisection in LDS, not by a table
+                                                         // look-up that costs an L2 request per non-zero
   const int gl = threadIdx.x & (kGroup - 1);
   const int group = threadIdx.x / kGroup;
   const int lane = threadIdx.x & 63;
   const bool lane_on = gl < K;
   const int64_t t0 = lamp->stream_base + t0_in_epoch;
   const int batch_id = lamp->batch_seq + batch_id_offset;
+  PHASE(0);
   for (int r = threadIdx.x; r < d.R; r += kBinBlock) cnt[r] = 0u;
+  for (int r = threadIdx.x; r <= d.R; r += kBinBlock) rlo[r] = d.range_lo[r];
   if (threadIdx.x < 16) d0s[threadIdx.x] = 0.0;
   if (threadIdx.x == 0) n_ent = 0u;
   __syncthreads();
   const double bl = lane_on ? d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0) : 0.0;
   if (d.standardize) cw_clear_next(d, batch_id);
+  int bis_steps = 0;
+  while ((1 << bis_steps) < d.R) ++bis_steps;
+  auto range_of = [&](int j) {
+    int a = 0, b = d.R;                       // rlo[a] <= j < rlo[b]
+    for (int it = 0; it < bis_steps; ++it) {
+      const int mid = (a + b) >> 1;
+      if (mid > a && j >= rlo[mid]) a = mid; else if (mid > a) b = mid;
+    }
+    return (unsigned)a;
+  };
 
+  // stage one entry per active lane: the slots of a wavefront's entries come from one LDS atomic;
+  // the staged copy carries its range in the upper 12 bits of the draw index (batch <= 2^20)
+  auto stage = [&](bool active, int i, uint32_t j, double v, unsigned r) {
+    const unsigned long long mask = __ballot(active);
+    if (mask == 0ull) return;
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned slot0 = 0u;
+    if (lane == leader) slot0 = atomicAdd(&n_ent, (unsigned)__popcll(mask));
+    slot0 = (unsigned)__shfl((int)slot0, leader, 64);
+    if (!active) return;
+    const unsigned slot = slot0 + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
+    if (slot < (unsigned)kBinEntCap) {
+      ent[slot] = BinEntry{(uint32_t)i | (r << 20), j, v};
+      atomicAdd(cnt + r, 1u);
+    } else {
+      bin_push_global(d, BinEntry{(uint32_t)i, j, v}, r);
+    }
+  };
+
+  PHASE(1);
+  constexpr int kG = kBinBlock / kGroup;
   const int lo = blockIdx.x * kBinDraws;
   const int hi = (lo + kBinDraws < m) ? lo + kBinDraws : m;
   double gct = 0.0;
-  for (int i = lo + group; i < hi; i += kBinBlock / kGroup) {
-    const uint32_t s = d.stream[t0 + i];
-    const char* base = d.rec + (size_t)s * d.rec_stride;
-    int prev = batch_id;
-    if (gl == 0)
-      prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const double mold = lane_on ? d.M[gl + (int64_t)s * K] : 0.0;
-    const double y0 = *reinterpret_cast<const double*>(base);
-    const int nnz = *reinterpret_cast<const int*>(base + 8);
-    const int ovf = *reinterpret_cast<const int*>(base + 12);
+  int i = lo + group;
+  uint32_t s_nxt = (i + kG < hi) ? d.stream[t0 + i + kG] : 0u;
+  BinDraw cur = bin_fetch(d, i, i < hi ? d.stream[t0 + i] : 0u, i < hi, gl, batch_id);
+  const int passes = (hi - lo + kG - 1) / kG;           // the same for every group: ballots stay wave-wide
+  for (int pass = 0; pass < passes; ++pass, i += kG) {
+    const uint32_t s_nn = (i + 2 * kG < hi) ? d.stream[t0 + i + 2 * kG] : 0u;
+    const BinDraw nxt = bin_fetch(d, i + kG, s_nxt, i + kG < hi, gl, batch_id);
+    // ---- the current draw ----
+    const bool have = cur.i >= 0;
+    const int cap = d.rec_cap;
+    const int cnt0 = cur.nnz < cap ? cur.nnz : cap;
+    const int creg = cnt0 < 2 * kGroup ? cnt0 : 2 * kGroup;
+    const bool rest = have && (cur.nnz > creg);
+    const char* base = d.rec + (size_t)cur.s * d.rec_stride;
+    // x . w: the feature ids sit in the group's registers, so the K-contiguous reads of w are all
+    // requested before the first one is used
+    const unsigned r0 = range_of(cur.j0);
+    const double mold = (have && lane_on) ? d.M[gl + (int64_t)cur.s * K] : 0.0;
     double acc = 0.0;
-    row_for_each_uniform(d, base, nnz, ovf, [&](int64_t j, double v) {
-      if (lane_on) acc += v * d.w[j * K + gl];
-    });
+#pragma unroll
+    for (int e0 = 0; e0 < kGroup; e0 += kBinW) {
+      if (e0 > 0 && !__any(have && creg > e0)) break;
+      double wv[kBinW];
+#pragma unroll
+      for (int e = 0; e < kBinW; ++e) {
+        const int j = __shfl(cur.j0, e0 + e, kGroup);
+        wv[e] = (have && e0 + e < creg && lane_on) ? d.wpad[(int64_t)j * KS + gl] : 0.0;
+      }
+#pragma unroll
+      for (int e = 0; e < kBinW; ++e) acc += shfl_d(cur.v0, e0 + e) * wv[e];
+    }
+    // record slots 16..31 (3 % of the rows at 10 non-zeros per sample): read where they are needed
+    int j1 = 0;
+    double v1 = 0.0;
+    if (__any(have && creg > kGroup)) {
+      if (have && kGroup + gl < creg) {
+        j1 = reinterpret_cast<const int*>(base + 16)[kGroup + gl];
+        v1 = reinterpret_cast<const double*>(base + d.rec_val_off)[kGroup + gl];
+      }
+      for (int e = 0; e < kGroup; ++e) {
+        const int j = __shfl(j1, e, kGroup);
+        const double v = shfl_d(v1, e);
+        if (have && kGroup + e < creg && lane_on) acc += v * d.wpad[(int64_t)j * KS + gl];
+      }
+    }
+    if (rest)
+      row_rest_uniform(d, base, cur.nnz, cur.ovf, [&](uint32_t j, double v) {
+        if (lane_on) acc += v * d.wpad[(int64_t)j * KS + gl];
+      });
     const double lp = acc + bl;
     double g;
     if (d.family == SGDNET_MULTINOMIAL) {
@@ -1923,59 +2086,65 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
       const double ssum = group_sum(lane_on ? exp(lp - mx) : 0.0);
       const double lse = log(ssum) + mx;
       g = exp(lp - lse);
-      if ((unsigned)gl == (unsigned)(y0 + 0.5)) g -= 1.0;
+      if ((unsigned)gl == (unsigned)(cur.y0 + 0.5)) g -= 1.0;
     } else if (d.family == SGDNET_BINOMIAL) {
-      g = 1.0 - y0 - 1.0 / (1.0 + exp(lp));
+      g = 1.0 - cur.y0 - 1.0 / (1.0 + exp(lp));
     } else {
-      g = lp - (lane_on ? d.y[(int64_t)s * d.Ky + gl] : 0.0);
+      g = lp - ((have && lane_on) ? d.y[(int64_t)cur.s * d.Ky + gl] : 0.0);
     }
-    const int first = __shfl(prev != batch_id ? 1 : 0, 0, kGroup);
-    if (!first) continue;          // a repeat inside the batch: same snapshot, gradient change 0
-    double gc = 0.0;
-    if (lane_on) {
-      gc = g - mold;
-      d.M[gl + (int64_t)s * K] = g;
-      d.gcb[(int64_t)i * K + gl] = gc;
+    // a repeat inside the batch sees the same snapshot: gradient change 0, nothing to stage
+    const bool first = have && (__shfl(cur.prev != batch_id ? 1 : 0, 0, kGroup) != 0);
+    if (first && lane_on) {
+      const double gc = g - mold;
+      d.M[gl + (int64_t)cur.s * K] = g;
+      d.gcb[(int64_t)cur.i * KS + gl] = gc;
+      gct += gc;
     }
-    gct += gc;
-    // one entry per non-zero: lanes of the group take entries gl, gl + 16, ...; the slots of a
-    // wavefront's entries are reserved with one LDS atomic
-    row_for_each_lane(d, base, nnz, ovf, gl, [&](uint32_t j, double v) {
-      const unsigned long long mask = __ballot(1);
-      const int leader = __ffsll((long long)mask) - 1;
-      unsigned slot0 = 0u;
-      if (lane == leader) slot0 = atomicAdd(&n_ent, (unsigned)__popcll(mask));
-      slot0 = (unsigned)__shfl((int)slot0, leader, 64);
-      const unsigned slot = slot0 + (unsigned)__popcll(mask & ((1ull << lane) - 1ull));
-      const BinEntry en{(uint32_t)i, j, v};
-      if (slot < (unsigned)kBinEntCap) {
-        ent[slot] = en;
-        atomicAdd(cnt + d.feat_range[j], 1u);
-      } else {
-        bin_push_global(d, en);
-      }
-    });
+    stage(first && gl < creg, cur.i, (uint32_t)cur.j0, cur.v0, r0);
+    if (__any(first && creg > kGroup)) {
+      const bool a1 = first && kGroup + gl < creg;
+      const unsigned r1 = range_of(j1);
+      stage(a1, cur.i, (uint32_t)j1, v1, r1);
+    }
+    if (first && rest)
+      row_rest_lane(d, base, cur.nnz, cur.ovf, gl, [&](uint32_t j, double v) {
+        stage(true, cur.i, j, v, range_of((int)j));
+      });
+    cur = nxt;
+    s_nxt = s_nn;
   }
+  PHASE(2);
   if (gct != 0.0) __hip_atomic_fetch_add(&d0s[gl], gct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __syncthreads();
+  PHASE(3);
   // reserve this workgroup's run in every bin it has entries for, then place the entries
+  // (rbase[r] becomes the ABSOLUTE entry index of the run's start, 0xffffffff if the bin is full)
   for (int r = threadIdx.x; r < d.R; r += kBinBlock) {
     const unsigned c = cnt[r];
-    rbase[r] = c ? atomicAdd(d.bin_count + r, c) : 0u;
+    unsigned at = 0xffffffffu;
+    if (c) {
+      const unsigned pos = atomicAdd(d.bin_count + r, c);
+      const int64_t b0 = d.bin_off[r], room = d.bin_off[r + 1] - b0;
+      if ((int64_t)pos + c <= room) at = (unsigned)(b0 + pos);
+      else atomicExch(d.bin_err, 1);
+    }
+    rbase[r] = at;
     cnt[r] = 0u;
   }
   __syncthreads();
+  PHASE(4);
   const unsigned staged = n_ent < (unsigned)kBinEntCap ? n_ent : (unsigned)kBinEntCap;
   for (unsigned e = threadIdx.x; e < staged; e += kBinBlock) {
-    const BinEntry en = ent[e];
-    const unsigned r = d.feat_range[en.j];
-    const unsigned pos = rbase[r] + atomicAdd(cnt + r, 1u);
-    const int64_t b0 = d.bin_off[r];
-    if ((int64_t)pos < d.bin_off[r + 1] - b0) reinterpret_cast<BinEntry*>(d.bins)[b0 + pos] = en;
-    else atomicExch(d.bin_err, 1);
+    BinEntry en = ent[e];
+    const unsigned r = en.t >> 20;
+    en.t &= 0xfffffu;
+    const unsigned at = rbase[r];
+    const unsigned k = atomicAdd(cnt + r, 1u);
+    if (at != 0xffffffffu) reinterpret_cast<BinEntry*>(d.bins)[(size_t)at + k] = en;
   }
   if ((d.fit_intercept || d.standardize) && (int)threadIdx.x < K)
     d0_publish(d, batch_id, threadIdx.x, d0s[threadIdx.x]);
+  PHASE(5);
 }
 
 __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
@@ -1985,14 +2154,27 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
   const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
   const int K = d.K;
   const int r = blockIdx.x;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  if (r == d.R) {
+    // the extra workgroup: intercept update and the reset of the next batch's accumulator slots.
+    // (Summing the gather's partials class by class takes ~9 us; inside a range's workgroup that
+    // was the tail every launch waited for.)
+    if (d.fit_intercept) {
+      block_d0<kRangeBlock>(d, n_parts, batch_id, sh_d0);
+      sweep_intercept(d, q, sh_d0);
+    }
+    double* nxt = d0_set(d, batch_id + 1);
+    for (int i = threadIdx.x; i < kD0Slots * K; i += kRangeBlock) nxt[i] = 0.0;
+    return;
+  }
   const int lo = d.range_lo[r], hi = d.range_lo[r + 1];
   const int E = (hi - lo) * K;
-  const int batch_id = lamp->batch_seq + batch_id_offset;
-  const bool need_d0 = d.standardize || (blockIdx.x == 0 && d.fit_intercept);
-  for (int i = threadIdx.x; i < E; i += kRangeBlock) Dl[i] = 0.0;
-  if (need_d0) block_d0<kRangeBlock>(d, n_parts, batch_id, sh_d0);
-  __syncthreads();
-  // ---- the bin's entries into the LDS slice: a 16-lane group per entry, lane = class ----
+  const bool need_d0 = d.standardize != 0;
+  // ---- the bin's entries into the LDS slice ----
+  // A 16-lane group takes 16 consecutive entries with one coalesced load (lane q holds entry q),
+  // then works through them with lane = class: the K-contiguous gradient changes of the 16 draws
+  // are requested together, the products go into the slice with ds_add_f64.  The next 16 entries
+  // are requested before the current ones are used.
   const int gl = threadIdx.x & (kGroup - 1);
   const int group = threadIdx.x / kGroup;
   constexpr int kGroups = kRangeBlock / kGroup;
@@ -2001,23 +2183,34 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
   if ((int64_t)cntb > bcap) cntb = (unsigned)bcap;
   const BinEntry* bin = reinterpret_cast<const BinEntry*>(d.bins) + b0;
   const bool lane_on = gl < K;
-  unsigned e = group;
-  for (; e + 3 * kGroups < cntb; e += 4 * kGroups) {          // four entries in flight per group
-    const BinEntry e0 = bin[e], e1 = bin[e + kGroups], e2 = bin[e + 2 * kGroups], e3 = bin[e + 3 * kGroups];
-    if (lane_on) {
-      const double g0 = d.gcb[(int64_t)e0.t * K + gl], g1 = d.gcb[(int64_t)e1.t * K + gl];
-      const double g2 = d.gcb[(int64_t)e2.t * K + gl], g3 = d.gcb[(int64_t)e3.t * K + gl];
-      scatter_add<true>(Dl + ((int)e0.j - lo) * K + gl, e0.x * g0);
-      scatter_add<true>(Dl + ((int)e1.j - lo) * K + gl, e1.x * g1);
-      scatter_add<true>(Dl + ((int)e2.j - lo) * K + gl, e2.x * g2);
-      scatter_add<true>(Dl + ((int)e3.j - lo) * K + gl, e3.x * g3);
-    }
-  }
-  for (; e < cntb; e += kGroups) {
-    const BinEntry e0 = bin[e];
-    if (lane_on) scatter_add<true>(Dl + ((int)e0.j - lo) * K + gl, e0.x * d.gcb[(int64_t)e0.t * K + gl]);
-  }
+  const BinEntry none{0u, (uint32_t)lo, 0.0};
+  PHASE(6);
+  unsigned e0 = (unsigned)group * kGroup;
+  BinEntry mine = (e0 + gl < cntb) ? bin[e0 + gl] : none;
+  for (int i = threadIdx.x; i < E; i += kRangeBlock) Dl[i] = 0.0;
+  if (need_d0) block_d0<kRangeBlock>(d, n_parts, batch_id, sh_d0);
   __syncthreads();
+  PHASE(7);
+  for (; e0 < cntb; e0 += kGroups * kGroup) {
+    const unsigned en = e0 + kGroups * kGroup;
+    const BinEntry nxt = (en + gl < cntb) ? bin[en + gl] : none;
+    double gq[kGroup];
+#pragma unroll
+    for (int qq = 0; qq < kGroup; ++qq) {
+      const int t = __shfl((int)mine.t, qq, kGroup);
+      gq[qq] = (lane_on && e0 + qq < cntb) ? d.gcb[(int64_t)t * d.KS + gl] : 0.0;
+    }
+#pragma unroll
+    for (int qq = 0; qq < kGroup; ++qq) {
+      const int j = __shfl((int)mine.j, qq, kGroup);
+      const double x = shfl_d(mine.x, qq);
+      if (lane_on && e0 + qq < cntb) scatter_add<true>(Dl + (j - lo) * K + gl, x * gq[qq]);
+    }
+    mine = nxt;
+  }
+  PHASE(8);
+  __syncthreads();
+  PHASE(9);
   if (threadIdx.x == 0) d.bin_count[r] = 0u;                 // the next batch fills the bin again
   // ---- per-feature update of this range ----
   double cwp[16];
@@ -2030,6 +2223,8 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
       for (int k = 0; k < K; ++k) dj[k] = Dl[f * K + k] - (d.standardize ? cj * sh_d0[k] : 0.0);
       sweep_feature(d, q, j, dj, wn);
       for (int k = 0; k < K; ++k) cwp[k] += cj * wn[k];
+      if (d.wpad != d.w)
+        for (int k = 0; k < K; ++k) d.wpad[j * d.KS + k] = wn[k];
     }
   } else {
     const double tau = q.beta * q.gamma * q.ls_m, gls = q.gamma * q.ls_m;
@@ -2041,17 +2236,14 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
       double v = q.r_m * d.w[t] - gls * d.G[t] - q.gamma * dk;
       if (q.penalty == SGDNET_ELASTICNET) v = soft_threshold(v, tau);
       d.w[t] = v;
+      if (d.wpad != d.w) d.wpad[(int64_t)(lo + f) * d.KS + k] = v;
       if (dk != 0.0) d.G[t] += dk / q.n_d;
       if (d.standardize)
         for (int kk = 0; kk < K; ++kk) cwp[kk] += kk == k ? cj * v : 0.0;
     }
   }
   if (d.standardize) cw_accumulate<kRangeBlock>(d, batch_id, cwp);
-  if (blockIdx.x == 0) {
-    if (d.fit_intercept) sweep_intercept(d, q, sh_d0);
-    double* nxt = d0_set(d, batch_id + 1);
-    for (int i = threadIdx.x; i < kD0Slots * K; i += kRangeBlock) nxt[i] = 0.0;
-  }
+  PHASE(10);
 }
 
 // ------------------------------ launchers ---------------------------------
@@ -2099,12 +2291,12 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
   }
   // worthwhile once the batch's non-zeros outnumber the table ~48x: below that the fixed
   // cost of writing and re-reading one table per workgroup exceeds the atomics it saves
-  if (d.R > 0 && d.bins && !d.force_global && force != 2) {
+  if (d.R > 0 && d.bins && !d.force_global && force != 2 && m <= (1 << 20)) {
     g.binned = true;
     g.draws_per_block = kBinDraws;
     g.grid = (m + kBinDraws - 1) / kBinDraws;
     if (g.grid < 1) g.grid = 1;
-    g.lds_bytes = sizeof(BinEntry) * (size_t)kBinEntCap + 2 * sizeof(unsigned) * (size_t)d.R;
+    g.lds_bytes = sizeof(BinEntry) * (size_t)kBinEntCap + sizeof(unsigned) * (3 * (size_t)d.R + 1);
     return g;
   }
   const bool pays = (double)m * (double)d.avg_nnz >= 48.0 * (double)d.K * (double)d.p;
@@ -2293,8 +2485,9 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
   const int n_parts = ov_m > 0.0 ? kD0Slots : (g.grid < kD0Slots ? g.grid : kD0Slots);
   const SweepOverride ov{ov_r, ov_ls, ov_m};
   if (g.binned) {
-    hipExtLaunchKernelGGL(saga_binned_sweep_kernel, dim3(d.R), dim3(kRangeBlock), kRangeLdsBytes, st, ev0, ev1, 0,
-                          d, lam, tail, n_parts, batch_id_offset);
+    hipExtLaunchKernelGGL(saga_binned_sweep_kernel, dim3(d.R + 1), dim3(kRangeBlock),
+                          sizeof(double) * (size_t)d.K * (size_t)d.range_max, st, ev0, ev1, 0, d, lam, tail, n_parts,
+                          batch_id_offset);
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;
   }

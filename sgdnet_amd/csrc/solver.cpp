@@ -188,7 +188,8 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     SGD_HIP_TRY(hipMemcpyAsync(h.data(), counts, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost, s->st));
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     const int64_t fmax = (int64_t)binned_max_range_features(d.K);
-    const int target = 256;                         // one range sweep workgroup per CU
+    static const int target_env = [] { const char* e = getenv("SGDNET_BIN_RANGES"); return e ? atoi(e) : 0; }();
+    const int target = target_env > 0 ? target_env : 512;   // range sweep workgroups (3 of 512 threads fit a CU)
     const double per = std::max(1.0, (double)s->nnz / target);
     std::vector<int32_t> lo{0};
     std::vector<uint16_t> fr((size_t)d.p);
@@ -208,7 +209,10 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     const int R = (int)lo.size() - 1;
     s->bin_mass.assign((size_t)R, 0.0);
     for (int64_t j = 0; j < d.p; ++j) s->bin_mass[fr[(size_t)j]] += h[(size_t)j];
-    if (R > 4096) return SGDNET_OK;                  // staging counters of the gather would not fit: atomic form
+    if (R > 2048) return SGDNET_OK;                  // staging counters of the gather would not fit: atomic form
+    int wmax = 1;
+    for (int r = 0; r < R; ++r) wmax = std::max(wmax, (int)(lo[(size_t)r + 1] - lo[(size_t)r]));
+    d.range_max = wmax;
     int32_t* lo_dev = nullptr;
     uint16_t* fr_dev = nullptr;
     rc = dev_upload(s, &lo_dev, lo.data(), lo.size());
@@ -219,6 +223,17 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     if (!rc) rc = dev_alloc(s, &be, 1, true);
     if (rc) return rc;
     SGD_HIP_TRY(hipStreamSynchronize(s->st));        // the uploads read host vectors that die here
+    int ks = 1;
+    while (ks < d.K) ks *= 2;
+    d.KS = ks;
+    if (ks != d.K) {
+      double* wp = nullptr;
+      rc = dev_alloc(s, &wp, (size_t)d.p * (size_t)ks, true);
+      if (rc) return rc;
+      d.wpad = wp;
+    } else {
+      d.wpad = d.w;
+    }
     d.R = R;
     d.range_lo = lo_dev;
     d.feat_range = fr_dev;
@@ -243,7 +258,7 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
       off[(size_t)r + 1] = off[(size_t)r] + (int64_t)(mean + 8.0 * std::sqrt(mean) + 512.0);
     }
     SGD_HIP_TRY(hipMalloc(&s->bin_bufs[0], (size_t)16 * (size_t)off[(size_t)d.R]));
-    SGD_HIP_TRY(hipMalloc(&s->bin_bufs[1], sizeof(double) * (size_t)batch * (size_t)d.K));
+    SGD_HIP_TRY(hipMalloc(&s->bin_bufs[1], sizeof(double) * (size_t)batch * (size_t)d.KS));
     SGD_HIP_TRY(hipMalloc(&s->bin_bufs[2], sizeof(int64_t) * off.size()));
     SGD_HIP_TRY(hipMemcpy(s->bin_bufs[2], off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice));
     s->bin_batch = batch;
@@ -374,6 +389,10 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
   if (vs_active(s, batch)) return enqueue_epoch_kernels_vs(s, batch, draws, ev);
   if (batch > draws) batch = draws;
   const int nb = n_batches(batch, draws);
+  if (binned_active(s->d, (int)batch)) {
+    const int rcw = launch_wpad_refresh(s->d, s->st);
+    if (rcw) return rcw;
+  }
   for (int k = 0; k < nb; ++k) {
     const int64_t t0 = (int64_t)k * batch;
     const int64_t m = (draws - t0 < batch) ? draws - t0 : batch;
@@ -1304,6 +1323,45 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   }
   for (hipEvent_t e : ev) (void)hipEventDestroy(e);
 #ifdef SGDNET_PHASE_TIMING
+  if (s->d.dbg && binned_active(s->d, (int)batch)) {   // binned form: slots 0-5 gather, 6-10 range sweep
+    std::vector<unsigned long long> t(16 * 1024);
+    SGD_HIP_TRY(hipMemcpy(t.data(), s->d.dbg, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
+    static const char* nm[10] = {"gather: init", "gather: draw loop", "gather: barrier", "gather: reserve runs",
+                                 "gather: place entries", "", "sweep: zero + first entries", "sweep: entries -> LDS",
+                                 "sweep: barrier", "sweep: update features"};
+    for (int ph = 0; ph < 10; ++ph) {
+      if (ph == 5) continue;
+      double sum = 0, mx = 0;
+      int cnt = 0;
+      for (int b = 0; b < 1024; ++b) {
+        if (!t[b * 16 + ph] || !t[b * 16 + ph + 1] || t[b * 16 + ph + 1] < t[b * 16 + ph]) continue;
+        const double dt = (double)(t[b * 16 + ph + 1] - t[b * 16 + ph]) / 100.0;
+        sum += dt; mx = std::max(mx, dt); ++cnt;
+      }
+      if (cnt) fprintf(stderr, "[phase] %-28s mean %6.2f us max %6.2f us (%d workgroups)\n", nm[ph], sum / cnt, mx, cnt);
+    }
+    for (int k0 : {0, 6}) {
+      unsigned long long first = ~0ull, last = 0;
+      const int k1 = k0 == 0 ? 5 : 10;
+      for (int b = 0; b < 1024; ++b) {
+        if (t[b * 16 + k0] && t[b * 16 + k0] < first) first = t[b * 16 + k0];
+        if (t[b * 16 + k1] > last) last = t[b * 16 + k1];
+      }
+      fprintf(stderr, "[phase] %s span seen by the workgroups %.2f us\n", k0 == 0 ? "gather" : "sweep", (double)(last - first) / 100.0);
+      std::vector<double> st, en;
+      for (int b = 0; b < 1024; ++b)
+        if (t[b * 16 + k0] && t[b * 16 + k1] >= t[b * 16 + k0]) {
+          st.push_back((double)(t[b * 16 + k0] - first) / 100.0);
+          en.push_back((double)(t[b * 16 + k1] - first) / 100.0);
+        }
+      std::sort(st.begin(), st.end());
+      std::sort(en.begin(), en.end());
+      if (!st.empty())
+        fprintf(stderr, "[phase]   workgroup start offsets: p10 %.1f p50 %.1f p90 %.1f max %.1f us; end offsets: p10 %.1f p50 %.1f p90 %.1f max %.1f us\n",
+                st[st.size() / 10], st[st.size() / 2], st[st.size() * 9 / 10], st.back(), en[en.size() / 10], en[en.size() / 2],
+                en[en.size() * 9 / 10], en.back());
+    }
+  } else
   if (s->d.dbg) {   // stamps of the epoch's last gather launch (the tail batch unless batch divides the epoch)
     std::vector<unsigned long long> t(16 * 256);
     SGD_HIP_TRY(hipMemcpy(t.data(), s->d.dbg, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
