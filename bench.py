@@ -323,8 +323,14 @@ def main():
             # ... and one returning device-scope exchange per draw on the gradient memory: the
             # memory-side atomic units sustain 21.7 G/s alone (profiles/r01_microbench.txt), i.e.
             # 21.7e9 x bytes-per-draw with nothing else on the fabric
+            # ... and the floor of the K = 1 gather's compulsory pattern, measured with no compute at all in
+            # the product's launch geometry (scripts/microbench/gather_exchange.hip,
+            # profiles/r02c_gather_exchange_floor_microbench.txt): one random 128-B record + one dependent
+            # returning exchange per draw run at 20.8 G draws/s, the exchanges alone at 23.7 G/s
             "ceilings": {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0,
-                         "one_returning_exchange_per_draw": 21.72 * alg_bytes_epoch / max(1, n_local)} if K == 1 else
+                         "one_returning_exchange_per_draw": 23.66 * alg_bytes_epoch / max(1, n_local),
+                         "record_plus_dependent_exchange_floor": 20.79 * alg_bytes_epoch / max(1, n_local)}
+            if K == 1 else
                         {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0},
         },
     }
