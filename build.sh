@@ -12,7 +12,7 @@ FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -Iinclude -I
 # objects are rebuilt when the flags change (e.g. EXTRA_FLAGS=-DSGDNET_PHASE_TIMING experiments)
 if [ ! -f build/.flags ] || [ "$(cat build/.flags)" != "$FLAGS" ]; then rm -f build/*.o; echo "$FLAGS" > build/.flags; fi
 pids=()
-for f in saga_exact.hip saga_batched.hip r_rng_device.hip setup_device.hip score.hip solver.cpp driver.cpp r_rng.cpp; do
+for f in saga_exact.hip saga_batched.hip r_rng_device.hip setup_device.hip score.hip solver.cpp driver.cpp r_rng.cpp mt_jump.cpp; do
   o=build/${f%.*}.o
   if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ "$SRC/common.hpp" -nt "$o" ] || [ "$SRC/device_math.hpp" -nt "$o" ] || [ "$SRC/setup_device.hpp" -nt "$o" ] || [ include/sgdnet_hip.h -nt "$o" ]; then
     $HIPCC $FLAGS -x hip -c "$SRC/$f" -o "$o" &
@@ -20,7 +20,7 @@ for f in saga_exact.hip saga_batched.hip r_rng_device.hip setup_device.hip score
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgdnet_hip.so" build/saga_exact.o build/saga_batched.o build/r_rng_device.o build/setup_device.o build/score.o build/solver.o build/driver.o build/r_rng.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgdnet_hip.so" build/saga_exact.o build/saga_batched.o build/r_rng_device.o build/setup_device.o build/score.o build/solver.o build/driver.o build/r_rng.o build/mt_jump.o
 make -s -C oracle liboracle.so
 # the .Call shim (shim/sgdnet_shim.c) compiled as it will be inside the R package, against the
 # mock of the R C API under tests/rmock (no R in this image): test infrastructure

@@ -158,6 +158,12 @@ int sgdnet_fit_dense(const double* x, int64_t n_samples, int64_t n_features,
 /* ------------------------------------------------------------------------ */
 void     sgdnet_rng_seed(sgdnet_rng* r, uint32_t seed);           /* set.seed(seed)        */
 double   sgdnet_rng_unif(sgdnet_rng* r);                          /* unif_rand()           */
+/* Jump-ahead on the same stream (sgdnet_amd/csrc/mt_jump.cpp): poly624 <- x^draws mod phi(x), the
+ * GF(2) polynomial that moves a generator state `draws` unif_rand() calls down R's stream; and its
+ * application on the host.  The fit driver uses the device form to run several generators on ONE
+ * set.seed() stream.  sgdnet_rng_jump_poly returns SGDNET_OK or SGDNET_EUNSUPPORTED. */
+int      sgdnet_rng_jump_poly(uint64_t draws, uint32_t* poly624);
+void     sgdnet_rng_jump(const sgdnet_rng* in, const uint32_t* poly624, sgdnet_rng* out);
 void     sgdnet_rng_fill(sgdnet_rng* r, uint32_t n_samples,       /* floor(runif(0, n))    */
                          uint32_t* out, int64_t count);
 

@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SGDNET_LIB_PATH") or os.path.join(_HERE, "lib", "libs
 EXPORTS = [
     "sgdnet_abi_version", "sgdnet_last_error", "sgdnet_device_count",
     "sgdnet_fit_sparse", "sgdnet_fit_dense",
-    "sgdnet_rng_seed", "sgdnet_rng_unif", "sgdnet_rng_fill",
+    "sgdnet_rng_seed", "sgdnet_rng_unif", "sgdnet_rng_fill", "sgdnet_rng_jump_poly", "sgdnet_rng_jump",
     "sgdnet_solver_create", "sgdnet_solver_destroy", "sgdnet_solver_set_penalty",
     "sgdnet_solver_get_state", "sgdnet_solver_set_state", "sgdnet_solver_upload_stream",
     "sgdnet_solver_generate_stream", "sgdnet_solver_get_stream",
@@ -164,6 +164,9 @@ def load():
                                    C.POINTER(C.c_double), C.c_int, C.POINTER(Control),
                                    C.POINTER(Result)]
     L.sgdnet_rng_fill.argtypes = [C.POINTER(Rng), C.c_uint32, C.POINTER(C.c_uint32), C.c_int64]
+    L.sgdnet_rng_jump_poly.argtypes = [C.c_uint64, C.POINTER(C.c_uint32)]
+    L.sgdnet_rng_jump.argtypes = [C.POINTER(Rng), C.POINTER(C.c_uint32), C.POINTER(Rng)]
+    L.sgdnet_rng_jump.restype = None
     _lib = L
     return L
 

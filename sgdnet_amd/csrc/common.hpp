@@ -181,4 +181,10 @@ int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_sa
                     int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,
                     int gens = 1);
 
+// jump-ahead of R's Mersenne-Twister (mt_jump.cpp, r_rng_device.hip)
+bool mt_jump_poly(uint64_t J, uint32_t* out624);
+void mt_jump_host(const sgdnet_rng* in, const uint32_t* poly624, sgdnet_rng* out);
+int launch_rng_jump(const uint32_t* state_in, uint32_t* state_out, const uint32_t* poly_dev, int gens,
+                    hipStream_t st);
+
 }  // namespace sgdnet

@@ -638,9 +638,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     ~PipeGuard() { if (on) (void)solver_rng_close(s, rng); }
   } pipe_guard{S, &draws.rng, false};
   if (pipe) {
-    // batched mode with epochs of 200 000 draws or more: 8-32 generators side by side (one makes
-    // 10M draws in 5.3 ms, six epochs of the batched kernels at C4).  Smaller problems and exact
-    // mode keep the single R stream.  SGDNET_RNG_GENERATORS overrides.
+    // batched mode with epochs of 200 000 draws or more: 8-32 generators side by side ON THE ONE
+    // R STREAM (one makes 10M draws in 5.3 ms, six epochs of the batched kernels at C4): generator g
+    // starts g * ceil(n / G) draws into the epoch and all of them jump n draws per epoch
+    // (mt_jump.cpp), so the sample order is set.seed()'s whatever G is.  Smaller problems and exact
+    // mode keep a single generator.  SGDNET_RNG_GENERATORS overrides.
     int gens = 1;
     if (mode == SGDNET_MODE_BATCHED) {
       const char* e = getenv("SGDNET_RNG_GENERATORS");

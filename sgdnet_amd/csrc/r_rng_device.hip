@@ -112,6 +112,73 @@ __global__ __launch_bounds__(kRngBlock) void r_mt_state_kernel(const uint32_t* s
   if (t == 0) st_out[0] = mti;
 }
 
+// Jump-ahead on the device (mt_jump.cpp has the mathematics and the host form): workgroup g moves
+// generator g's state window J words down its stream, J given by poly = x^J mod phi:
+//   out[j] = XOR over { i : poly_i = 1 } of x[i + j],  x = the raw word sequence that starts with the window.
+// The 19937 + 624 words of x live in LDS (82 KB); they are produced block by block with the same
+// three-phase step as r_mt_state_kernel, then thread j accumulates its word.  mti is kept.
+constexpr int kJumpSeq = 19937 + kN;         // words of x the convolution reads
+constexpr int kJumpBlock = 640;              // >= 624 threads: one per word of the window
+
+__global__ __launch_bounds__(kJumpBlock) void r_mt_jump_kernel(const uint32_t* st_in, uint32_t* st_out,
+                                                               const uint32_t* poly) {
+  extern __shared__ uint32_t xs[];           // kJumpSeq + kN words (the last block may run over)
+  const int t = threadIdx.x;
+  st_in += (int64_t)blockIdx.x * (kN + 1);
+  st_out += (int64_t)blockIdx.x * (kN + 1);
+  if (t < kN) xs[t] = st_in[1 + t];
+  __syncthreads();
+  constexpr int kD = kN - kM;
+  for (int base = 0; base + kN < kJumpSeq; base += kN) {
+    const uint32_t* cur = xs + base;
+    uint32_t* nxt = xs + base + kN;
+    if (t < kD) {
+      uint32_t v = cur[t + kM] ^ twist(cur[t], cur[t + 1]);
+      nxt[t] = v;
+      const int k2 = kD + t;
+      v ^= twist(cur[k2], cur[k2 + 1]);
+      nxt[k2] = v;
+      const int k3 = 2 * kD + t;
+      if (k3 < kN) {
+        const uint32_t nb = k3 == kN - 1 ? (cur[kM] ^ twist(cur[0], cur[1])) : cur[k3 + 1];
+        v ^= twist(cur[k3], nb);
+        nxt[k3] = v;
+      }
+    }
+    __syncthreads();
+  }
+  if (t < kN) {
+    uint32_t acc = 0u;
+    for (int wi = 0; wi < kN; ++wi) {
+      uint32_t bits = poly[wi];              // the same word for every thread: a scalar load
+      const uint32_t* xb = xs + 32 * wi + t;
+      while (bits) {
+        const int b = __ffs((int)bits) - 1;
+        acc ^= xb[b];
+        bits &= bits - 1u;
+      }
+    }
+    st_out[1 + t] = acc;
+  }
+  if (t == 0) st_out[0] = st_in[0];
+}
+
+int launch_rng_jump(const uint32_t* state_in, uint32_t* state_out, const uint32_t* poly_dev, int gens,
+                    hipStream_t st) {
+  static bool attr_done_dev[64] = {};
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  const size_t lds = sizeof(uint32_t) * (size_t)(kJumpSeq + kN);
+  if (!attr_done_dev[cur & 63]) {
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(r_mt_jump_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done_dev[cur & 63] = true;
+  }
+  hipLaunchKernelGGL(r_mt_jump_kernel, dim3(gens), dim3(kJumpBlock), lds, st, state_in, state_out, poly_dev);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
 // shards.V > 1 (virtual shards, common.hpp): the epoch's positions are split into V regions of
 // dps draws and region v draws from shard v's sample range -- lo_v + floor(size_v * u); positions
 // past V * dps (n not a multiple of V) keep the plain floor(n * u) and are not consumed

@@ -72,7 +72,12 @@ struct sgdnet_solver {
     int64_t n = 0;
     int64_t gens = 0, used = 0;
     static constexpr int kMaxGen = 64;
-    int G = 1;                                  // independent generators (segments of an epoch's stream)
+    int G = 1;                                  // generators side by side (segments of an epoch's stream)
+    // G > 1: ONE R stream.  state[.][g] is the state at the START of generator g's segment;
+    // the next epoch's starts are those states jumped n draws ahead (poly_n), the ends the generation
+    // kernel leaves go to `ends` and are not used
+    uint32_t* poly_n = nullptr;
+    uint32_t* ends = nullptr;
   } pipe;
   int64_t nnz = 0;
   bool penalty_set = false;
@@ -861,6 +866,8 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
     if (s->pipe.freed[i]) (void)hipEventDestroy(s->pipe.freed[i]);
     if (s->pipe.state[i]) (void)hipFree(s->pipe.state[i]);
   }
+  if (s->pipe.poly_n) (void)hipFree(s->pipe.poly_n);
+  if (s->pipe.ends) (void)hipFree(s->pipe.ends);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
 }
@@ -1031,14 +1038,29 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
                             sizeof(sgdnet_rng) * sgdnet_solver::RngPipe::kMaxGen));
     }
   }
-  std::vector<sgdnet_rng> st((size_t)generators);
-  for (int g = 1; g < generators; ++g) {
-    const double u = sgdnet_rng_unif(rng);
-    sgdnet_rng_seed(&st[(size_t)g], (uint32_t)(u * 4294967296.0));
-  }
-  st[0] = *rng;
+  // Several generators work on ONE stream -- R's, as set.seed() left it: generator g starts
+  // g * seg draws into the epoch (its state = the first one jumped g * seg draws ahead), and every
+  // epoch all starts move n draws on (mt_jump.cpp).  If the jump polynomials cannot be had the fit
+  // keeps a single generator.
+  const int64_t seg = (n + generators - 1) / generators;
+  std::vector<uint32_t> poly_seg(624), poly_n(624);
+  if (generators > 1 && !(mt_jump_poly((uint64_t)seg, poly_seg.data()) && mt_jump_poly((uint64_t)n, poly_n.data())))
+    generators = 1;
   P.G = generators;
-  SGD_HIP_TRY(hipMemcpy(P.state[0], st.data(), sizeof(sgdnet_rng) * (size_t)generators, hipMemcpyHostToDevice));
+  SGD_HIP_TRY(hipMemcpy(P.state[0], rng, sizeof(sgdnet_rng), hipMemcpyHostToDevice));
+  if (generators > 1) {
+    if (!P.poly_n) {
+      SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&P.poly_n), sizeof(uint32_t) * 624 * 2));
+      SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&P.ends), sizeof(sgdnet_rng) * sgdnet_solver::RngPipe::kMaxGen));
+    }
+    SGD_HIP_TRY(hipMemcpy(P.poly_n, poly_n.data(), sizeof(uint32_t) * 624, hipMemcpyHostToDevice));
+    SGD_HIP_TRY(hipMemcpy(P.poly_n + 624, poly_seg.data(), sizeof(uint32_t) * 624, hipMemcpyHostToDevice));
+    for (int g = 1; g < generators; ++g) {      // start[g] = start[g - 1] jumped seg draws: once per fit
+      int rcj = launch_rng_jump(P.state[0] + (size_t)(g - 1) * 625, P.state[0] + (size_t)g * 625, P.poly_n + 624, 1, P.st);
+      if (rcj) return rcj;
+    }
+    SGD_HIP_TRY(hipStreamSynchronize(P.st));
+  }
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   for (int i = 0; i < 2; ++i) SGD_HIP_TRY(hipEventRecord(P.freed[i], s->st));
   P.n = n;
@@ -1054,8 +1076,15 @@ int solver_rng_prefetch(sgdnet_solver* s) {
   SGD_HIP_TRY(hipSetDevice(s->device));
   const int slot = (int)(P.gens & 1);
   SGD_HIP_TRY(hipStreamWaitEvent(P.st, P.freed[slot], 0));
-  int rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
-                           s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G);
+  int rc;
+  if (P.G > 1) {
+    rc = launch_rng_fill(P.state[P.gens & 1], P.ends, (uint32_t)s->d.n, s->stream_dev + (int64_t)slot * P.n, P.n,
+                         P.st, s->d.V, s->d.v_size, P.G);
+    if (!rc) rc = launch_rng_jump(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], P.poly_n, P.G, P.st);
+  } else {
+    rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
+                         s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G);
+  }
   if (rc) return rc;
   SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
   ++P.gens;

@@ -105,3 +105,42 @@ def test_exact_mode_does_not_report_a_blown_up_run_as_converged(sa):
 def sp_csc(a):
     import scipy.sparse as sp
     return sp.csc_matrix(a)
+
+
+def test_parallel_generators_stay_on_rs_single_stream(sa, big, monkeypatch):
+    """The fit driver runs 8-32 Mersenne-Twisters side by side for large batched fits; with the
+    jump-ahead of sgdnet_amd/csrc/mt_jump.cpp they all sit on the ONE stream set.seed() defines, so
+    the fit is the single-generator fit and R's generator ends where the reference leaves it."""
+    import ctypes as C
+    x, y = big
+    n = x.shape[0]
+    kw = dict(family="binomial", alpha=0.5, lambda_=[2e-3, 1e-3], standardize=False, thresh=1e-7, maxit=60,
+              mode="batched")
+    r_par = sa.RRng(3)
+    par = sa.sgdnet(x, y, rng=r_par, **kw)                     # default: several generators
+    monkeypatch.setenv("SGDNET_RNG_GENERATORS", "1")
+    r_one = sa.RRng(3)
+    one = sa.sgdnet(x, y, rng=r_one, **kw)
+    assert par.npasses == one.npasses
+    assert np.abs(par.beta - one.beta).max() <= 1e-12 * np.abs(one.beta).max()
+    host = sa.RRng(3)
+    host.stream(n, int(par.npasses) * n)                       # the draws the reference would have consumed
+    for r in (r_par, r_one):
+        assert np.array_equal(host.unif(64), r.unif(64))       # same position on the same stream
+
+
+def test_device_jump_equals_the_sequential_generator(sa):
+    """sgdnet_rng_jump_poly + the host jump against plain stepping (the device kernel is covered by
+    the fit above): the state J draws ahead produces the draws the stepped generator produces."""
+    import ctypes as C
+    from sgdnet_amd import _lib
+    L = sa.load()
+    for J in (1, 624, 99_991, 10_000_000):
+        poly = (C.c_uint32 * 624)()
+        assert L.sgdnet_rng_jump_poly(C.c_uint64(J), poly) == 0
+        a, b = sa.RRng(11), sa.RRng(11)
+        a.unif(1000), b.unif(1000)
+        out = sa.RRng(0)
+        L.sgdnet_rng_jump(C.byref(a.state), poly, C.byref(out.state))
+        b.stream(7, J)
+        assert np.array_equal(out.unif(1500), b.unif(1500))
