@@ -123,9 +123,10 @@ def test_parallel_generators_stay_on_rs_single_stream(sa, big, monkeypatch):
     one = sa.sgdnet(x, y, rng=r_one, **kw)
     assert par.npasses == one.npasses
     assert np.abs(par.beta - one.beta).max() <= 1e-12 * np.abs(one.beta).max()
-    host = sa.RRng(3)
-    host.stream(n, int(par.npasses) * n)                       # the draws the reference would have consumed
-    for r in (r_par, r_one):
+    assert par.draws_used == one.draws_used and par.draws_used >= int(par.npasses) * n
+    for r, fit in ((r_par, par), (r_one, one)):
+        host = sa.RRng(3)
+        host.stream(n, fit.draws_used)                         # every draw the fit took, one by one
         assert np.array_equal(host.unif(64), r.unif(64))       # same position on the same stream
 
 
