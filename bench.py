@@ -194,6 +194,14 @@ def main():
     shard_period = max(1, n // int(os.environ.get("SGDNET_BENCH_PERIOD_DIV", "32")))
     runs = merge_segments(n_local, n, V * min(batch, n_local // V), period=V * shard_period) \
         if merged_job else [n_local]
+    # One process: the sample order is R's single Mersenne-Twister stream of set.seed(config id),
+    # produced ON THE DEVICE INSIDE THE TIMED REGION, one epoch ahead on a side stream, by several
+    # generators kept on that one stream by jump-ahead (sgdnet_solver_rng_*, as sgdnet_fit_* does).
+    # N > 1: every rank's draws for all epochs are generated on the host before the timed region
+    # (the per-merge-segment layout of sharded ranks is not produced on the device yet).
+    pipe = (world == 1 and not force_merge and os.environ.get("SGDNET_BENCH_RESIDENT_STREAM") != "1")
+    gens = int(os.environ.get("SGDNET_RNG_GENERATORS", "0")) or (
+        min(32, max(8, n_local // 300000)) if n_local >= 200000 else 1)
     if V > 1:
         from sgdnet_amd.parallel import shard_bounds as sb
         S.set_virtual_shards(V)
@@ -212,10 +220,14 @@ def main():
                         parts.append(np.zeros(run - dps * V, dtype=np.uint32))  # positions no shard consumes
             return np.concatenate(parts)
 
-        stream = host_stream(epochs_total)
+        stream = None if pipe else host_stream(epochs_total)
     else:
-        stream = sa.RRng(seed + rank).stream(n_local, n_local * epochs_total)
-    S.upload_stream(stream)
+        stream = None if pipe else sa.RRng(seed + rank).stream(n_local, n_local * epochs_total)
+    bench_rng = sa.RRng(seed)
+    if pipe:
+        S.rng_open(bench_rng, n_local, gens)
+    else:
+        S.upload_stream(stream)
     # device-ordered merge (no host sync inside an epoch) unless SGDNET_BENCH_FUSED=0
     fused = ((world > 1 or force_merge) and backend == "nccl"
              and os.environ.get("SGDNET_BENCH_FUSED", "1") == "1")
@@ -244,6 +256,13 @@ def main():
         return sj.epoch, sh, desc, 0
 
     run_epoch, shard, merge_desc, sync_rounds = make_job("sync" if sync_mode else "avg")
+    if pipe:
+        lb_pipe = min(batch, n_local)
+
+        def run_epoch():                          # noqa: F811 -- draws of this epoch, epoch, hand the slot back
+            off_ = S.rng_next()
+            S.enqueue_epochs(1, batch=lb_pipe, stream_offset=off_, draws_per_epoch=n_local)
+            S.rng_done()
 
     def fence():
         S.sync()
@@ -271,12 +290,15 @@ def main():
 
     note(f"timed region done: {elapsed:.4f}s")
     # dominant kernel, HIP events around every launch of one more epoch (same stream)
-    off = shard.offset
+    off = S.rng_next() if pipe else shard.offset
     # sync mode: this rank's share of a global batch, same (global-atomic) gather kernel as the
     # timed region; the profiled epoch runs without the exchange, the state is reset below
     local_batch = min(batch, n_local) if not sync_mode else max(1, -(-n_local // sync_rounds))
     prof = S.profile_epoch(batch=local_batch, stream_offset=off, draws_per_epoch=n_local)
-    alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, stream[off:off + n_local], K)
+    epoch_draws = S.get_stream(off, n_local) if pipe else stream[off:off + n_local]
+    if pipe:
+        S.rng_done()
+    alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, epoch_draws, K)
     gather_s = prof["gather_ms"] * 1e-3
     achieved = alg_bytes_epoch / gather_s / 1e9
     alg_all = torch.tensor([alg_bytes_epoch], dtype=torch.float64, device=red_dev)
@@ -306,7 +328,9 @@ def main():
             "workload": f"{args.workload}: synthetic CSC {n}x{p}, {density:.4%} nnz, family={family}, "
                         f"alpha={mix}, lambda=1/n, intercept, standardize=FALSE",
             "mode": "batched", "batch": batch, "samples_per_gpu": n_local, "virtual_shards": V,
-            "sample_order": f"R MT19937 set.seed({seed}+rank), with replacement",
+            "sample_order": (f"R MT19937 set.seed({seed}), with replacement: one stream, {gens} generators kept on it by "
+                             "jump-ahead, generated on the device inside the timed region (one epoch ahead, side stream)"
+                             if pipe else f"R MT19937 set.seed({seed}+rank [+100 shard]), with replacement, resident before the timed region"),
             "merge": merge_desc,
             "gen_s": round(t_gen, 2),
         },
@@ -348,6 +372,21 @@ def main():
 
     def convergence_leg(epoch_fn, sh, max_epochs):
         cold_start()
+        if pipe:                                   # the epoch function draws its own sample order
+            S.convergence(args.conv_thresh)
+            fence()
+            tconv = time.perf_counter()
+            done, conv_ep = False, 0
+            while not done and conv_ep < max_epochs:
+                epoch_fn()
+                S.sync()
+                done = S.convergence(args.conv_thresh)
+                conv_ep += 1
+            tconv = time.perf_counter() - tconv
+            return {"thresh": args.conv_thresh, "epochs": conv_ep, "converged": bool(done), "seconds": tconv,
+                    "deviance": S.deviance(),
+                    "note": "cold start, ConvergenceCheck on the merged coefficients every epoch; "
+                            "includes the per-epoch sample order and one host synchronisation per epoch"}
         crng = sa.RRng(seed + 1000 + rank)
         S.convergence(args.conv_thresh)            # w_prev <- 0
         fence()
@@ -416,6 +455,8 @@ def main():
         # bounded sample (10-30 s of one core): at most 2e7 inner iterations of the reference loop;
         # on config 5 that is a fraction of one epoch, run as the first draws of the same stream
         cpu_draws = min(ce * n_local, 20_000_000)
+        if stream is None:                         # the same R stream, generated on the host for the CPU loop
+            stream = sa.RRng(seed).stream(n_local, cpu_draws)
         tc = time.perf_counter()
         if cpu_draws == ce * n_local:
             po.saga(X, prob["y"], st, family=family, penalty="elasticnet", gamma=gamma, alpha=a_l2,
@@ -436,6 +477,8 @@ def main():
         }
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if pipe:
+        S.rng_close()
     S.close()
     if world > 1 or force_merge:
         dist.destroy_process_group()

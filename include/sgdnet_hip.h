@@ -233,6 +233,19 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
                                  int64_t draws_per_epoch, int n_epochs);
 int sgdnet_solver_sync(sgdnet_solver* s);
 
+/* Sample order produced on the device, one epoch ahead of the epoch that consumes it, on a side
+ * stream (what sgdnet_fit_* does for the built-in generator).  generators > 1 runs that many
+ * Mersenne-Twisters side by side ON THE ONE STREAM `rng` defines (jump-ahead, see
+ * sgdnet_rng_jump_poly): the draws are those of a single generator whatever the count.
+ *   rng_open(s, &rng, n, G); for every epoch { rng_next(s, &off); run / enqueue an epoch with
+ *   stream_offset = off; rng_done(s); }  rng_close(s, &rng) -> rng = the state after exactly the
+ *   epochs that were consumed (a speculative generation is discarded).
+ * With virtual shards the draws come in the layout sgdnet_solver_set_virtual_shards describes. */
+int sgdnet_solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t draws_per_epoch, int generators);
+int sgdnet_solver_rng_next(sgdnet_solver* s, int64_t* stream_offset);
+int sgdnet_solver_rng_done(sgdnet_solver* s);
+int sgdnet_solver_rng_close(sgdnet_solver* s, sgdnet_rng* rng);
+
 /* One batched epoch launched eagerly with HIP events around every gather
  * kernel launch; returns summed kernel time and launch count. */
 int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_offset,

@@ -29,6 +29,7 @@ EXPORTS = [
     "sgdnet_solver_sync_end", "sgdnet_solver_set_n_total",
     "sgdnet_solver_export_delta_weighted_async", "sgdnet_solver_set_virtual_shards", "sgdnet_solver_set_merge_period",
     "sgdnet_score_sparse", "sgdnet_score_dense", "sgdnet_predict_sparse", "sgdnet_predict_dense",
+    "sgdnet_solver_rng_open", "sgdnet_solver_rng_next", "sgdnet_solver_rng_done", "sgdnet_solver_rng_close",
 ]
 MEASURES = {"deviance": 0, "mse": 1, "mae": 2, "class": 3}
 
@@ -164,6 +165,10 @@ def load():
                                    C.POINTER(C.c_double), C.c_int, C.POINTER(Control),
                                    C.POINTER(Result)]
     L.sgdnet_rng_fill.argtypes = [C.POINTER(Rng), C.c_uint32, C.POINTER(C.c_uint32), C.c_int64]
+    L.sgdnet_solver_rng_open.argtypes = [C.c_void_p, C.POINTER(Rng), C.c_int64, C.c_int]
+    L.sgdnet_solver_rng_next.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.sgdnet_solver_rng_done.argtypes = [C.c_void_p]
+    L.sgdnet_solver_rng_close.argtypes = [C.c_void_p, C.POINTER(Rng)]
     L.sgdnet_rng_jump_poly.argtypes = [C.c_uint64, C.POINTER(C.c_uint32)]
     L.sgdnet_rng_jump.argtypes = [C.POINTER(Rng), C.POINTER(C.c_uint32), C.POINTER(Rng)]
     L.sgdnet_rng_jump.restype = None

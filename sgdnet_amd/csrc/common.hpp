@@ -57,6 +57,7 @@ struct SagaDev {
   double* vd0;           // one intercept partial per gather workgroup
   double* vref;          // snapshot [g_sum | w | g_sum_b | b] the replicas started from
   unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
+  int cu_reserve;    // CUs left to the sample-order generators that run beside the epoch (LDS gather grids shrink by it)
   int force_global;  // synchronous sharded mode: always the global-atomic gather (D must be one array)
   int ablate;      // -DSGDNET_EXPERIMENTS builds only: SGDNET_ABLATE bit mask, timing-only variants of the gather (results are wrong)
   // data, sample-major (SURVEY.md 8a "x")
@@ -172,6 +173,7 @@ int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
 int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st);
 int launch_delta_apply(const SagaDev& d, double* ref, const double* merged, double w_weight, hipStream_t st);
 int batched_max_classes();
+int lds_target_grid(const SagaDev& d);   // workgroups of the LDS-privatised gather forms (one per CU)
 // binned form: is it the form launch_batch_gather / launch_batch_sweep would use for m draws?
 bool binned_active(const SagaDev& d, int m);
 int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_t st);

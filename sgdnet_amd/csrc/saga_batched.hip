@@ -2249,6 +2249,20 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
 // ------------------------------ launchers ---------------------------------
 int batched_max_classes() { return 16; }
 
+// The LDS-privatised gather forms pin one workgroup per CU (their tables fill the LDS).  When the
+// sample order is generated beside the epoch (solver_rng_*), its G workgroups need CUs of their own:
+// a gather launch of 256 workgroups would otherwise wait for them and run a second round (C4: 930
+// epochs/s with 256 + 32, 1055 with 224 + 32).  SGDNET_LDS_GRID overrides (experiments).
+int lds_target_grid(const SagaDev& d) {
+  static const int forced = [] {
+    const char* e = getenv("SGDNET_LDS_GRID");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
+  const int g = 256 - d.cu_reserve;
+  return g < 64 ? 64 : g;
+}
+
 // Launch geometry of the gather for a batch of m draws.  The LDS-privatised form
 // needs the dense K*p table in LDS twice per CU (2 workgroups per CU) and enough
 // draws per workgroup to amortise its flush.
@@ -2271,10 +2285,7 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     const char* e = getenv("SGDNET_GATHER");   // "lds" | "global": experiments only
     return !e ? 0 : (e[0] == 'l' ? 1 : 2);
   }();
-  static const int target_grid = [] {
-    const char* e = getenv("SGDNET_LDS_GRID");
-    return e ? atoi(e) : 256;
-  }();
+  const int target_grid = lds_target_grid(d);
   const bool fits = table <= 80 * 1024;
   if (d.xd) {   // dense x: wave per draw, slab form only (solver.cpp: check_batched_ok)
     g.dense = true;
@@ -2518,13 +2529,7 @@ bool vs_eligible(const SagaDev& d, int m) {
   return 2 * table + 16 + kLdsStaticReserve <= kLdsPerCu;     // accumulator + coefficient snapshot in LDS
 }
 
-static int vs_grid(const SagaDev& d) {
-  static const int target_grid = [] {
-    const char* e = getenv("SGDNET_LDS_GRID");
-    return e ? atoi(e) : 256;
-  }();
-  return (target_grid / d.V) * d.V;
-}
+static int vs_grid(const SagaDev& d) { return d.v_bps * d.V; }
 
 int launch_vs_broadcast(const SagaDev& d, hipStream_t st) {
   int grid = (int)((2 * d.p + 2 + kBlock - 1) / kBlock);

@@ -964,6 +964,31 @@ int sgdnet_solver_upload_stream(sgdnet_solver* s, const uint32_t* host, int64_t 
   return SGDNET_OK;
 }
 
+// ---- sample-order pipeline in the C ABI (what sgdnet_fit_* uses internally) ----
+int sgdnet_solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t draws_per_epoch, int generators) {
+  if (!s || !rng || draws_per_epoch <= 0) {
+    set_error("sgdnet_solver_rng_open: invalid argument");
+    return SGDNET_EINVAL;
+  }
+  int rc = solver_rng_open(s, rng, draws_per_epoch, generators);
+  if (rc) return rc;
+  return solver_rng_prefetch(s);
+}
+
+int sgdnet_solver_rng_next(sgdnet_solver* s, int64_t* stream_offset) {
+  if (!s || !stream_offset) return SGDNET_EINVAL;
+  int rc = solver_rng_prefetch(s);               // the epoch after this one, concurrently
+  if (rc) return rc;
+  return solver_rng_acquire(s, stream_offset);
+}
+
+int sgdnet_solver_rng_done(sgdnet_solver* s) { return s ? solver_rng_release(s) : SGDNET_EINVAL; }
+
+int sgdnet_solver_rng_close(sgdnet_solver* s, sgdnet_rng* rng) {
+  if (!s || !rng) return SGDNET_EINVAL;
+  return solver_rng_close(s, rng);
+}
+
 int sgdnet_solver_get_stream(sgdnet_solver* s, uint32_t* host, int64_t offset, int64_t count) {
   if (!s || !host || offset < 0 || count <= 0 || offset + count > s->stream_len) {
     set_error("sgdnet_solver_get_stream: range outside the resident stream");
@@ -1047,6 +1072,16 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   if (generators > 1 && !(mt_jump_poly((uint64_t)seg, poly_seg.data()) && mt_jump_poly((uint64_t)n, poly_n.data())))
     generators = 1;
   P.G = generators;
+  {
+    // the generators' workgroups get CUs of their own: the LDS gather forms shrink their grids
+    const int reserve = generators > 1 ? generators : 0;
+    if (reserve != s->d.cu_reserve) {
+      SGD_HIP_TRY(hipStreamSynchronize(s->st));
+      s->d.cu_reserve = reserve;
+      if (s->d.V > 1) s->d.v_bps = lds_target_grid(s->d) / s->d.V;
+      drop_graph(s);
+    }
+  }
   SGD_HIP_TRY(hipMemcpy(P.state[0], rng, sizeof(sgdnet_rng), hipMemcpyHostToDevice));
   if (generators > 1) {
     if (!P.poly_n) {
@@ -1118,6 +1153,11 @@ int solver_rng_close(sgdnet_solver* s, sgdnet_rng* rng) {
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   SGD_HIP_TRY(hipMemcpy(rng, P.state[P.used & 1], sizeof(sgdnet_rng), hipMemcpyDeviceToHost));
   P.open = false;
+  if (s->d.cu_reserve) {
+    s->d.cu_reserve = 0;
+    if (s->d.V > 1) s->d.v_bps = lds_target_grid(s->d) / s->d.V;
+    drop_graph(s);
+  }
   return SGDNET_OK;
 }
 
@@ -1629,11 +1669,7 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
     return rc;
   }
   d.V = n_shards;
-  static const int target_grid = [] {
-    const char* e = getenv("SGDNET_LDS_GRID");
-    return e ? atoi(e) : 256;
-  }();
-  d.v_bps = target_grid / n_shards;
+  d.v_bps = lds_target_grid(d) / n_shards;
   // shard v owns the samples [v * base + min(v, rem), ...): sgdnet_amd/parallel.py shard_bounds
   const int64_t base = d.n / n_shards, rem = d.n % n_shards;
   for (int v = 0; v < 8; ++v) d.v_size[v] = v < n_shards ? (double)(base + (v < rem ? 1 : 0)) : 0.0;

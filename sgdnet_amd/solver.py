@@ -169,6 +169,23 @@ class SagaSolver:
         check(self._L.sgdnet_solver_generate_stream(self._h, C.byref(rrng.state), count))
         self.stream_len = count
 
+    # ---- the device-side sample-order pipeline (sgdnet_solver_rng_*) ----
+    def rng_open(self, rrng, draws_per_epoch=None, generators=1):
+        self._rrng = rrng
+        check(self._L.sgdnet_solver_rng_open(self._h, C.byref(rrng.state),
+                                             self.n if draws_per_epoch is None else draws_per_epoch, generators))
+
+    def rng_next(self):
+        off = C.c_int64(0)
+        check(self._L.sgdnet_solver_rng_next(self._h, C.byref(off)))
+        return off.value
+
+    def rng_done(self):
+        check(self._L.sgdnet_solver_rng_done(self._h))
+
+    def rng_close(self):
+        check(self._L.sgdnet_solver_rng_close(self._h, C.byref(self._rrng.state)))
+
     def get_stream(self, offset=0, count=None):
         count = self.stream_len - offset if count is None else count
         out = np.empty(count, dtype=np.uint32)
