@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--alt-merge", action="store_true",
                     help="N > 1: also measure the exchange scheme that --merge did not select")
     ap.add_argument("--no-alt-merge", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--weak", action="store_true",
+                    help="weak scaling: every rank holds a full copy of the workload's sample count (n = N x n_workload, "
+                         "lambda = 1/n); the default is BASELINE's strong scaling of the fixed problem")
     ap.add_argument("--merge", default="avg", choices=["avg", "sync"],
                     help="N > 1: periodic averaging of locally normalised shard runs (default), or a "
                          "per-batch all-reduce of the scatter accumulator (exact single-GPU iterates)")
@@ -133,6 +136,8 @@ def main():
             print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     n, p, density, family, K, seed = WORKLOADS[args.workload]
+    if args.weak:
+        n *= world
     lo, hi = shard_bounds(n, world, rank)
     n_local = hi - lo
     t_gen = time.time()
@@ -191,7 +196,13 @@ def main():
     merged_job = (world > 1 or force_merge) and not sync_mode
     # every shard (virtual or not) runs n / 32 draws between merges: a rank with V virtual shards
     # exchanges after V * n / 32 draws, when its own shards are averaged on the device anyway
-    shard_period = max(1, n // int(os.environ.get("SGDNET_BENCH_PERIOD_DIV", "32")))
+    # measured with the HIP kernels (profiles/r02d_multi_gpu_emulation.txt): the averaging keeps the
+    # single-process epochs-to-tolerance when every shard runs a QUARTER OF ITS OWN samples between
+    # merges and holds >= 100 samples per feature -- 8 shards of C4 (n / 32, the round-1 rule), and also 16
+    # and 32 shards of a 2x / 4x larger problem (--weak); 16 / 32 shards of the SAME 10M samples need 39 /
+    # >150 epochs instead of 27.  SGDNET_BENCH_PERIOD_DIV forces n / div.
+    div = os.environ.get("SGDNET_BENCH_PERIOD_DIV")
+    shard_period = max(1, n // int(div)) if div else max(1, (n_local // max(1, V)) // 4 if V > 1 else n // 32)
     runs = merge_segments(n_local, n, V * min(batch, n_local // V), period=V * shard_period) \
         if merged_job else [n_local]
     # One process: the sample order is R's single Mersenne-Twister stream of set.seed(config id),
@@ -319,7 +330,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "strong",
+        "scaling": "weak" if args.weak else "strong",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
