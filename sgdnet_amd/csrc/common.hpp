@@ -145,6 +145,9 @@ int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& 
 int launch_dense_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
                        hipStream_t st);
 size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state);
+size_t dense_exact_small_lds_bytes(const SagaDev& d, int64_t nit);
+int launch_dense_exact_small(const SagaDev& d, int penalty, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                             hipStream_t st);
 size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state);
 
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,

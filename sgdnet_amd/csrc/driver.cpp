@@ -630,7 +630,20 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   // built-in generator: the draws are produced in HBM (r_rng_device.hip), one epoch ahead of
   // the epoch that consumes them, on a side stream (solver.cpp: solver_rng_*)
-  const bool pipe = draws.internal();
+  // Exact mode with the built-in generator: the draws come in BLOCKS of several epochs (generated on
+  // the device, ~1M draws at a time) and one launch runs as many epochs as the block still holds,
+  // with the convergence test in the kernel -- a small problem (iris: 150 draws per epoch) is then no
+  // longer one launch + one host round trip per epoch.  The stream is consumed contiguously across
+  // epochs and lambdas, so the generator ends exactly where the reference's would: the final state is
+  // the block's start state stepped by the draws that were used.
+  const bool exact_blocks = draws.internal() && mode == SGDNET_MODE_EXACT && !ctl->debug && !getenv("SGDNET_EXACT_PER_EPOCH");
+  const bool pipe = draws.internal() && !exact_blocks;
+  struct {
+    sgdnet_rng start;
+    int64_t cap = 0, used = 0;
+    bool have = false;
+  } blk;
+  const int64_t blk_epochs = std::max<int64_t>(1, std::min<int64_t>(64, (1 << 20) / std::max<int64_t>(1, n)));
   struct PipeGuard {
     sgdnet_solver* s;
     sgdnet_rng* rng;
@@ -689,7 +702,19 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     while (epochs < ctl->max_iter && !converged) {
       int64_t stream_off = 0;
       auto t0 = now();
-      if (pipe) {
+      unsigned want_epochs = 1;
+      if (exact_blocks) {
+        if (!blk.have || blk.cap - blk.used < n) {
+          blk.start = draws.rng;
+          blk.cap = blk_epochs * n;
+          blk.used = 0;
+          blk.have = true;
+          rc = sgdnet_solver_generate_stream(S, &draws.rng, blk.cap);   // draws.rng <- state after the block
+          if (rc) return rc;
+        }
+        stream_off = blk.used;
+        want_epochs = (unsigned)std::min<int64_t>((blk.cap - blk.used) / n, (int64_t)(ctl->max_iter - epochs));
+      } else if (pipe) {
         rc = solver_rng_prefetch(S);               // next epoch's draws, concurrently
         if (rc) return rc;
         rc = solver_rng_acquire(S, &stream_off);   // this epoch's
@@ -704,9 +729,13 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       t0 = now();
       unsigned ran = 0;
       if (ctl->debug && losses.size() < (size_t)epochs + 1) losses.resize(std::max<size_t>(64, 2 * losses.size()));
-      rc = sgdnet_solver_run(S, mode, batch, stream_off, n, 1, ctl->tol, &ran, &converged,
+      rc = sgdnet_solver_run(S, mode, batch, stream_off, n, want_epochs, ctl->tol, &ran, &converged,
                              ctl->debug ? losses.data() + epochs : nullptr);
       if (rc) return rc;
+      if (exact_blocks) {
+        blk.used += (int64_t)ran * n;
+        draws.pos += (int64_t)ran * n;
+      }
       if (pipe) {
         rc = solver_rng_release(S);
         if (rc) return rc;
@@ -848,6 +877,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     pipe_guard.on = false;
     rc = solver_rng_close(S, &draws.rng);          // state after exactly the epochs that ran
     if (rc) return rc;
+  }
+  if (exact_blocks && blk.have) {                    // state after exactly the draws that were used
+    draws.rng = blk.start;
+    std::vector<uint32_t> scratch((size_t)std::max<int64_t>(1, blk.used));
+    if (blk.used > 0) sgdnet_rng_fill(&draws.rng, (uint32_t)n, scratch.data(), blk.used);
   }
   draws.finish();
   return SGDNET_OK;

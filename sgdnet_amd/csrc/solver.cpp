@@ -1189,6 +1189,9 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       if (rc) return rc;
     }
     const size_t lds_cap = 160 * 1024 - 256;
+    // small dense problems: the register-resident kernel (saga_exact.hip); SGDNET_EXACT_SMALL=0 keeps the general one
+    static const int small_ok = [] { const char* e = getenv("SGDNET_EXACT_SMALL"); return e ? atoi(e) : 1; }();
+    const size_t lds_small = (!s->sparse && small_ok) ? dense_exact_small_lds_bytes(s->d, draws_per_epoch) : 0;
     const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true);
     const bool stage = lds_full <= lds_cap;
     const size_t lds = stage ? lds_full
@@ -1216,7 +1219,8 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       ctl.use_lds = stage ? 1 : 0;
       ctl.out = s->out_dev;
       rc = s->sparse ? launch_sparse_exact(s->d, s->lam_dev, ctl, lds, s->st)
-                     : launch_dense_exact(s->d, s->lam_dev, ctl, lds, s->st);
+                     : (lds_small ? launch_dense_exact_small(s->d, s->lam.penalty, s->lam_dev, ctl, lds_small, s->st)
+                                  : launch_dense_exact(s->d, s->lam_dev, ctl, lds, s->st));
       if (rc) return rc;
       int out[2] = {0, 0};
       SGD_HIP_TRY(hipMemcpyAsync(out, s->out_dev, sizeof(out), hipMemcpyDeviceToHost, s->st));
