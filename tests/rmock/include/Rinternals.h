@@ -29,7 +29,7 @@ typedef unsigned int SEXPTYPE;
 #define NA_INTEGER (-2147483647 - 1)
 #define NA_LOGICAL NA_INTEGER
 
-extern SEXP R_NilValue, R_NamesSymbol, R_DimSymbol;
+extern SEXP R_NilValue, R_NamesSymbol, R_DimSymbol, R_GlobalEnv, R_UnboundValue;
 
 int      TYPEOF(SEXP x);
 R_xlen_t XLENGTH(SEXP x);
@@ -61,6 +61,8 @@ double Rf_asReal(SEXP x);
 SEXP   Rf_asChar(SEXP x);
 int    Rf_isNull(SEXP x);
 SEXP   Rf_GetOption1(SEXP tag);
+SEXP   Rf_findVar(SEXP sym, SEXP env);          /* R_UnboundValue when absent */
+void   Rf_defineVar(SEXP sym, SEXP value, SEXP env);
 SEXP   Rf_protect(SEXP x);
 void   Rf_unprotect(int n);
 #define PROTECT(x) Rf_protect(x)

@@ -30,7 +30,11 @@ struct rmock_sexprec {
 };
 
 static struct rmock_sexprec nil_rec = {NILSXP, 0, NULL, NULL, NULL};
+static struct rmock_sexprec env_rec = {4 /* ENVSXP */, 0, NULL, NULL, NULL};
+static struct rmock_sexprec unbound_rec = {SYMSXP, 0, NULL, NULL, NULL};
 SEXP R_NilValue = &nil_rec;
+SEXP R_GlobalEnv = &env_rec;          /* its variables are kept as the record's attribute list */
+SEXP R_UnboundValue = &unbound_rec;
 SEXP R_NamesSymbol = NULL, R_DimSymbol = NULL;
 
 static SEXP arena = NULL;
@@ -268,6 +272,13 @@ SEXP Rf_GetOption1(SEXP tag) {
   return R_NilValue;
 }
 
+SEXP Rf_findVar(SEXP sym, SEXP env) {
+  for (struct attr_node* a = env->attrib; a; a = a->next)
+    if (a->tag == sym) return a->val;
+  return R_UnboundValue;
+}
+void Rf_defineVar(SEXP sym, SEXP value, SEXP env) { Rf_setAttrib(env, sym, value); }
+
 SEXP Rf_protect(SEXP x) {
   if (++protect_depth > protect_max) protect_max = protect_depth;
   if (protect_depth > 10000) Rf_error("protect(): protection stack overflow");
@@ -291,6 +302,8 @@ static uint32_t mt[624];
 static int mti = 625;
 static long long n_unif = 0;
 static int n_get = 0, n_put = 0;
+void rmock_set_seed(uint32_t seed);
+void PutRNGstate(void);
 
 void rmock_set_seed(uint32_t seed) {               /* set.seed(seed) */
   for (int j = 0; j < 50; ++j) seed = 69069u * seed + 1u;
@@ -301,6 +314,7 @@ void rmock_set_seed(uint32_t seed) {               /* set.seed(seed) */
   }
   memcpy(mt, i_seed + 1, sizeof(mt));
   mti = 624;                                       /* FixupSeeds: dummy[0] = 624 */
+  PutRNGstate();                                   /* set.seed() leaves .Random.seed in the global environment */
   n_unif = 0;
   n_get = n_put = 0;
 }
@@ -334,8 +348,32 @@ double unif_rand(void) {
   if (1.0 - v <= 0.0) return 1.0 - 0.5 * 2.328306437080797e-10;
   return v;
 }
-void GetRNGstate(void) { ++n_get; }
-void PutRNGstate(void) { ++n_put; }
+/* .Random.seed: integer(626) = { kind code, mti, mt[624] }; code = RNG kind (3 = Mersenne-Twister)
+ * + 100 * normal kind (3 = Inversion) + 10000 * sample kind (R >= 3.6: 1 = Rejection) */
+static int rng_kind_code = 10403;
+void GetRNGstate(void) {
+  ++n_get;
+  SEXP seed = Rf_findVar(Rf_install(".Random.seed"), R_GlobalEnv);
+  if (seed == R_UnboundValue) {
+    if (mti == 625) rmock_set_seed(4357u);        /* R would randomise from the clock */
+    return;
+  }
+  if (seed->type != INTSXP || seed->len != 626) Rf_error("'.Random.seed' has wrong length");
+  const int* v = (const int*)seed->data;
+  rng_kind_code = v[0];
+  mti = v[1];
+  memcpy(mt, v + 2, sizeof(mt));
+}
+void PutRNGstate(void) {
+  ++n_put;
+  SEXP seed = Rf_allocVector(INTSXP, 626);
+  int* v = (int*)seed->data;
+  v[0] = rng_kind_code;
+  v[1] = mti;
+  memcpy(v + 2, mt, sizeof(mt));
+  Rf_defineVar(Rf_install(".Random.seed"), seed, R_GlobalEnv);
+}
+void rmock_set_rng_kind(int code) { rng_kind_code = code; }
 
 /* ---- registration ---- */
 static const R_CallMethodDef* registered = NULL;
@@ -354,6 +392,8 @@ int R_useDynamicSymbols(DllInfo* info, int value) {
 
 /* ================= test-side helpers (called from Python through ctypes) ================= */
 void rmock_reset(void) {
+  env_rec.attrib = NULL;
+  rng_kind_code = 10403;
   while (arena) {
     SEXP nx = arena->arena_next;
     free(arena->data);

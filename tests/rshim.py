@@ -36,7 +36,8 @@ def lib():
             ("rmock_reset", None, []), ("rmock_registered", C.c_int, [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]),
             ("rmock_registered_fn", vp, [C.c_char_p]), ("rmock_dynamic_symbols", C.c_int, []),
             ("rmock_rng_state", None, [C.POINTER(C.c_uint32)]), ("R_init_sgdnet", None, [vp]),
-            ("unif_rand", C.c_double, []),
+            ("unif_rand", C.c_double, []), ("GetRNGstate", None, []), ("PutRNGstate", None, []),
+            ("rmock_set_rng_kind", None, [C.c_int]),
         ]:
             f = getattr(L, name)
             f.restype, f.argtypes = res, args

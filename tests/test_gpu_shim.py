@@ -52,16 +52,22 @@ def mock_state(R):
     return np.array(st[:])
 
 
+@pytest.mark.parametrize("rng_path", ["handoff", "callback"])
 @pytest.mark.parametrize("family,K,sparse,alpha", [("gaussian", 1, False, 1.0), ("binomial", 1, True, 0.5),
                                                    ("multinomial", 3, False, 0.8), ("mgaussian", 2, True, 0.5),
                                                    ("binomial", 1, False, 0.0)])
-def test_call_through_the_shim_matches_the_oracle(R, family, K, sparse, alpha):
+def test_call_through_the_shim_matches_the_oracle(R, family, K, sparse, alpha, rng_path):
+    """rng_path: "handoff" = the default with R's Mersenne-Twister -- .Random.seed is handed to the backend,
+    which continues R's stream on the device and hands the advanced state back; "callback" =
+    options(sgdnet.rng = "callback"): one unif_rand() per inner iteration, as Rcpp's R::runif."""
     from oracle import pyoracle as po
     n, p, nl = 300, 6, 12
     x, y = problem(family, n, p, K, 5, sparse)
     ctl = rshim.control_list(family=family, alpha=alpha, n_classes=K, nlambda=nl, lambda_min_ratio=1e-3,
                              thresh=1e-4, is_sparse=sparse)
     ry = rshim.r_matrix(np.asarray(y, dtype=float).reshape(n, -1))
+    if rng_path == "callback":
+        rshim.set_option("sgdnet.rng", "callback")
     R.rmock_set_seed(7)
     res = rshim.call("_sgdnet_SgdnetSparse" if sparse else "_sgdnet_SgdnetDense",
                      rshim.r_dgcmatrix(x) if sparse else rshim.r_matrix(x), ry, ctl)
@@ -87,8 +93,15 @@ def test_call_through_the_shim_matches_the_oracle(R, family, K, sparse, alpha):
     else:
         assert family in ("binomial", "multinomial")       # only exp/log can move a stopping epoch
         assert np.allclose(got["dev_ratio"], ref["dev_ratio"], atol=5e-3)
-    assert R.rmock_unif_count() == int(got["npasses"]) * n   # one unif_rand() per inner iteration
-    assert R.rmock_rng_scope_calls() == 101                  # GetRNGstate(); ...; PutRNGstate();
+    if rng_path == "callback":
+        assert R.rmock_unif_count() == int(got["npasses"]) * n   # one unif_rand() per inner iteration
+        assert R.rmock_rng_scope_calls() == 101                  # GetRNGstate(); ...; PutRNGstate();
+    else:
+        assert R.rmock_unif_count() == 0                         # no host call per draw ...
+        host = po.Rng(7)                                         # ... and R's generator where the reference leaves it
+        host.stream(n, int(got["npasses"]) * n)
+        R.GetRNGstate()
+        assert [R.unif_rand() for _ in range(5)] == list(host.unif(5))
     assert R.rmock_protect_depth() == 0
 
 
@@ -139,8 +152,20 @@ def test_mode_option_reaches_the_batched_kernels_with_virtual_shards(R):
     R.rmock_set_seed(1)
     fast = rshim.decode_result(rshim.call("_sgdnet_SgdnetSparse", rshim.r_dgcmatrix(x), rshim.r_matrix(y),
                                           rshim.control_list(**kw)))
-    assert fast["return_codes"][0] == 0 and R.rmock_unif_count() == int(fast["npasses"]) * n
+    assert fast["return_codes"][0] == 0 and R.rmock_unif_count() == 0
     import sgdnet_amd as sa
     ref = sa.sgdnet(x, y.ravel(), family="binomial", alpha=0.5, lambda_=[1e-3], standardize=False, thresh=1e-9,
                     maxit=300, mode="batched", seed=5)
     assert np.abs(fast["unlist_beta"] - ref.beta[:, 0]).max() <= 1e-6 * np.abs(ref.beta).max()
+
+
+def test_other_rng_kinds_keep_the_callback(R):
+    """RNGkind("Wichmann-Hill") etc.: the backend cannot continue that stream, the shim keeps unif_rand()."""
+    n, p = 200, 3
+    x, y = problem("gaussian", n, p, 1, 2, False)
+    R.rmock_set_seed(1)
+    R.rmock_set_rng_kind(10400)                               # kind code % 100 != 3: not Mersenne-Twister
+    R.PutRNGstate()
+    got = rshim.decode_result(rshim.call("_sgdnet_SgdnetDense", rshim.r_matrix(x), rshim.r_matrix(y.reshape(n, 1)),
+                                         rshim.control_list(family="gaussian", nlambda=5)))
+    assert R.rmock_unif_count() == int(got["npasses"]) * n
