@@ -13,7 +13,7 @@ contiguous shard of the samples and their gradient-memory rows; the model state
   The direction a rank follows in expectation is  grad f_r(w) - grad f_r(w_ref) + g_sum_ref :
   its own shard with full curvature plus a stale correction for the others (the DANE
   correction), which is what makes the local runs agree with each other.  It is stable when the
-  local runs are short: measured (scripts/merge_rule_experiment3.py and the HIP kernels,
+  local runs are short: measured (scripts/dev/merge_rule_experiment3.py and the HIP kernels,
   DESIGN.md 8) with period = n_total / 32 draws per rank the epochs-to-tolerance are those of
   one process for 2-16 ranks and lambda from 0.1/n to 10/n; n_total / 16 costs up to 1.6x the
   epochs on one of the two benchmark shapes, n_total / 2 does not converge.  The first version
