@@ -451,9 +451,12 @@ def main():
     # HBM traffic of the same kernel from the committed PMC passes (rocprofv3 cannot run inside
     # this process); attached only when workload, batch and kernel match that profile
     try:
+        import hashlib
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json")))
-        if (pmc["workload"], pmc["batch"], pmc["n_gpus"], pmc["kernel"], pmc.get("virtual_shards", 1)) == \
-                (args.workload, batch, world, prof["gather_kernel"], V):
+        src_sha = hashlib.sha256(open(os.path.join(ROOT, "sgdnet_amd", "csrc", "saga_batched.hip"), "rb").read()).hexdigest()[:16]
+        # only a profile of THIS kernel source, workload, window and shard count is quoted
+        if (pmc.get("kernel_source_sha16"), pmc["workload"], pmc["batch"], pmc["n_gpus"], pmc["kernel"],
+                pmc.get("virtual_shards", 1)) == (src_sha, args.workload, batch, world, prof["gather_kernel"], V):
             out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
             out["roofline"]["traffic_source"] = "profiles/pmc_latest.json"
     except (OSError, KeyError, ValueError):

@@ -24,7 +24,9 @@ f, w = pick(out["FETCH_SIZE"]), pick(out["WRITE_SIZE"])
 # gfx950: FETCH_SIZE tallies 128-B requests at 64 B (MI355X_MICROARCH.md, HBM section) -> x2.  Calibrated on
 # this kernel's own access pattern: one launch must fetch at least batch x 256-B records
 # (33.6 MB at batch 131072) and the raw counter reads 17.45 MB.  WRITE_SIZE is exact.
-latest = {"workload": bench["config"]["workload"].split(":")[0], "batch": bench["config"]["batch"], "n_gpus": bench["n_gpus"],
+import hashlib
+src_sha = hashlib.sha256(open("sgdnet_amd/csrc/saga_batched.hip", "rb").read()).hexdigest()[:16]
+latest = {"kernel_source_sha16": src_sha, "workload": bench["config"]["workload"].split(":")[0], "batch": bench["config"]["batch"], "n_gpus": bench["n_gpus"],
           "virtual_shards": bench["config"].get("virtual_shards", 1),
           "kernel": kern, "fetch_raw_bytes_per_launch": f * 1024, "fetch_bytes_per_launch": 2 * f * 1024,
           "write_bytes_per_launch": w * 1024, "traffic_bytes_per_launch": (2 * f + w) * 1024,

@@ -824,11 +824,15 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // up -- it can settle into a bounded oscillation that the change-ratio guard never sees and
     // that returns a useless fit (deviance above the null model's).  Then: a quarter of the window
     // for the rest of the path, and this lambda again from the null model.
-    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && li > 0 && lambda[(size_t)li] < lambda[(size_t)li - 1] &&
-        dev > prev_dev * (1.0 + 1e-3) && batch > 64 && retries < 8) {
+    // ... and whatever the order of a user-supplied lambda sequence: a fit whose deviance is above the
+    // null model's (w = 0, intercept only -- the point every lambda can reach) is not a fit.
+    const bool worse_than_previous = li > 0 && lambda[(size_t)li] < lambda[(size_t)li - 1] && dev > prev_dev * (1.0 + 1e-3);
+    const bool worse_than_null = dev > null_dev_scaled * (1.0 + 1e-3) || !std::isfinite(dev);
+    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && (worse_than_previous || worse_than_null) && batch > 64 &&
+        retries < 8) {
       if (getenv("SGDNET_TRACE"))
-        fprintf(stderr, "[sgdnet]   lambda %d: deviance %.6g after %.6g at the previous lambda -> window %lld / 4, again\n",
-                li, dev, prev_dev, (long long)batch);
+        fprintf(stderr, "[sgdnet]   lambda %d: deviance %.6g (previous lambda %.6g, null model %.6g) -> window %lld / 4, again\n",
+                li, dev, prev_dev, null_dev_scaled, (long long)batch);
       if (vshards > 1) {
         vshards = 0;
         rc = sgdnet_solver_set_virtual_shards(S, 0);

@@ -220,3 +220,22 @@ def test_nonnegative_sparse_features_keep_the_automatic_window_stable(sa, monkey
     # depends on the draws: 1e-4 there, 2e-5 below)
     assert abs(fit.dev_ratio[0] - ref.dev_ratio[0]) <= 1e-4
     assert np.allclose(fit.dev_ratio[1:], ref.dev_ratio[1:], atol=2e-5)
+
+
+def test_increasing_lambda_sequence_is_caught_by_the_null_model_net(sa, monkeypatch):
+    """A user-supplied lambda sequence that is not decreasing defeats the "deviance can only fall along the
+    path" safety net; a fit that is worse than the null model is still redone with a shorter window."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2)
+    n, p = 200_000, 2_000
+    X = sp.random(n, p, density=0.005, format="csc", random_state=3)
+    b = rng.standard_normal(p) * (rng.random(p) < 0.1)
+    y = (rng.random(n) < 1 / (1 + np.exp(-np.asarray(X @ b).ravel()))).astype(int)
+    lam = np.geomspace(2e-6, 2e-4, 6)                              # increasing: smallest (hardest) lambda first
+    monkeypatch.setenv("SGDNET_NO_LMAX", "1")                      # window from the diagonal bound: ~8x too long
+    fit = sa.sgdnet(X, y, family="binomial", alpha=1.0, lambda_=lam, thresh=1e-5, standardize=False, mode="auto",
+                    maxit=300, seed=3)
+    ref = sa.sgdnet(X, y, family="binomial", alpha=1.0, lambda_=lam, thresh=1e-5, standardize=False, mode="batched",
+                    batch=500, maxit=300, seed=3)
+    assert np.all(fit.dev_ratio > 0.0) and np.all(np.isfinite(fit.beta))
+    assert np.allclose(fit.dev_ratio, ref.dev_ratio, atol=1e-4)
