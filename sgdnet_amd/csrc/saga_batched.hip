@@ -1411,7 +1411,7 @@ __device__ __forceinline__ void sweep_intercept(const SagaDev& d, const SweepPar
 // adds this block's sum of c_j * w_new_kj into the next batch's c.w slots
 template <int kThreads>
 __device__ __forceinline__ void cw_accumulate(const SagaDev& d, int batch_id, const double* cwp) {
-  __shared__ double red[kThreads / 64][16];
+  __shared__ double red[kThreads / 64][64];
   const int K = d.K;
   for (int k = 0; k < K; ++k) {
     const double t = wave_sum(cwp[k]);
@@ -1876,6 +1876,20 @@ int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_
   return SGDNET_OK;
 }
 
+// class-lane groups of the binned kernels: 16 lanes (K <= 16) or a whole wavefront (K <= 64)
+template <int kGrp>
+__device__ __forceinline__ double grp_sum(double v) {
+#pragma unroll
+  for (int off = kGrp / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, kGrp);
+  return v;
+}
+template <int kGrp>
+__device__ __forceinline__ double grp_max(double v) {
+#pragma unroll
+  for (int off = kGrp / 2; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, kGrp));
+  return v;
+}
+
 // one entry straight into its bin (staging full: a workgroup that drew unusually long rows)
 __device__ __forceinline__ void bin_push_global(const SagaDev& d, const BinEntry& en, unsigned r) {
   const unsigned pos = atomicAdd(d.bin_count + r, 1u);
@@ -1887,13 +1901,13 @@ __device__ __forceinline__ void bin_push_global(const SagaDev& d, const BinEntry
 // Entries of the row beyond the 32 a group keeps in registers (record slots >= 32 and the overflow
 // chain).  Uniform form: every lane sees every entry (x.w); lane form: lane gl takes entries
 // gl, gl + 16, ... of every stretch (staging).
-template <class F>
+template <int kGrp, class F>
 __device__ __forceinline__ void row_rest_uniform(const SagaDev& d, const char* base, int nnz, int ovf, F f) {
   const int cap = d.rec_cap;
   const int cnt0 = nnz < cap ? nnz : cap;
   const int* ridx = reinterpret_cast<const int*>(base + 16);
   const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
-  for (int e = 2 * kGroup; e < cnt0; ++e) f((uint32_t)ridx[e], rval[e]);
+  for (int e = 2 * kGrp; e < cnt0; ++e) f((uint32_t)ridx[e], rval[e]);
   int rem = nnz - cnt0;
   while (rem > 0) {
     const char* ob = d.ovf + (size_t)ovf * kOvfStride;
@@ -1907,13 +1921,13 @@ __device__ __forceinline__ void row_rest_uniform(const SagaDev& d, const char* b
   }
 }
 
-template <class F>
+template <int kGrp, class F>
 __device__ __forceinline__ void row_rest_lane(const SagaDev& d, const char* base, int nnz, int ovf, int gl, F f) {
   const int cap = d.rec_cap;
   const int cnt0 = nnz < cap ? nnz : cap;
   const int* ridx = reinterpret_cast<const int*>(base + 16);
   const double* rval = reinterpret_cast<const double*>(base + d.rec_val_off);
-  for (int e = 2 * kGroup + gl; e < cnt0; e += kGroup) f((uint32_t)ridx[e], rval[e]);
+  for (int e = 2 * kGrp + gl; e < cnt0; e += kGrp) f((uint32_t)ridx[e], rval[e]);
   int rem = nnz - cnt0;
   while (rem > 0) {
     const char* ob = d.ovf + (size_t)ovf * kOvfStride;
@@ -1921,7 +1935,7 @@ __device__ __forceinline__ void row_rest_lane(const SagaDev& d, const char* base
     const int c = reinterpret_cast<const int*>(ob)[1];
     const int* oi = reinterpret_cast<const int*>(ob + 8);
     const double* ov = reinterpret_cast<const double*>(ob + 8 + 4 * kOvfCap);
-    for (int e = gl; e < c; e += kGroup) f((uint32_t)oi[e], ov[e]);
+    for (int e = gl; e < c; e += kGrp) f((uint32_t)oi[e], ov[e]);
     rem -= c;
     ovf = next;
   }
@@ -1962,18 +1976,20 @@ __device__ __forceinline__ BinDraw bin_fetch(const SagaDev& d, int i, uint32_t s
   return q;
 }
 
+template <int kGrp>
 __device__ __forceinline__ double shfl_d(double v, int src) {
   const long long b = __double_as_longlong(v);
-  const int lo = __shfl((int)(b & 0xffffffffll), src, kGroup);
-  const int hi = __shfl((int)(b >> 32), src, kGroup);
+  const int lo = __shfl((int)(b & 0xffffffffll), src, kGrp);
+  const int hi = __shfl((int)(b >> 32), src, kGrp);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+template <int kGrp>
 __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d, const LamParams* lamp,
                                                                        int64_t t0_in_epoch, int m,
                                                                        int batch_id_offset) {
   extern __shared__ __attribute__((aligned(16))) char bsm[];
-  __shared__ double d0s[16];
+  __shared__ double d0s[kGrp];
   __shared__ unsigned n_ent;
   BinEntry* ent = reinterpret_cast<BinEntry*>(bsm);
   unsigned* cnt = reinterpret_cast<unsigned*>(bsm + sizeof(BinEntry) * kBinEntCap);
@@ -1981,8 +1997,8 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   int* rlo = reinterpret_cast<int*>(rbase + d.R);       // R + 1 range boundaries: the range of a feature
   const int K = d.K, KS = d.KS;                          // is found by bisection in LDS, not by a table
                                                          // look-up that costs an L2 request per non-zero
-  const int gl = threadIdx.x & (kGroup - 1);
-  const int group = threadIdx.x / kGroup;
+  const int gl = threadIdx.x & (kGrp - 1);
+  const int group = threadIdx.x / kGrp;
   const int lane = threadIdx.x & 63;
   const bool lane_on = gl < K;
   const int64_t t0 = lamp->stream_base + t0_in_epoch;
@@ -1990,7 +2006,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   PHASE(0);
   for (int r = threadIdx.x; r < d.R; r += kBinBlock) cnt[r] = 0u;
   for (int r = threadIdx.x; r <= d.R; r += kBinBlock) rlo[r] = d.range_lo[r];
-  if (threadIdx.x < 16) d0s[threadIdx.x] = 0.0;
+  if (threadIdx.x < kGrp) d0s[threadIdx.x] = 0.0;
   if (threadIdx.x == 0) n_ent = 0u;
   __syncthreads();
   const double bl = lane_on ? d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0) : 0.0;
@@ -2026,7 +2042,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   };
 
   PHASE(1);
-  constexpr int kG = kBinBlock / kGroup;
+  constexpr int kG = kBinBlock / kGrp;
   const int lo = blockIdx.x * kBinDraws;
   const int hi = (lo + kBinDraws < m) ? lo + kBinDraws : m;
   double gct = 0.0;
@@ -2041,7 +2057,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
     const bool have = cur.i >= 0;
     const int cap = d.rec_cap;
     const int cnt0 = cur.nnz < cap ? cur.nnz : cap;
-    const int creg = cnt0 < 2 * kGroup ? cnt0 : 2 * kGroup;
+    const int creg = cnt0 < 2 * kGrp ? cnt0 : 2 * kGrp;
     const bool rest = have && (cur.nnz > creg);
     const char* base = d.rec + (size_t)cur.s * d.rec_stride;
     // x . w: the feature ids sit in the group's registers, so the K-contiguous reads of w are all
@@ -2050,40 +2066,40 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
     const double mold = (have && lane_on) ? d.M[gl + (int64_t)cur.s * K] : 0.0;
     double acc = 0.0;
 #pragma unroll
-    for (int e0 = 0; e0 < kGroup; e0 += kBinW) {
+    for (int e0 = 0; e0 < kGrp; e0 += kBinW) {
       if (e0 > 0 && !__any(have && creg > e0)) break;
       double wv[kBinW];
 #pragma unroll
       for (int e = 0; e < kBinW; ++e) {
-        const int j = __shfl(cur.j0, e0 + e, kGroup);
+        const int j = __shfl(cur.j0, e0 + e, kGrp);
         wv[e] = (have && e0 + e < creg && lane_on) ? d.wpad[(int64_t)j * KS + gl] : 0.0;
       }
 #pragma unroll
-      for (int e = 0; e < kBinW; ++e) acc += shfl_d(cur.v0, e0 + e) * wv[e];
+      for (int e = 0; e < kBinW; ++e) acc += shfl_d<kGrp>(cur.v0, e0 + e) * wv[e];
     }
     // record slots 16..31 (3 % of the rows at 10 non-zeros per sample): read where they are needed
     int j1 = 0;
     double v1 = 0.0;
-    if (__any(have && creg > kGroup)) {
-      if (have && kGroup + gl < creg) {
-        j1 = reinterpret_cast<const int*>(base + 16)[kGroup + gl];
-        v1 = reinterpret_cast<const double*>(base + d.rec_val_off)[kGroup + gl];
+    if (__any(have && creg > kGrp)) {
+      if (have && kGrp + gl < creg) {
+        j1 = reinterpret_cast<const int*>(base + 16)[kGrp + gl];
+        v1 = reinterpret_cast<const double*>(base + d.rec_val_off)[kGrp + gl];
       }
-      for (int e = 0; e < kGroup; ++e) {
-        const int j = __shfl(j1, e, kGroup);
-        const double v = shfl_d(v1, e);
-        if (have && kGroup + e < creg && lane_on) acc += v * d.wpad[(int64_t)j * KS + gl];
+      for (int e = 0; e < kGrp; ++e) {
+        const int j = __shfl(j1, e, kGrp);
+        const double v = shfl_d<kGrp>(v1, e);
+        if (have && kGrp + e < creg && lane_on) acc += v * d.wpad[(int64_t)j * KS + gl];
       }
     }
     if (rest)
-      row_rest_uniform(d, base, cur.nnz, cur.ovf, [&](uint32_t j, double v) {
+      row_rest_uniform<kGrp>(d, base, cur.nnz, cur.ovf, [&](uint32_t j, double v) {
         if (lane_on) acc += v * d.wpad[(int64_t)j * KS + gl];
       });
     const double lp = acc + bl;
     double g;
     if (d.family == SGDNET_MULTINOMIAL) {
-      const double mx = group_max(lane_on ? lp : -HUGE_VAL);
-      const double ssum = group_sum(lane_on ? exp(lp - mx) : 0.0);
+      const double mx = grp_max<kGrp>(lane_on ? lp : -HUGE_VAL);
+      const double ssum = grp_sum<kGrp>(lane_on ? exp(lp - mx) : 0.0);
       const double lse = log(ssum) + mx;
       g = exp(lp - lse);
       if ((unsigned)gl == (unsigned)(cur.y0 + 0.5)) g -= 1.0;
@@ -2093,7 +2109,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
       g = lp - ((have && lane_on) ? d.y[(int64_t)cur.s * d.Ky + gl] : 0.0);
     }
     // a repeat inside the batch sees the same snapshot: gradient change 0, nothing to stage
-    const bool first = have && (__shfl(cur.prev != batch_id ? 1 : 0, 0, kGroup) != 0);
+    const bool first = have && (__shfl(cur.prev != batch_id ? 1 : 0, 0, kGrp) != 0);
     if (first && lane_on) {
       const double gc = g - mold;
       d.M[gl + (int64_t)cur.s * K] = g;
@@ -2101,13 +2117,13 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
       gct += gc;
     }
     stage(first && gl < creg, cur.i, (uint32_t)cur.j0, cur.v0, r0);
-    if (__any(first && creg > kGroup)) {
-      const bool a1 = first && kGroup + gl < creg;
+    if (__any(first && creg > kGrp)) {
+      const bool a1 = first && kGrp + gl < creg;
       const unsigned r1 = range_of(j1);
       stage(a1, cur.i, (uint32_t)j1, v1, r1);
     }
     if (first && rest)
-      row_rest_lane(d, base, cur.nnz, cur.ovf, gl, [&](uint32_t j, double v) {
+      row_rest_lane<kGrp>(d, base, cur.nnz, cur.ovf, gl, [&](uint32_t j, double v) {
         stage(true, cur.i, j, v, range_of((int)j));
       });
     cur = nxt;
@@ -2147,10 +2163,11 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   PHASE(5);
 }
 
+template <int kGrp>
 __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
                                                                         int n_parts, int batch_id_offset) {
   extern __shared__ __attribute__((aligned(16))) double Dl[];
-  __shared__ double sh_d0[16];
+  __shared__ double sh_d0[kGrp];
   const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
   const int K = d.K;
   const int r = blockIdx.x;
@@ -2175,9 +2192,10 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
   // then works through them with lane = class: the K-contiguous gradient changes of the 16 draws
   // are requested together, the products go into the slice with ds_add_f64.  The next 16 entries
   // are requested before the current ones are used.
-  const int gl = threadIdx.x & (kGroup - 1);
-  const int group = threadIdx.x / kGroup;
-  constexpr int kGroups = kRangeBlock / kGroup;
+  const int gl = threadIdx.x & (kGrp - 1);
+  const int group = threadIdx.x / kGrp;
+  constexpr int kGrps = kRangeBlock / kGrp;
+  constexpr int kEnt = 16;                        // entries a group takes per round (held by its first 16 lanes)
   unsigned cntb = d.bin_count[r];
   const int64_t b0 = d.bin_off[r], bcap = d.bin_off[r + 1] - b0;
   if ((int64_t)cntb > bcap) cntb = (unsigned)bcap;
@@ -2185,25 +2203,25 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
   const bool lane_on = gl < K;
   const BinEntry none{0u, (uint32_t)lo, 0.0};
   PHASE(6);
-  unsigned e0 = (unsigned)group * kGroup;
-  BinEntry mine = (e0 + gl < cntb) ? bin[e0 + gl] : none;
+  unsigned e0 = (unsigned)group * kEnt;
+  BinEntry mine = (gl < kEnt && e0 + gl < cntb) ? bin[e0 + gl] : none;
   for (int i = threadIdx.x; i < E; i += kRangeBlock) Dl[i] = 0.0;
   if (need_d0) block_d0<kRangeBlock>(d, n_parts, batch_id, sh_d0);
   __syncthreads();
   PHASE(7);
-  for (; e0 < cntb; e0 += kGroups * kGroup) {
-    const unsigned en = e0 + kGroups * kGroup;
-    const BinEntry nxt = (en + gl < cntb) ? bin[en + gl] : none;
-    double gq[kGroup];
+  for (; e0 < cntb; e0 += kGrps * kEnt) {
+    const unsigned en = e0 + kGrps * kEnt;
+    const BinEntry nxt = (gl < kEnt && en + gl < cntb) ? bin[en + gl] : none;
+    double gq[kEnt];
 #pragma unroll
-    for (int qq = 0; qq < kGroup; ++qq) {
-      const int t = __shfl((int)mine.t, qq, kGroup);
+    for (int qq = 0; qq < kEnt; ++qq) {
+      const int t = __shfl((int)mine.t, qq, kGrp);
       gq[qq] = (lane_on && e0 + qq < cntb) ? d.gcb[(int64_t)t * d.KS + gl] : 0.0;
     }
 #pragma unroll
-    for (int qq = 0; qq < kGroup; ++qq) {
-      const int j = __shfl((int)mine.j, qq, kGroup);
-      const double x = shfl_d(mine.x, qq);
+    for (int qq = 0; qq < kEnt; ++qq) {
+      const int j = __shfl((int)mine.j, qq, kGrp);
+      const double x = shfl_d<kGrp>(mine.x, qq);
       if (lane_on && e0 + qq < cntb) scatter_add<true>(Dl + (j - lo) * K + gl, x * gq[qq]);
     }
     mine = nxt;
@@ -2213,12 +2231,12 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
   PHASE(9);
   if (threadIdx.x == 0) d.bin_count[r] = 0u;                 // the next batch fills the bin again
   // ---- per-feature update of this range ----
-  double cwp[16];
+  double cwp[kGrp];
   for (int k = 0; k < K; ++k) cwp[k] = 0.0;
   if (q.penalty == SGDNET_GROUPLASSO) {
     for (int f = threadIdx.x; f < hi - lo; f += kRangeBlock) {
       const int64_t j = lo + f;
-      double dj[16], wn[16];
+      double dj[kGrp], wn[kGrp];
       const double cj = d.standardize ? d.c[j] : 0.0;
       for (int k = 0; k < K; ++k) dj[k] = Dl[f * K + k] - (d.standardize ? cj * sh_d0[k] : 0.0);
       sweep_feature(d, q, j, dj, wn);
@@ -2247,7 +2265,7 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
 }
 
 // ------------------------------ launchers ---------------------------------
-int batched_max_classes() { return 16; }
+int batched_max_classes() { return 64; }   // 17..64: sparse x only (binned form, a wavefront per draw)
 
 // The LDS-privatised gather forms pin one workgroup per CU (their tables fill the LDS).  When the
 // sample order is generated beside the epoch (solver_rng_*), its G workgroups need CUs of their own:
@@ -2377,11 +2395,11 @@ int64_t batch_gather_slab_doubles(const SagaDev& d, int m) {
 int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, int tail,
                         int batch_id_offset, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   (void)tail;
-  if (d.K > 16) {
-    set_error("batched mode supports n_classes <= 16 (got %d)", d.K);
+  const GatherPlan g = plan_gather(d, m);
+  if (d.K > 16 && !g.binned) {
+    set_error("batched mode with more than 16 classes needs the binned form (sparse x, n_classes <= 64; got %d)", d.K);
     return SGDNET_EUNSUPPORTED;
   }
-  const GatherPlan g = plan_gather(d, m);
   if (g.dense) {
     if (!g.lds) {
       set_error("batched mode on dense x needs n_classes * n_features <= 10240 (LDS copy of the accumulator)");
@@ -2419,14 +2437,22 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
     int cur = 0;
     (void)hipGetDevice(&cur);
     if (!battr_done_dev[cur & 63]) {
-      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_gather_kernel),
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_gather_kernel<16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
-      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel),
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_gather_kernel<64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<16>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRangeLdsBytes));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRangeLdsBytes));
       battr_done_dev[cur & 63] = true;
     }
-    hipExtLaunchKernelGGL(saga_binned_gather_kernel, dim3(g.grid), dim3(kBinBlock), g.lds_bytes, st, ev0, ev1, 0, d,
-                          lam, t0_in_epoch, m, batch_id_offset);
+    if (d.K <= 16)
+      hipExtLaunchKernelGGL(saga_binned_gather_kernel<16>, dim3(g.grid), dim3(kBinBlock), g.lds_bytes, st, ev0, ev1, 0,
+                            d, lam, t0_in_epoch, m, batch_id_offset);
+    else
+      hipExtLaunchKernelGGL(saga_binned_gather_kernel<64>, dim3(g.grid), dim3(kBinBlock), g.lds_bytes, st, ev0, ev1, 0,
+                            d, lam, t0_in_epoch, m, batch_id_offset);
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;
   }
@@ -2496,9 +2522,14 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
   const int n_parts = ov_m > 0.0 ? kD0Slots : (g.grid < kD0Slots ? g.grid : kD0Slots);
   const SweepOverride ov{ov_r, ov_ls, ov_m};
   if (g.binned) {
-    hipExtLaunchKernelGGL(saga_binned_sweep_kernel, dim3(d.R + 1), dim3(kRangeBlock),
-                          sizeof(double) * (size_t)d.K * (size_t)d.range_max, st, ev0, ev1, 0, d, lam, tail, n_parts,
-                          batch_id_offset);
+    if (d.K <= 16)
+      hipExtLaunchKernelGGL(saga_binned_sweep_kernel<16>, dim3(d.R + 1), dim3(kRangeBlock),
+                            sizeof(double) * (size_t)d.K * (size_t)d.range_max, st, ev0, ev1, 0, d, lam, tail, n_parts,
+                            batch_id_offset);
+    else
+      hipExtLaunchKernelGGL(saga_binned_sweep_kernel<64>, dim3(d.R + 1), dim3(kRangeBlock),
+                            sizeof(double) * (size_t)d.K * (size_t)d.range_max, st, ev0, ev1, 0, d, lam, tail, n_parts,
+                            batch_id_offset);
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;
   }

@@ -174,8 +174,10 @@ void drop_graph(sgdnet_solver* s) {
 int ensure_binned(sgdnet_solver* s, int64_t batch) {
   SagaDev& d = s->d;
   static const int allow = [] { const char* e = getenv("SGDNET_BINNED"); return e ? atoi(e) : 1; }();
-  const bool want = allow && s->sparse && !d.xd && d.rec && d.idx && d.K <= 16 && !d.force_global &&
-                    sizeof(double) * (size_t)d.K * (size_t)d.p > 80 * 1024 && batch >= 4096 && d.p < (1ll << 31);
+  // more than 16 classes: the only batched form there is (a wavefront per draw), whatever the sizes
+  const bool want = allow && s->sparse && !d.xd && d.rec && d.idx && d.K <= 64 && !d.force_global &&
+                    d.p < (1ll << 31) &&
+                    (d.K > 16 || (sizeof(double) * (size_t)d.K * (size_t)d.p > 80 * 1024 && batch >= 4096));
   if (!want) {
     if (d.R > 0 && d.bins) {             // e.g. a tiny batch after a large one: fall back to the atomic form
       d.bins = nullptr;

@@ -795,16 +795,32 @@ def test_extreme_shapes_batched_and_exact(sa, oracle, family, K, n, p, dens, bat
         assert relerr(got[k], st[k]) < TOL_EXACT, k
 
 
-def test_fit_with_more_than_sixteen_classes_falls_back_to_exact(sa, oracle):
+def test_more_than_sixteen_classes(sa, oracle):
+    """17..64 classes: sparse x runs the binned form with a wavefront per draw (per-epoch parity with the
+    batched oracle, then the fit driver against the exact optimum); dense x and K > 64 keep the exact
+    iteration behind mode = "batched"."""
+    # kernels: K = 18 and K = 40, elastic net and group lasso, tail batch, small p (the table would fit LDS)
+    for family, K, penalty in (("multinomial", 18, "elasticnet"), ("mgaussian", 40, "grouplasso")):
+        x, y = make_problem(family, K, 3000, 50, 0.2, seed=12)
+        ref, got = run_both(sa, oracle, x, y, family=family, K=K, penalty=penalty, gamma=0.02, alpha=1e-3, beta=1e-3,
+                            epochs=2, mode="batched", batch=1300, seed=4)
+        for name in STATE:
+            assert relerr(got[2][name], ref[2][name]) < TOL_BATCHED, (K, name)
     rng = np.random.default_rng(8)
     n, p, K = 600, 6, 18
     X = sp.csc_matrix(rng.standard_normal((n, p)) * (rng.random((n, p)) < 0.7))
     y = rng.integers(0, K, n)
     y[:K] = np.arange(K)
     y[K:2 * K] = np.arange(K)                              # every class at least twice
-    kw = dict(family="multinomial", alpha=0.5, lambda_=[0.01], standardize=False, thresh=1e-6, maxit=300)
-    ref = oracle.fit(X, y, seed=2, **kw)
-    fit = sa.sgdnet(X, y, seed=2, mode="batched", **kw)   # K > 16: the exact iteration, same stream
+    kw = dict(family="multinomial", alpha=0.5, lambda_=[0.01], standardize=False, maxit=3000)
+    ref = oracle.fit(X, y, seed=2, thresh=1e-10, **kw)
+    fit = sa.sgdnet(X, y, seed=2, mode="batched", batch=64, thresh=1e-10, **kw)      # sparse: batched kernels
+    assert fit.return_codes[0] == 0
+    for k in range(K):
+        assert np.abs(fit.beta[k][:, 0] - ref["beta"][k, :, 0]).max() < 1e-7
+    kw["thresh"] = 1e-6
+    ref = oracle.fit(np.asarray(X.todense()), y, seed=2, **kw)
+    fit = sa.sgdnet(np.asarray(X.todense()), y, seed=2, mode="batched", **kw)         # dense: the exact iteration
     assert fit.npasses == ref["npasses"]
     for k in range(K):
         assert relerr(fit.beta[k][:, 0], ref["beta"][k, :, 0]) < 1e-8 or np.abs(ref["beta"][k, :, 0]).max() < 1e-12
