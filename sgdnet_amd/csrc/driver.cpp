@@ -59,6 +59,7 @@ struct Features {
   DeviceSetup* dev = nullptr;
   hipStream_t st = nullptr;
   double dev_max_mean_sq = 0.0;
+  bool dense_dev = false;       // dense x prepared by dense_setup_* (large matrices)
 };
 
 // math.h:66-79 Mean / :114-130 StandardDeviation (population sd, 0 -> 1)
@@ -125,7 +126,7 @@ void transpose_to_sample_major(const double* xd, int64_t n, int64_t p, double* x
 
 // x^T v for every feature column; v is n x cols column-major
 int xt_times(const Features& X, const double* v, int cols, double* out) {
-  if (X.dev) return device_xt_times(*X.dev, v, cols, out, X.st);
+  if (X.dev) return X.dense_dev ? dense_xt_times(*X.dev, v, cols, out, X.st) : device_xt_times(*X.dev, v, cols, out, X.st);
   for (int c = 0; c < cols; ++c) {
     const double* vc = v + (int64_t)c * X.n;
     parallel_for(X.p, X.sparse ? 0.0 : (double)X.n * (double)X.p, [&](int64_t j0, int64_t j1) {
@@ -323,6 +324,35 @@ struct DrawSource {
   }
 };
 
+// largest eigenvalue of Xs'Xs / m for an m x p column-major sample of the rows (power iteration)
+double sample_gram_lmax(const double* xs, size_t m, size_t p) {
+  std::vector<double> v(p, 1.0 / std::sqrt((double)p)), w(p), u(m);
+  double lmax = 0.0;
+  for (int it = 0; it < 30; ++it) {
+    std::fill(u.begin(), u.end(), 0.0);
+    for (size_t j = 0; j < p; ++j) {
+      const double* col = xs + j * m;
+      const double vj = v[j];
+      for (size_t r = 0; r < m; ++r) u[r] += col[r] * vj;
+    }
+    double nrm = 0.0;
+    for (size_t j = 0; j < p; ++j) {
+      const double* col = xs + j * m;
+      double sacc = 0.0;
+      for (size_t r = 0; r < m; ++r) sacc += col[r] * u[r];
+      w[j] = sacc / (double)m;
+      nrm += w[j] * w[j];
+    }
+    nrm = std::sqrt(nrm);
+    if (!(nrm > 0.0)) break;
+    const double prev = lmax;
+    lmax = nrm;
+    for (size_t j = 0; j < p; ++j) v[j] = w[j] / nrm;
+    if (it >= 3 && std::fabs(lmax - prev) <= 2e-3 * lmax) break;
+  }
+  return lmax;
+}
+
 int64_t auto_batch(const Features& X, double max_sample_sqnorm) {
   // largest mean squared feature value = largest diagonal entry of X'X/n
   double diag = 0.0;
@@ -505,7 +535,20 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   // ColNormsMax: utils.h:60-85
   double norm_max = 0.0;
-  if (X.dev) {
+  if (X.dev && X.dense_dev) {
+    // L_F for the automatic window from a strided sample of the standardised rows (<= 2e6 elements), while
+    // the column-major copy is still there; then transpose + row norms on the device
+    if (ctl->mode != SGDNET_MODE_EXACT && ctl->batch <= 0 && p > 1) {
+      const int64_t m_max = std::max<int64_t>(1000, 2000000 / p);
+      const int64_t stride = (n + m_max - 1) / m_max, m = (n + stride - 1) / stride;
+      std::vector<double> xs((size_t)(m * p));
+      int rcd = dense_sample_rows(*X.dev, stride, m, xs.data(), X.st);
+      if (rcd) return rcd;
+      X.dev_max_mean_sq = std::max(X.dev_max_mean_sq, sample_gram_lmax(xs.data(), (size_t)m, (size_t)p));
+    }
+    int rcd = dense_setup_finish(*X.dev, X.st, &norm_max);
+    if (rcd) return rcd;
+  } else if (X.dev) {
     // transpose, row norms and record packing on the device; y rides inside the records
     static const int align = [] { const char* e = getenv("SGDNET_REC_ALIGN"); return e ? atoi(e) : 128; }();
     int rcd = device_setup_finish(*X.dev, yt.data(), Ky, ctl->standardize ? 1 : 0, align, X.st, &norm_max);
@@ -579,7 +622,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   pb.fit_intercept = fit_intercept ? 1 : 0;
   pb.standardize = (X.sparse && ctl->standardize) ? 1 : 0;
   if (X.dev) {
-    // matrix, centring vector and records are adopted from the device setup
+    // matrix (and for sparse x the centring vector and records) are adopted from the device setup
   } else if (X.sparse) {
     pb.rowptr = X.sptr.data();
     pb.colidx = X.sidx.data();
@@ -1004,6 +1047,32 @@ int sgdnet_fit_dense(const double* x, int64_t n, int64_t p, const double* y, int
   X.sparse = false;
   X.n = n;
   X.p = p;
+  if (n * p >= kDenseDeviceSetupElems && !getenv("SGDNET_HOST_SETUP")) {
+    // large dense x: statistics, standardisation, lambda_max products, transpose and row norms on the
+    // device (dense_setup_*), no host pass over the n * p doubles beyond the one upload
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+      set_error("no HIP device available: the SAGA backend has no CPU fallback");
+      return SGDNET_ENODEVICE;
+    }
+    if (ctl->device < 0 || ctl->device >= ndev) {
+      set_error("device %d out of range (%d devices)", ctl->device, ndev);
+      return SGDNET_EINVAL;
+    }
+    SGD_HIP_TRY(hipSetDevice(ctl->device));
+    DeviceSetup dev;
+    hipStream_t st = nullptr;
+    SGD_HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    X.dev = &dev;
+    X.st = st;
+    X.dense_dev = true;
+    X.x_center_scaled.assign((size_t)p, 0.0);
+    rc = dense_setup_begin(dev, x, n, p, ctl->standardize ? 1 : 0, st, X.x_center, X.x_scale, &X.dev_max_mean_sq);
+    if (!rc) rc = fit_common(X, y, y_cols, ctl, out);
+    dev.release();
+    (void)hipStreamDestroy(st);
+    return rc;
+  }
   X.xd.assign(x, x + n * p);
   X.x_center.assign((size_t)p, 0.0);
   X.x_scale.assign((size_t)p, 1.0);

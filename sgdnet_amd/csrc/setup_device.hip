@@ -211,8 +211,9 @@ int grid_for(int64_t items) {
 
 void DeviceSetup::release() {
   for (void* p : {(void*)colptr, (void*)rowidx, (void*)val, (void*)sptr, (void*)sidx, (void*)sval,
-                  (void*)center_scaled, (void*)rec, (void*)ovf})
+                  (void*)center_scaled, (void*)rec, (void*)ovf, (void*)xd_cm, (void*)xd_t})
     if (p) (void)hipFree(p);
+  xd_cm = xd_t = nullptr;
   colptr = rowidx = nullptr;
   val = sval = center_scaled = nullptr;
   sptr = nullptr;
@@ -434,6 +435,174 @@ int device_setup_finish(DeviceSetup& S, const double* y_host, int y_rows, int st
   SGD_HIP_TRY(hipStreamSynchronize(st));
   for (void* q : {(void*)tmp, (void*)counts, (void*)stats, (void*)ocnt, (void*)ooff, (void*)y_dev})
     if (q) (void)hipFree(q);
+  return SGDNET_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Dense x (SURVEY.md 8 row f1 for SgdnetDense): the same once-per-fit passes for a column-major
+// n x p matrix.  All streaming: a block per column for the statistics and products, LDS tiles for
+// the transpose.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kTB) void dense_col_stats_kernel(double* x, int64_t n, int standardize, double* center,
+                                                              double* scale, double* mean_sq) {
+  __shared__ double red[kTB / 64];
+  double* col = x + (int64_t)blockIdx.x * n;
+  double mean = 0.0, sd = 1.0;
+  if (standardize) {
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kTB) s += col[i];
+    mean = block_sum(s, red) / (double)n;                          // math.h:66-79
+    double v = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kTB) {
+      const double dlt = col[i] - mean;
+      v += dlt * dlt;
+    }
+    const double var = block_sum(v, red) / (double)n;              // math.h:114-130 (population sd, 0 -> 1)
+    sd = var == 0.0 ? 1.0 : sqrt(var);
+    for (int64_t i = threadIdx.x; i < n; i += kTB) col[i] = (col[i] - mean) / sd;   // utils.h:99-108
+    __syncthreads();
+  }
+  double sq = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += kTB) sq += col[i] * col[i];
+  sq = block_sum(sq, red);
+  if (threadIdx.x == 0) {
+    center[blockIdx.x] = mean;
+    scale[blockIdx.x] = sd;
+    mean_sq[blockIdx.x] = sq / (double)n;
+  }
+}
+
+__global__ __launch_bounds__(kTB) void dense_xt_times_kernel(const double* x, const double* ymap, int64_t n, int64_t p,
+                                                             int cols, double* out) {
+  __shared__ double red[kTB / 64];
+  const double* col = x + (int64_t)blockIdx.x * n;
+  for (int c = 0; c < cols; ++c) {
+    const double* yc = ymap + (int64_t)c * n;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += kTB) s += col[i] * yc[i];
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) out[blockIdx.x + (int64_t)c * p] = s;
+  }
+}
+
+// xt[j + i*p] = x[i + j*n]: 32 x 32 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void dense_transpose_kernel(const double* x, int64_t n, int64_t p, double* xt) {
+  __shared__ double tile[32][33];
+  const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = i0 + tx, j = j0 + r;
+    tile[r][tx] = (i < n && j < p) ? x[i + j * n] : 0.0;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = i0 + r, j = j0 + tx;
+    if (i < n && j < p) xt[j + i * p] = tile[tx][r];
+  }
+}
+
+// max over samples of |x_i|^2 on the sample-major matrix: a wavefront per sample
+__global__ __launch_bounds__(kTB) void dense_row_norm_kernel(const double* xt, int64_t n, int64_t p,
+                                                             unsigned long long* max_bits) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave = ((int64_t)blockIdx.x * kTB + threadIdx.x) >> 6, nwaves = (int64_t)gridDim.x * (kTB / 64);
+  double best = 0.0;
+  for (int64_t i = wave; i < n; i += nwaves) {
+    const double* row = xt + i * p;
+    double s = 0.0;
+    for (int64_t j = lane; j < p; j += 64) s += row[j] * row[j];
+    s = wave_sum(s);
+    best = s > best ? s : best;
+  }
+  if (lane == 0 && best > 0.0) atomicMax(max_bits, (unsigned long long)__double_as_longlong(best));
+}
+
+__global__ __launch_bounds__(kTB) void dense_sample_rows_kernel(const double* x, int64_t n, int64_t p, int64_t stride,
+                                                                int64_t m, double* out) {
+  for (int64_t t = (int64_t)blockIdx.x * kTB + threadIdx.x; t < m * p; t += (int64_t)gridDim.x * kTB) {
+    const int64_t r = t % m, j = t / m;
+    out[t] = x[r * stride + j * n];
+  }
+}
+
+int dense_setup_begin(DeviceSetup& S, const double* x_host, int64_t n, int64_t p, int standardize, hipStream_t st,
+                      std::vector<double>& x_center, std::vector<double>& x_scale, double* max_mean_sq) {
+  S.n = n;
+  S.p = p;
+  int rc;
+  if ((rc = dmalloc(&S.xd_cm, (size_t)n * (size_t)p))) return rc;
+  SGD_HIP_TRY(hipMemcpyAsync(S.xd_cm, x_host, sizeof(double) * (size_t)n * (size_t)p, hipMemcpyHostToDevice, st));
+  double *center = nullptr, *scale = nullptr, *msq = nullptr;
+  if ((rc = dmalloc(&center, (size_t)p)) || (rc = dmalloc(&scale, (size_t)p)) || (rc = dmalloc(&msq, (size_t)p))) return rc;
+  hipLaunchKernelGGL(dense_col_stats_kernel, dim3((unsigned)p), dim3(kTB), 0, st, S.xd_cm, n, standardize, center, scale,
+                     msq);
+  SGD_HIP_TRY(hipGetLastError());
+  x_center.resize((size_t)p);
+  x_scale.resize((size_t)p);
+  std::vector<double> m((size_t)p);
+  SGD_HIP_TRY(hipMemcpyAsync(x_center.data(), center, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, st));
+  SGD_HIP_TRY(hipMemcpyAsync(x_scale.data(), scale, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, st));
+  SGD_HIP_TRY(hipMemcpyAsync(m.data(), msq, sizeof(double) * (size_t)p, hipMemcpyDeviceToHost, st));
+  SGD_HIP_TRY(hipStreamSynchronize(st));
+  double best = 0.0;
+  for (double v : m) best = v > best ? v : best;
+  *max_mean_sq = best;
+  (void)hipFree(center);
+  (void)hipFree(scale);
+  (void)hipFree(msq);
+  return SGDNET_OK;
+}
+
+int dense_xt_times(const DeviceSetup& S, const double* ymap_host, int cols, double* xty_host, hipStream_t st) {
+  double *ymap = nullptr, *out = nullptr;
+  int rc;
+  if ((rc = dmalloc(&ymap, (size_t)S.n * cols)) || (rc = dmalloc(&out, (size_t)S.p * cols))) return rc;
+  SGD_HIP_TRY(hipMemcpyAsync(ymap, ymap_host, sizeof(double) * (size_t)S.n * cols, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(dense_xt_times_kernel, dim3((unsigned)S.p), dim3(kTB), 0, st, S.xd_cm, ymap, S.n, S.p, cols, out);
+  SGD_HIP_TRY(hipGetLastError());
+  SGD_HIP_TRY(hipMemcpyAsync(xty_host, out, sizeof(double) * (size_t)S.p * cols, hipMemcpyDeviceToHost, st));
+  SGD_HIP_TRY(hipStreamSynchronize(st));
+  (void)hipFree(ymap);
+  (void)hipFree(out);
+  return SGDNET_OK;
+}
+
+int dense_sample_rows(const DeviceSetup& S, int64_t stride, int64_t m, double* out_host, hipStream_t st) {
+  double* out = nullptr;
+  int rc;
+  if ((rc = dmalloc(&out, (size_t)m * (size_t)S.p))) return rc;
+  int64_t grid = (m * S.p + kTB - 1) / kTB;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(dense_sample_rows_kernel, dim3((unsigned)grid), dim3(kTB), 0, st, S.xd_cm, S.n, S.p, stride, m, out);
+  SGD_HIP_TRY(hipGetLastError());
+  SGD_HIP_TRY(hipMemcpyAsync(out_host, out, sizeof(double) * (size_t)m * (size_t)S.p, hipMemcpyDeviceToHost, st));
+  SGD_HIP_TRY(hipStreamSynchronize(st));
+  (void)hipFree(out);
+  return SGDNET_OK;
+}
+
+// transpose to sample-major, row norms; the column-major copy is released
+int dense_setup_finish(DeviceSetup& S, hipStream_t st, double* max_sqnorm) {
+  int rc;
+  if ((rc = dmalloc(&S.xd_t, (size_t)S.n * (size_t)S.p))) return rc;
+  hipLaunchKernelGGL(dense_transpose_kernel, dim3((unsigned)((S.n + 31) / 32), (unsigned)((S.p + 31) / 32)), dim3(256), 0,
+                     st, S.xd_cm, S.n, S.p, S.xd_t);
+  SGD_HIP_TRY(hipGetLastError());
+  unsigned long long* mb = nullptr;
+  if ((rc = dmalloc(&mb, 1))) return rc;
+  SGD_HIP_TRY(hipMemsetAsync(mb, 0, sizeof(unsigned long long), st));
+  int64_t grid = (S.n * 64 + kTB - 1) / kTB;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(dense_row_norm_kernel, dim3((unsigned)grid), dim3(kTB), 0, st, S.xd_t, S.n, S.p, mb);
+  SGD_HIP_TRY(hipGetLastError());
+  unsigned long long bits = 0;
+  SGD_HIP_TRY(hipMemcpyAsync(&bits, mb, sizeof(bits), hipMemcpyDeviceToHost, st));
+  SGD_HIP_TRY(hipStreamSynchronize(st));
+  memcpy(max_sqnorm, &bits, sizeof(double));
+  (void)hipFree(mb);
+  (void)hipFree(S.xd_cm);
+  S.xd_cm = nullptr;
   return SGDNET_OK;
 }
 

@@ -22,8 +22,24 @@ struct DeviceSetup {
   char* ovf = nullptr;
   int rec_stride = 0, rec_cap = 0, rec_val_off = 0;
   float avg_nnz = 0.f;
+  // dense x (large problems only, dense_setup_*): column-major copy (freed after the transpose) and
+  // the sample-major p x n matrix the solver adopts
+  double* xd_cm = nullptr;
+  double* xd_t = nullptr;
   void release();
 };
+
+// Dense x on the device: column statistics + standardisation (utils.h:99-108), lambda_max products,
+// the transpose (utils.h:283-288) and ColNormsMax without the host passes over n*p doubles.
+// Used above kDenseDeviceSetupElems elements; smaller matrices (the reference's own data sets) keep
+// the host loops, whose sums run in the reference's order.
+constexpr int64_t kDenseDeviceSetupElems = 4000000;
+int dense_setup_begin(DeviceSetup& S, const double* x_host, int64_t n, int64_t p, int standardize, hipStream_t st,
+                      std::vector<double>& x_center, std::vector<double>& x_scale, double* max_mean_sq);
+int dense_xt_times(const DeviceSetup& S, const double* ymap_host, int cols, double* xty_host, hipStream_t st);
+int dense_setup_finish(DeviceSetup& S, hipStream_t st, double* max_sqnorm);
+// rows r * stride (r < m) of the standardised matrix, m x p column-major, for the host power iteration
+int dense_sample_rows(const DeviceSetup& S, int64_t stride, int64_t m, double* out_host, hipStream_t st);
 
 int device_setup_begin(DeviceSetup& S, const sgdnet_csc* x, int standardize, hipStream_t st,
                        std::vector<double>& x_center, std::vector<double>& x_scale, double* max_mean_sq);

@@ -693,7 +693,7 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
 
   sgdnet_solver* s = new sgdnet_solver();
   s->device = pb->device;
-  s->sparse = adopt != nullptr || pb->x_dense == nullptr;
+  s->sparse = adopt ? adopt->xd_t == nullptr : pb->x_dense == nullptr;
   hipError_t e = hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking);
   if (e != hipSuccess) {
     set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -729,7 +729,13 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
       return rc;                   \
     }                              \
   } while (0)
-  if (adopt) {
+  if (adopt && adopt->xd_t) {
+    // dense x standardised and transposed on the device (dense_setup_*): take ownership
+    s->nnz = (int64_t)n * (int64_t)p;
+    d.xd = adopt->xd_t;
+    s->owned.push_back(adopt->xd_t);
+    adopt->xd_t = nullptr;
+  } else if (adopt) {
     // buffers produced on the device by setup_device.hip: take ownership
     s->nnz = adopt->nnz;
     d.avg_nnz = adopt->avg_nnz;

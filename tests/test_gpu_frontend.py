@@ -239,3 +239,24 @@ def test_increasing_lambda_sequence_is_caught_by_the_null_model_net(sa, monkeypa
                     batch=500, maxit=300, seed=3)
     assert np.all(fit.dev_ratio > 0.0) and np.all(np.isfinite(fit.beta))
     assert np.allclose(fit.dev_ratio, ref.dev_ratio, atol=1e-4)
+
+
+@pytest.mark.parametrize("family,mode", [("binomial", "exact"), ("gaussian", "batched")])
+def test_large_dense_x_is_prepared_on_the_device(sa, monkeypatch, family, mode):
+    """Dense matrices of >= 4M elements are standardised, multiplied for lambda_max, transposed and normed
+    on the device (dense_setup_*); the host loops (SGDNET_HOST_SETUP=1, the path small
+    matrices keep because their sums run in the reference's order) must give the same fit."""
+    rng = np.random.default_rng(5)
+    n, p = 4100, 1000
+    x = rng.standard_normal((n, p)) * np.linspace(0.5, 3.0, p) + np.linspace(-1, 1, p)
+    b = rng.standard_normal(p) * (rng.random(p) < 0.05)
+    lp = (x - x.mean(0)) / x.std(0) @ b
+    y = (rng.random(n) < 1 / (1 + np.exp(-lp))).astype(int) if family == "binomial" else lp + rng.standard_normal(n)
+    kw = dict(family=family, alpha=0.5, nlambda=4, lambda_min_ratio=0.2, thresh=1e-7, maxit=400, seed=2, mode=mode)
+    dev = sa.sgdnet(x, y, **kw)
+    monkeypatch.setenv("SGDNET_HOST_SETUP", "1")
+    host = sa.sgdnet(x, y, **kw)
+    assert np.allclose(dev.lambda_, host.lambda_, rtol=1e-11) and dev.nulldev == pytest.approx(host.nulldev, rel=1e-12)
+    assert np.all(dev.return_codes == 0)
+    assert np.abs(dev.beta - host.beta).max() <= 1e-6 * np.abs(host.beta).max()
+    assert np.allclose(dev.dev_ratio, host.dev_ratio, atol=1e-7)
