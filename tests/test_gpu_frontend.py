@@ -253,6 +253,8 @@ def test_large_dense_x_is_prepared_on_the_device(sa, monkeypatch, family, mode):
     lp = (x - x.mean(0)) / x.std(0) @ b
     y = (rng.random(n) < 1 / (1 + np.exp(-lp))).astype(int) if family == "binomial" else lp + rng.standard_normal(n)
     kw = dict(family=family, alpha=0.5, nlambda=4, lambda_min_ratio=0.2, thresh=1e-7, maxit=400, seed=2, mode=mode)
+    if mode == "exact":                       # one wavefront, p = 1000: keep the test short
+        kw.update(nlambda=2, lambda_min_ratio=0.5, thresh=1e-4, maxit=60)
     dev = sa.sgdnet(x, y, **kw)
     monkeypatch.setenv("SGDNET_HOST_SETUP", "1")
     host = sa.sgdnet(x, y, **kw)
