@@ -12,7 +12,7 @@ pids=()
 for v in "$@"; do
   name=${v%%:*}; fl=${v#*:}
   ( /opt/rocm/bin/hipcc $FLAGS $fl -x hip -c sgdnet_amd/csrc/$src -o build/variants/$name.o &&
-    objs=""; for f in saga_exact saga_batched r_rng_device setup_device score solver driver r_rng; do
+    objs=""; for f in saga_exact saga_batched r_rng_device setup_device score solver driver r_rng mt_jump; do
       if [ "$f.hip" == "$src" ] || [ "$f.cpp" == "$src" ]; then objs="$objs build/variants/$name.o"; else objs="$objs build/$f.o"; fi; done
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o build/variants/libsgdnet_hip_$name.so $objs ) &
   pids+=($!)

@@ -126,7 +126,10 @@ __global__ __launch_bounds__(kJumpBlock) void r_mt_jump_kernel(const uint32_t* s
   const int t = threadIdx.x;
   st_in += (int64_t)blockIdx.x * (kN + 1);
   st_out += (int64_t)blockIdx.x * (kN + 1);
-  if (t < kN) xs[t] = st_in[1 + t];
+  if (t < kN) {
+    xs[t] = st_in[1 + t];
+    xs[kJumpSeq + kN + t] = poly[t];
+  }
   __syncthreads();
   constexpr int kD = kN - kM;
   for (int base = 0; base + kN < kJumpSeq; base += kN) {
@@ -148,9 +151,15 @@ __global__ __launch_bounds__(kJumpBlock) void r_mt_jump_kernel(const uint32_t* s
     __syncthreads();
   }
   if (t < kN) {
+    // The polynomial sits in LDS behind the sequence (every thread reads the same word: a broadcast);
+    // a term is one LDS read + one XOR behind a scalar bit scan.  ~0.4 ms per launch: the ~10 000 terms
+    // per thread cost ~10 issued instructions each (requesting eight reads at a time measured slower).
     uint32_t acc = 0u;
+    const uint32_t* pl = xs + kJumpSeq + kN;
+    uint32_t bits_next = __builtin_amdgcn_readfirstlane(pl[0]);
     for (int wi = 0; wi < kN; ++wi) {
-      uint32_t bits = poly[wi];              // the same word for every thread: a scalar load
+      uint32_t bits = bits_next;
+      bits_next = __builtin_amdgcn_readfirstlane(pl[wi + 1 < kN ? wi + 1 : wi]);
       const uint32_t* xb = xs + 32 * wi + t;
       while (bits) {
         const int b = __ffs((int)bits) - 1;
@@ -168,7 +177,7 @@ int launch_rng_jump(const uint32_t* state_in, uint32_t* state_out, const uint32_
   static bool attr_done_dev[64] = {};
   int cur = 0;
   (void)hipGetDevice(&cur);
-  const size_t lds = sizeof(uint32_t) * (size_t)(kJumpSeq + kN);
+  const size_t lds = sizeof(uint32_t) * (size_t)(kJumpSeq + 2 * kN);
   if (!attr_done_dev[cur & 63]) {
     SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(r_mt_jump_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
