@@ -14,14 +14,14 @@ if [ ! -f build/.flags ] || [ "$(cat build/.flags)" != "$FLAGS" ]; then rm -f bu
 pids=()
 for f in saga_exact.hip saga_batched.hip r_rng_device.hip setup_device.hip score.hip solver.cpp driver.cpp r_rng.cpp mt_jump.cpp; do
   o=build/${f%.*}.o
-  if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ "$SRC/common.hpp" -nt "$o" ] || [ "$SRC/device_math.hpp" -nt "$o" ] || [ "$SRC/setup_device.hpp" -nt "$o" ] || [ include/sgdnet_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$SRC/$f" -nt "$o" ] || [ "$SRC/common.hpp" -nt "$o" ] || [ "$SRC/device_math.hpp" -nt "$o" ] || [ "$SRC/setup_device.hpp" -nt "$o" ] || [ include/sgdnet_hip.h -nt "$o" ] || [ include/sgdnet_detmath.h -nt "$o" ]; then
     $HIPCC $FLAGS -x hip -c "$SRC/$f" -o "$o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libsgdnet_hip.so" build/saga_exact.o build/saga_batched.o build/r_rng_device.o build/setup_device.o build/score.o build/solver.o build/driver.o build/r_rng.o build/mt_jump.o
-make -s -C oracle liboracle.so
+make -s -C oracle liboracle.so liboracle_det.so
 # the .Call shim (shim/sgdnet_shim.c) compiled as it will be inside the R package, against the
 # mock of the R C API under tests/rmock (no R in this image): test infrastructure
 gcc -O2 -std=gnu11 -Wall -Wextra -Wno-cast-function-type -fPIC -shared -Itests/rmock/include -Iinclude -o tests/rmock/libsgdnet_shim_mock.so \

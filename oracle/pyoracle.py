@@ -12,6 +12,16 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIBS = {}
+_DET = False
+
+
+def use_det_math(flag):
+    """Switch to liboracle_det.so: the same restatement with include/sgdnet_detmath.h's exp/log in the family
+    gradients (what the HIP exact kernels compute with), instead of libm."""
+    global _DET, _LIB
+    _DET = bool(flag)
+    _LIB = None
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
 PENALTIES = {"ridge": 0, "elasticnet": 1, "grouplasso": 2}
@@ -21,10 +31,11 @@ def build(force=False):
     if os.environ.get("SGDNET_ORACLE_ASAN") == "1":     # sanitizer run of the CPU test-suite
         subprocess.check_call(["make", "-C", _HERE, "liboracle_asan.so"], stdout=subprocess.DEVNULL)
         return os.path.join(_HERE, "liboracle_asan.so")
-    so = os.path.join(_HERE, "liboracle.so")
+    name = "liboracle_det.so" if _DET else "liboracle.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "sgdnet_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     return so
 
 
@@ -67,7 +78,10 @@ class _Result(C.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        path = build()
+        if path not in _LIBS:
+            _LIBS[path] = C.CDLL(path)
+        _LIB = _LIBS[path]
         _LIB.orc_unif_rand.restype = C.c_double
         _LIB.orc_draw.restype = C.c_uint32
         for f in ("orc_saga_sparse", "orc_saga_dense", "orc_saga_sparse_batched"):

@@ -141,12 +141,26 @@ static inline void penalty_apply(int penalty, int K, double* w, int64_t j,
 /* ------------------------------------------------------------------------ */
 /* src/math.h:25-33 LogSumExp                                                */
 /* ------------------------------------------------------------------------ */
+/* exp/log of the family gradients (src/families.h:161-168,244-260 via src/math.h:25-33): libm, like the
+ * reference -- or, in the liboracle_det.so build (-DORC_DET_MATH), the plain-IEEE functions of
+ * include/sgdnet_detmath.h that the HIP exact kernels use too, so that GPU and CPU agree bit for bit. */
+#ifdef ORC_DET_MATH
+#include "sgdnet_detmath.h"
+#define ORC_EXP sgd_exp
+#define ORC_LOG sgd_log
+double orc_det_exp(double x) { return sgd_exp(x); }   /* test hooks (tests/test_detmath.py) */
+double orc_det_log(double x) { return sgd_log(x); }
+#else
+#define ORC_EXP exp
+#define ORC_LOG log
+#endif
+
 static double log_sum_exp(const double* x, int K) {
   double x_max = x[0], exp_sum = 0.0;
   int k;
   for (k = 1; k < K; ++k) if (x[k] > x_max) x_max = x[k];
-  for (k = 0; k < K; ++k) exp_sum += exp(x[k] - x_max);
-  return log(exp_sum) + x_max;
+  for (k = 0; k < K; ++k) exp_sum += ORC_EXP(x[k] - x_max);
+  return ORC_LOG(exp_sum) + x_max;
 }
 
 /* ------------------------------------------------------------------------ */
@@ -161,13 +175,13 @@ static void family_gradient(int family, int K, const double* lp, const double* y
     g[0] = lp[0] - y[i];
     break;
   case ORC_BINOMIAL:
-    g[0] = 1.0 - y[i] - 1.0 / (1.0 + exp(lp[0]));
+    g[0] = 1.0 - y[i] - 1.0 / (1.0 + ORC_EXP(lp[0]));
     break;
   case ORC_MULTINOMIAL: {
     double lse = log_sum_exp(lp, K);
     unsigned c = (unsigned)(y[i] + 0.5);
     for (k = 0; k < K; ++k) {
-      g[k] = exp(lp[k] - lse);
+      g[k] = ORC_EXP(lp[k] - lse);
       if ((unsigned)k == c) g[k] -= 1.0;
     }
     break;

@@ -10,6 +10,18 @@
 
 #include "common.hpp"
 
+// exp/log of the family gradients: the exact kernels (saga_exact.hip defines SGDNET_DET_MATH) use the
+// plain-IEEE functions of include/sgdnet_detmath.h, bit-identical to the CPU restatement built with
+// -DORC_DET_MATH; the throughput kernels keep the device math library.
+#ifdef SGDNET_DET_MATH
+#include "sgdnet_detmath.h"
+#define SGD_EXP sgd_exp
+#define SGD_LOG sgd_log
+#else
+#define SGD_EXP exp
+#define SGD_LOG log
+#endif
+
 namespace sgdnet {
 
 __device__ __forceinline__ double soft_threshold(double x, double s) {
@@ -54,8 +66,8 @@ __device__ __forceinline__ double log_sum_exp(const double* lp, int K) {
   double mx = lp[0];
   for (int k = 1; k < K; ++k) mx = lp[k] > mx ? lp[k] : mx;
   double s = 0.0;
-  for (int k = 0; k < K; ++k) s += exp(lp[k] - mx);
-  return log(s) + mx;
+  for (int k = 0; k < K; ++k) s += SGD_EXP(lp[k] - mx);
+  return SGD_LOG(s) + mx;
 }
 
 // g_k for class k given all K linear predictors; y points at column s of y (Ky rows).
@@ -65,11 +77,11 @@ __device__ __forceinline__ double family_gradient_k(int family, int K, int k, co
     case SGDNET_GAUSSIAN:
       return lp[0] - ys[0];
     case SGDNET_BINOMIAL:
-      return 1.0 - ys[0] - 1.0 / (1.0 + exp(lp[0]));
+      return 1.0 - ys[0] - 1.0 / (1.0 + SGD_EXP(lp[0]));
     case SGDNET_MULTINOMIAL: {
       const double lse = log_sum_exp(lp, K);
       const unsigned c = (unsigned)(ys[0] + 0.5);
-      double g = exp(lp[k] - lse);
+      double g = SGD_EXP(lp[k] - lse);
       if ((unsigned)k == c) g -= 1.0;
       return g;
     }

@@ -13,6 +13,7 @@
 // Lane roles: lanes stride the nonzeros of the drawn sample for the per-feature
 // steps; lane k owns class k for the linear predictor / gradient / intercept.
 // w, g_sum and lag are staged in LDS when they fit (160 KiB per CU).
+#define SGDNET_DET_MATH 1   // bit-identical family gradients (include/sgdnet_detmath.h)
 #include "device_math.hpp"
 
 namespace sgdnet {
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
         if (kFamily == SGDNET_GAUSSIAN) {
           g = lp - y_cur;
         } else if (kFamily == SGDNET_BINOMIAL) {
-          g = 1.0 - y_cur - 1.0 / (1.0 + exp(lp));
+          g = 1.0 - y_cur - 1.0 / (1.0 + SGD_EXP(lp));
         } else if (kFamily == SGDNET_MGAUSSIAN) {
           g = lp - (cls ? y_cur : 0.0);
         } else {

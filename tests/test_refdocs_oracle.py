@@ -20,9 +20,15 @@ def d():
     return F.load()
 
 
-@pytest.fixture(scope="module")
-def be():
-    return F.OracleBackend()
+@pytest.fixture(scope="module", params=["libm", "detmath"])
+def be(request):
+    """libm: the restatement as the reference runs it (glibc's exp/log).  detmath: the same with the
+    plain-IEEE exp/log of include/sgdnet_detmath.h in the family gradients -- the build the HIP exact
+    kernels are bit-identical to -- which reproduces the printed numbers just the same."""
+    from oracle import pyoracle as po
+    po.use_det_math(request.param == "detmath")
+    yield F.OracleBackend()
+    po.use_det_math(False)
 
 
 def test_gaussian_lasso_path_coefficients_as_printed(be, d):
