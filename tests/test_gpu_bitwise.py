@@ -53,7 +53,7 @@ def test_general_dense_kernel_and_convergence_epochs(sa, det):
     from test_gpu_parity import make_problem
     x, y = make_problem("multinomial", 4, 700, 40, None, seed=5, dense=True)          # K*p = 160: the general dense kernel
     ref, got = run(sa, det, x, y, family="multinomial", K=4, penalty="elasticnet", gamma=0.02, alpha=1e-3, beta=1e-3,
-                   epochs=60, tol=1e-4)
-    assert ref[0] == got[0] and ref[0] < 60                                            # same stopping epoch
+                   epochs=300, tol=1e-3)
+    assert ref[0] == got[0] and ref[0] < 300                                           # same stopping epoch
     for name in STATE:
         assert np.array_equal(got[2][name], ref[2][name]), name

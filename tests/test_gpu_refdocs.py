@@ -34,14 +34,12 @@ def test_binomial_cv_predictions_and_the_multinomial_fit_that_follows(be, d):
     assert np.abs(r["link"] - d["cv_heart_link"]).max() <= 5.1e-11
     want = d["deviance_wine"]
     assert abs(r["nulldev"] - want[0]) <= 5.1e-7
-    # The wine fit starts at lambda_max, where a few coefficients flicker around the soft
-    # threshold at the 1e-17 level and the relative stopping rule (src/utils.h:240-262) is decided
-    # by the last bit of exp/log: the device libm and glibc differ there by an ulp, the fit runs a
-    # different number of epochs at s0 and the sample order of the rest of the path shifts.  The
-    # path is then the reference's at the reference's own tolerance class (thresh = 1e-3), not at
-    # print precision (the CPU oracle, on glibc like the reference, does match all 100 to 6 decimals).
-    rel = np.abs(r["deviance"] / want - 1.0)
-    assert np.median(rel) <= 5e-3 and rel.max() <= 5e-2
+    # (Round 2, first version: the wine path was only reproduced to 1e-3 here -- it starts at lambda_max, where a
+    # few coefficients flicker around the soft threshold and the stopping epoch hangs on the last bit of exp/log,
+    # which the device math library and glibc round differently now and then.  With the plain-IEEE exp/log of
+    # include/sgdnet_detmath.h in the exact kernels the epochs are those of the CPU restatement, and the path is
+    # the printed one to the printed precision.)
+    assert np.abs(r["deviance"] - want).max() <= 5.1e-7
 
 
 def test_predict_print_chain(be, d):
