@@ -26,6 +26,10 @@
  * Beyond that it is checked against the reference's own known-answer tests
  * (closed-form ridge, OLS, logistic MLE, lambda_max formulas, null deviances,
  * sparse==dense, ...; tests/test_oracle_properties.py).
+ * A second build, liboracle_det.so (-DORC_DET_MATH), replaces libm's exp/log in the family
+ * gradients by the plain-IEEE functions of include/sgdnet_detmath.h, which the HIP exact
+ * kernels use as well: that build and those kernels agree bit for bit
+ * (tests/test_gpu_bitwise.py), and it reproduces the printed numbers like the libm build.
  * Not pinned: bit-level equality of intermediate state (Eigen's packetised
  * reductions, the libm of the machine that built the docs).
  */
