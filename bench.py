@@ -489,10 +489,24 @@ def main():
             "algorithmic_gbps": cpu_bytes / tc / 1e9,
             "host_cpus": os.cpu_count(),
         }
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if pipe:
         S.rng_close()
+        # the same kernel WITHOUT the sample-order generators beside it (all 256 CUs, draws already resident):
+        # `roofline.frac` above is what the timed epochs experience, this is the kernel's own figure
+        try:
+            S.sync()
+            alone = S.profile_epoch(batch=min(batch, n_local), stream_offset=0, draws_per_epoch=n_local)
+            bytes_alone = D.algorithmic_bytes(S.row_nnz, S.get_stream(0, n_local), K)
+            out["roofline"]["kernel_alone"] = {
+                "avg_launch_us": 1e3 * alone["gather_ms"] / max(1, alone["gather_launches"]),
+                "launches": alone["gather_launches"],
+                "achieved": bytes_alone / (alone["gather_ms"] * 1e-3) / 1e9,
+                "frac": bytes_alone / (alone["gather_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "note": "one more epoch after the timed region with the generators idle and the full grid"}
+        except Exception as e:                      # noqa: BLE001 -- an extra, never at the price of the line
+            out["roofline"]["kernel_alone"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     S.close()
     if world > 1 or force_merge:
         dist.destroy_process_group()
