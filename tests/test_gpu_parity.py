@@ -829,7 +829,8 @@ def test_more_than_sixteen_classes(sa, oracle):
 # ---------------------------------------------------------------------------------------------
 # Periodic averaging of locally normalised shard runs (sgdnet_amd/parallel.py: ShardedSaga)
 # ---------------------------------------------------------------------------------------------
-def _gpu_avg_worker(rank, world, port, outdir, n, p, batch, max_epochs, tol):
+def _gpu_avg_worker(rank, world, port, outdir, n, p, batch, max_epochs, tol, family="binomial", K=1, density=0.05,
+                    reg=1e-5):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import torch                      # before sgdnet_amd: one HIP runtime per process
@@ -839,10 +840,10 @@ def _gpu_avg_worker(rank, world, port, outdir, n, p, batch, max_epochs, tol):
     from sgdnet_amd.parallel import HipShard, ShardedSaga, merge_segments, shard_bounds
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     lo, hi = shard_bounds(n, world, rank)
-    pr = D.make_sparse_glm(n, p, 0.05, family="binomial", seed=31, lo=lo, hi=hi)
+    pr = D.make_sparse_glm(n, p, density, family=family, n_classes=K, seed=31, lo=lo, hi=hi)
     nl = hi - lo
-    S = sa.SagaSolver(D.as_scipy(pr), pr["y"], family="binomial", n_classes=1, n_total=nl)   # local normalisation
-    S.set_penalty("elasticnet", 0.01, 1e-5, 1e-5)
+    S = sa.SagaSolver(D.as_scipy(pr), pr["y"], family=family, n_classes=K, n_total=nl)   # local normalisation
+    S.set_penalty("elasticnet", 0.01, reg, reg)
     shard = HipShard(S, batch=batch, draws_per_epoch=nl, device=torch.device("cuda", 0), weight=nl / n,
                      stage_on_host=True)
     job = ShardedSaga(shard, world, merge_segments(nl, n, batch))
@@ -858,9 +859,32 @@ def _gpu_avg_worker(rank, world, port, outdir, n, p, batch, max_epochs, tol):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         done = bool(flag[0] > 0.5)
         epochs += 1
-    np.savez(os.path.join(outdir, f"a{rank}.npz"), w=S.get("w"), b=S.get("intercept"), epochs=epochs)
+    np.savez(os.path.join(outdir, f"a{rank}.npz"), w=S.get("w"), b=S.get("intercept"), epochs=epochs,
+             form=S._L.sgdnet_solver_gather_form(S._h, batch))
     S.close()
     dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_avg_mode_two_ranks_on_one_gpu_with_the_binned_multinomial_kernels(sa, oracle, tmp_path):
+    # the config-5 code path under the multi-rank averaging: K = 10, K * p * 8 bytes beyond the LDS table
+    # (binned gather/sweep, padded coefficient copy refreshed after every merge), two processes on cuda:0
+    import socket
+    import torch.multiprocessing as mp
+    from sgdnet_amd import data as D
+    n, p, K, batch, world, tol = 65536, 2000, 10, 4096, 2, 1e-10      # segments of whole batches
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_gpu_avg_worker, args=(world, port, str(tmp_path), n, p, batch, 600, tol, "multinomial", K, 0.005, 1e-3),
+             nprocs=world, join=True)
+    out = [np.load(tmp_path / f"a{r}.npz") for r in range(world)]
+    assert int(out[0]["form"]) == 2                                  # binned form
+    assert np.array_equal(out[0]["w"], out[1]["w"]) and int(out[0]["epochs"]) < 600
+    pr = D.make_sparse_glm(n, p, 0.005, family="multinomial", n_classes=K, seed=31)
+    st = oracle.new_state(K, p, n)
+    oracle.saga(D.as_scipy(pr), pr["y"], st, family="multinomial", penalty="elasticnet", gamma=0.01,
+                alpha=1e-3, beta=1e-3, max_iter=3000, tol=tol, rng=oracle.Rng(3))
+    assert np.abs(out[0]["w"] - st["w"]).max() < 1e-7 * np.abs(st["w"]).max()
+    assert np.abs(out[0]["b"] - st["intercept"]).max() < 1e-7
 
 
 @pytest.mark.timeout(900)
