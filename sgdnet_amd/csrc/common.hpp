@@ -146,6 +146,9 @@ int launch_dense_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& c
                        hipStream_t st);
 size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state);
 size_t dense_exact_small_lds_bytes(const SagaDev& d, int64_t nit);
+int dense_exact_wide_threads(const SagaDev& d);
+size_t dense_exact_wide_lds_bytes(const SagaDev& d, bool stage_state);
+int launch_dense_exact_wide(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st);
 int launch_dense_exact_small(const SagaDev& d, int penalty, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
                              hipStream_t st);
 size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state);

@@ -601,11 +601,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   int mode = ctl->mode;
   int64_t batch = ctl->batch;
-  // SGDNET_MODE_BATCHED means "batched where it is implemented": more than 16 classes, and dense
-  // x whose K x p accumulator does not fit a workgroup's LDS, run the exact iteration instead (a global options(sgdnet.mode = "batched") in R
-  // must not make dense fits fail)
+  // SGDNET_MODE_BATCHED means "batched where it is implemented": more than 64 classes, and dense
+  // x with more than 16, run the exact iteration instead (a global options(sgdnet.mode = "batched")
+  // in R must not make such fits fail)
   if (mode == SGDNET_MODE_AUTO) mode = SGDNET_MODE_BATCHED;
-  if (mode == SGDNET_MODE_BATCHED && (K > 64 || (!X.sparse && (K > 16 || (int64_t)K * p > 10240)))) mode = SGDNET_MODE_EXACT;
+  if (mode == SGDNET_MODE_BATCHED && (K > 64 || (!X.sparse && K > 16))) mode = SGDNET_MODE_EXACT;
   if (mode == SGDNET_MODE_BATCHED) {
     if (batch <= 0) batch = X.dev ? sgdnet_auto_batch(norm_max, X.dev_max_mean_sq) : auto_batch(X, norm_max);
   } else if (mode != SGDNET_MODE_EXACT) {

@@ -1038,7 +1038,10 @@ constexpr int kDenseBlock = 256;
 
 // kVS (K == 1): virtual shards as in the sparse LDS gather -- workgroup b works for shard
 // b / d.v_bps on that shard's replica of (w, b) and its region of the sample stream.
-template <int KMAX, int kThreads = kDenseBlock, bool kVS = false>
+// kTiled: K x p tables that fit no LDS.  The kernel stops after the gradient: the gradient change of
+// draw i goes to d.gcb[i * K + k] (zero for a repeated sample) and saga_dense_tiled_accumulate_kernel
+// forms D = X_batch^T gc feature tile by feature tile.
+template <int KMAX, int kThreads = kDenseBlock, bool kVS = false, bool kTiled = false>
 __global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaDev d, const LamParams* lamp,
                                                                            int64_t t0_in_epoch, int m,
                                                                            int batch_id_offset,
@@ -1049,8 +1052,10 @@ __global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaD
   const int vsh = kVS ? (int)blockIdx.x / d.v_bps : 0;
   const int vblk = kVS ? (int)blockIdx.x - vsh * d.v_bps : (int)blockIdx.x;
   const double* w_src = kVS ? d.vw + (int64_t)vsh * KP : d.w;
-  for (int64_t i = threadIdx.x; i < KP; i += kThreads) Dl[i] = 0.0;
-  __syncthreads();
+  if (!kTiled) {
+    for (int64_t i = threadIdx.x; i < KP; i += kThreads) Dl[i] = 0.0;
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t t0 = lamp->stream_base + t0_in_epoch + (kVS ? (int64_t)vsh * d.v_dps : 0);
   const int batch_id = lamp->batch_seq + batch_id_offset;
@@ -1145,22 +1150,29 @@ __global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaD
         }
       }
     }
+    if (kTiled) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K && lane == k) d.gcb[(int64_t)i * K + k] = first ? gc[k] : 0.0;
+    }
     if (first) {
-      for (int64_t j0 = lane; j0 < p; j0 += 64 * kRowU) {
-        double xv[kRowU];
+      if (!kTiled) {
+        for (int64_t j0 = lane; j0 < p; j0 += 64 * kRowU) {
+          double xv[kRowU];
 #pragma unroll
-        for (int r = 0; r < kRowU; ++r) {
-          const int64_t j = j0 + 64 * r;
-          xv[r] = j < p ? xs[j] : 0.0;
-        }
+          for (int r = 0; r < kRowU; ++r) {
+            const int64_t j = j0 + 64 * r;
+            xv[r] = j < p ? xs[j] : 0.0;
+          }
 #pragma unroll
-        for (int r = 0; r < kRowU; ++r) {
-          const int64_t j = j0 + 64 * r;
-          if (j < p) {
-            double* dj = Dl + j * K;
+          for (int r = 0; r < kRowU; ++r) {
+            const int64_t j = j0 + 64 * r;
+            if (j < p) {
+              double* dj = Dl + j * K;
 #pragma unroll
-            for (int k = 0; k < KMAX; ++k)
-              if (k < K && gc[k] != 0.0) scatter_add<true>(dj + k, xv[r] * gc[k]);
+              for (int k = 0; k < KMAX; ++k)
+                if (k < K && gc[k] != 0.0) scatter_add<true>(dj + k, xv[r] * gc[k]);
+            }
           }
         }
       }
@@ -1170,9 +1182,11 @@ __global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaD
       }
     }
   }
-  __syncthreads();
-  double* slab = d.slab + (int64_t)blockIdx.x * KP;
-  for (int64_t i = threadIdx.x; i < KP; i += kThreads) slab[i] = Dl[i];
+  if (!kTiled) {
+    __syncthreads();
+    double* slab = d.slab + (int64_t)blockIdx.x * KP;
+    for (int64_t i = threadIdx.x; i < KP; i += kThreads) slab[i] = Dl[i];
+  }
   if (kVS) {                                    // one partial per workgroup, summed per shard by the sweep
     __shared__ double vpart[kThreads / 64];
     if (lane == 0) vpart[wave] = gct[0];
@@ -1184,6 +1198,80 @@ __global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaD
     }
   } else if (d.fit_intercept) {
     store_d0_partial<KMAX, kThreads>(d, K, batch_id, gct);
+  }
+}
+
+// --------------------------------------------------------------------------
+// Dense x, K x p beyond the LDS table: D = X_batch^T gc by feature tiles.  A workgroup owns 64
+// consecutive features (lane <-> feature: every row segment is one 512-B read) and a chunk of the
+// batch's draws (blockIdx.y); its four wavefronts take every fourth draw of the chunk, kTileU rows
+// requested before the first is used, and meet in LDS in a fixed order.  One atomic add per
+// (feature, class, chunk) into d.D -- chunks x K x p atomics per batch instead of m x K x p.
+// Sample ids and gradient changes are wave-uniform (scalar loads); rows whose change is zero
+// (repeated samples) are not read.
+// --------------------------------------------------------------------------
+constexpr int kTileF = 64;
+constexpr int kTileU = 8;
+
+template <int KMAX>
+__global__ __launch_bounds__(kDenseBlock) void saga_dense_tiled_accumulate_kernel(SagaDev d, const LamParams* lamp,
+                                                                                  int64_t t0_in_epoch, int m,
+                                                                                  int draws_per_chunk) {
+  __shared__ double part[kDenseBlock / 64 - 1][KMAX][kTileF];
+  const int K = KMAX == 1 ? 1 : d.K;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  constexpr int kWaves = kDenseBlock / 64;
+  const int64_t j = (int64_t)blockIdx.x * kTileF + lane;
+  const bool live = j < d.p;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int lo = (int)blockIdx.y * draws_per_chunk;
+  const int hi = (lo + draws_per_chunk < m) ? lo + draws_per_chunk : m;
+  double acc[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
+  for (int i0 = lo + wave; i0 < hi; i0 += kWaves * kTileU) {
+    double xv[kTileU];
+    bool on[kTileU];
+#pragma unroll
+    for (int u = 0; u < kTileU; ++u) {
+      const int i = i0 + u * kWaves;
+      on[u] = false;
+      xv[u] = 0.0;
+      if (i < hi) {
+        const double* gci = d.gcb + (int64_t)i * K;
+        bool any = false;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) any = any || (k < K && gci[k] != 0.0);
+        on[u] = any;
+        if (any && live) xv[u] = d.xd[(int64_t)d.stream[t0 + i] * d.p + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kTileU; ++u) {
+      if (on[u]) {
+        const double* gci = d.gcb + (int64_t)(i0 + u * kWaves) * K;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+          if (k < K) acc[k] += xv[u] * gci[k];
+      }
+    }
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) part[wave - 1][k][lane] = acc[k];
+  }
+  __syncthreads();
+  if (wave == 0 && live) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        double tot = acc[k];
+#pragma unroll
+        for (int wv = 0; wv < kWaves - 1; ++wv) tot += part[wv][k][lane];
+        if (tot != 0.0) scatter_add<false>(d.D + j * K + k, tot);
+      }
+    }
   }
 }
 
@@ -2288,6 +2376,9 @@ struct GatherPlan {
   bool binned;  // range-binned form (tables that fit no LDS)
   bool lds;     // per-workgroup LDS copies of D flushed as slabs (sparse LDS form and dense form)
   bool dense;   // dense x: saga_batch_gather_dense_kernel
+  bool tiled;   // dense x, table beyond LDS: gradient changes to d.gcb, D by feature tiles (global sweep)
+  int chunks;   // tiled: draw chunks of the accumulate kernel (blockIdx.y)
+  int draws_per_chunk;
   bool w_lds;   // K == 1: the coefficient snapshot is staged in LDS as well
   int grid;
   int draws_per_block;
@@ -2305,10 +2396,28 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
   }();
   const int target_grid = lds_target_grid(d);
   const bool fits = table <= 80 * 1024;
-  if (d.xd) {   // dense x: wave per draw, slab form only (solver.cpp: check_batched_ok)
+  if (d.xd) {   // dense x: wave per draw; LDS table + slabs, or the tiled form for larger tables
     g.dense = true;
     g.lds = d.slab != nullptr && fits;
     const int waves = kDenseBlock / 64;
+    if (!fits && d.gcb && d.K <= 16) {
+      g.tiled = true;
+      int dpb = (m + 8191) / 8192;               // a row is >= 5 KB here: one or a few draws per wavefront
+      dpb = (dpb + waves - 1) / waves * waves;
+      if (dpb < waves) dpb = waves;
+      g.draws_per_block = dpb;
+      g.grid = (m + dpb - 1) / dpb;
+      if (g.grid < 1) g.grid = 1;
+      const int64_t tiles = (d.p + kTileF - 1) / kTileF;
+      int64_t chunks = (2048 + tiles - 1) / tiles;   // ~2048 workgroups over the chip
+      const int64_t most = (m + 4 * waves - 1) / (4 * waves);
+      if (chunks > most) chunks = most;
+      if (chunks < 1) chunks = 1;
+      if (chunks > 65535) chunks = 65535;
+      g.draws_per_chunk = (int)((m + chunks - 1) / chunks);
+      g.chunks = (int)((m + g.draws_per_chunk - 1) / g.draws_per_chunk);
+      return g;
+    }
     int dpb = (m + target_grid - 1) / target_grid;
     dpb = (dpb + waves - 1) / waves * waves;
     if (dpb < waves) dpb = waves;
@@ -2400,9 +2509,33 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
     set_error("batched mode with more than 16 classes needs the binned form (sparse x, n_classes <= 64; got %d)", d.K);
     return SGDNET_EUNSUPPORTED;
   }
+  if (g.tiled) {
+    if (d.K == 1)
+      hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<1, kDenseBlock, false, true>), dim3(g.grid), dim3(kDenseBlock),
+                            0, st, ev0, nullptr, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    else if (d.K <= 4)
+      hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<4, kDenseBlock, false, true>), dim3(g.grid), dim3(kDenseBlock),
+                            0, st, ev0, nullptr, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    else
+      hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<16, kDenseBlock, false, true>), dim3(g.grid), dim3(kDenseBlock),
+                            0, st, ev0, nullptr, 0, d, lam, t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    SGD_HIP_TRY(hipGetLastError());
+    const dim3 agrid((unsigned)((d.p + kTileF - 1) / kTileF), (unsigned)g.chunks);
+    if (d.K == 1)
+      hipExtLaunchKernelGGL(saga_dense_tiled_accumulate_kernel<1>, agrid, dim3(kDenseBlock), 0, st, nullptr, ev1, 0, d,
+                            lam, t0_in_epoch, m, g.draws_per_chunk);
+    else if (d.K <= 4)
+      hipExtLaunchKernelGGL(saga_dense_tiled_accumulate_kernel<4>, agrid, dim3(kDenseBlock), 0, st, nullptr, ev1, 0, d,
+                            lam, t0_in_epoch, m, g.draws_per_chunk);
+    else
+      hipExtLaunchKernelGGL(saga_dense_tiled_accumulate_kernel<16>, agrid, dim3(kDenseBlock), 0, st, nullptr, ev1, 0, d,
+                            lam, t0_in_epoch, m, g.draws_per_chunk);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
+  }
   if (g.dense) {
     if (!g.lds) {
-      set_error("batched mode on dense x needs n_classes * n_features <= 10240 (LDS copy of the accumulator)");
+      set_error("batched mode on dense x with n_classes * n_features > 10240 needs n_classes <= 16 (tiled form)");
       return SGDNET_EUNSUPPORTED;
     }
     // function attributes are per device: one process may drive several GPUs (cv_sgdnet fan-out)

@@ -498,6 +498,387 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
 }
 
 // --------------------------------------------------------------------------
+// Dense variant for WIDE rows (K * p > 64, K <= 16): the same iteration, one draw at a time in stream
+// order, executed by a whole workgroup.  An iteration is O(K p) work that is parallel over the
+// features; only consecutive ITERATIONS depend on each other (through the linear predictor).  One
+// wavefront walking 10 000 features -- and one lane adding up the dot product in ascending order, as
+// saga_dense_exact_kernel does -- needs 0.8 ms per draw; here
+//   * thread t owns features t, t + T, ...: it alone reads and writes their w and g_sum (LDS when
+//     2 K p doubles fit, else global/L2), so those need no synchronisation at all;
+//   * the linear predictor is the one cross-thread sum: per-thread partial sums, wave_sum, one LDS
+//     slot per wavefront, barrier, and thread k (< K, all in wavefront 0) adds the slots in a fixed
+//     order, evaluates the gradient, owns intercept k and gradient-memory entry k of every sample
+//     (it alone loads and stores them: program order of one thread, no cross-wavefront visibility
+//     question), and publishes the gradient change through LDS; second barrier; every thread
+//     updates its features;
+//   * the barriers wait for LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads() would also
+//     wait for the next draw's row, which is requested one iteration ahead (sample ids two ahead).
+// Difference to the reference order: the dot product is summed as a tree instead of feature by
+// feature (rounding only, ~1e-16 relative; the parity tests hold at 1e-10).
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// a / n for a constant n (an integer count held as a double), rn = RN(1 / n): quotient estimate, exact
+// remainder, one correction (Markstein) -- three instructions instead of the ~30 of an IEEE division
+// sequence.  Correctly rounded whenever the remainder does not underflow; the wide kernel's parity
+// is to rounding, not bit for bit.
+__device__ __forceinline__ double div_by_n(double a, double n, double rn) {
+  const double q0 = a * rn;
+  const double rem = __builtin_fma(-q0, n, a);
+  return __builtin_fma(rem, rn, q0);
+}
+
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Wavefront sum through the DPP lane network (v_mov_b32_dpp: a few cycles per step, against an LDS
+// crossbar round trip per __shfl_xor): quad swaps, half-row and row mirrors, then the row totals
+// travel down the rows (row_bcast15 / row_bcast31, GFX9); lane 63 ends up with the sum of all 64.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_get(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), kCtrl, kRowMask, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), kCtrl, kRowMask, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_get<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xf>(v);   // row_half_mirror
+  v += dpp_get<0x140, 0xf>(v);   // row_mirror: every lane holds its row's sum
+  v += dpp_get<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+  v += dpp_get<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// penalty(w, j, w_scale, 1, g_sum) on one feature column held in registers: the arithmetic of
+// penalty_apply (device_math.hpp) with f = gamma / w_scale and bg = beta * gamma formed once per iteration.
+template <int KMAX>
+__device__ __forceinline__ void penalty_regs(int penalty, int K, double (&wj)[KMAX], const double (&gj)[KMAX], double f,
+                                             double bg, double tau, double w_scale) {
+  if (penalty == SGDNET_RIDGE) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) wj[k] -= f * gj[k];
+  } else if (penalty == SGDNET_ELASTICNET) {
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) wj[k] = soft_threshold(wj[k] - f * gj[k], tau);
+  } else {
+    double nrm = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const double v = wj[k] - f * gj[k];
+        wj[k] = v;
+        nrm += v * v;
+      }
+    }
+    nrm = sqrt(nrm);
+    const double factor = bg / nrm;
+    if (factor < 1.0) {
+      const double m = 1.0 - factor / w_scale;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) wj[k] *= m;
+    } else {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) wj[k] = 0.0;
+    }
+  }
+}
+
+// kU: feature chunks handled per batch (loads of a batch are issued together; the first batch of the NEXT
+// draw's row is requested one iteration ahead).  kStage: w and g_sum live in LDS (typed pointers: ds_read /
+// ds_write instead of flat accesses that wait on both memory counters).
+template <int KMAX, int kT, int kU, bool kStage>
+__global__ __launch_bounds__(kT) void saga_dense_exact_wide_kernel(SagaDev d, const LamParams* lamp, ExactCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) double wide_smem[];
+  constexpr int kNW = kT / kWave;
+  const int T = (int)blockDim.x;                                      // multiple of 64
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = T >> 6;
+  const int K = KMAX == 1 ? 1 : d.K, Ky = KMAX == 1 ? 1 : d.Ky;
+  const int64_t p = d.p, KP = (int64_t)K * p;
+  // LDS carve: [part kNW][KMAX] [sgc KMAX] [red 3][kNW] [w KP][G KP]
+  double* part = wide_smem;
+  double* sgc = part + kNW * KMAX;
+  double* red = sgc + KMAX;
+  double* wl = red + 3 * kNW;
+  double* Gl = wl + KP;
+  // w(j, k) / g_sum(j, k) of an own feature
+  auto wld = [&](int64_t i) -> double { return kStage ? wl[i] : d.w[i]; };
+  auto gld = [&](int64_t i) -> double { return kStage ? Gl[i] : d.G[i]; };
+  auto wst = [&](int64_t i, double v) { if (kStage) wl[i] = v; else d.w[i] = v; };
+  auto gst = [&](int64_t i, double v) { if (kStage) Gl[i] = v; else d.G[i] = v; };
+  if (kStage) {
+    // element (k, j) is staged by the thread that owns feature j
+    for (int64_t j = tid; j < p; j += T)
+      for (int k = 0; k < K; ++k) {
+        wl[j * K + k] = d.w[j * K + k];
+        Gl[j * K + k] = d.G[j * K + k];
+      }
+  }
+  for (int64_t j = tid; j < p; j += T)
+    for (int k = 0; k < K; ++k) d.w_prev[j * K + k] = d.w[j * K + k];   // saga-dense.h:142
+  const bool cls = tid < K;                                            // thread k owns class k
+  const bool ycls = tid < Ky;
+  double sb_own = 0.0, sgb_own = 0.0;
+  if (cls) {
+    sb_own = d.b[tid];
+    sgb_own = d.gb[tid];
+  }
+  __syncthreads();
+
+  const int penalty = lamp->penalty;
+  const int family = d.family;
+  const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
+  const double wscale_update = 1.0 - alpha * gamma;                  // :131
+  const double bg = beta * gamma * 1.0;
+  const double n_d = d.n_total, rn_d = 1.0 / n_d;
+  const unsigned nit = (unsigned)ctl.nit;
+  double wscale = 1.0;                                               // :129
+  unsigned it_outer = 0;
+  int converged = 0;
+  int64_t t = ctl.stream_off;
+  const int64_t t_last = ctl.stream_off + (int64_t)ctl.max_epochs * nit - 1;
+  auto clampt = [&](int64_t x) { return x < t_last ? x : t_last; };
+
+  // sample ids two draws ahead; the next draw's row (first kU chunks), response and gradient memory one ahead
+  uint32_t s1 = d.stream[clampt(t)], s2 = d.stream[clampt(t + 1)];
+  double xn[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const int64_t j = tid + (int64_t)u * T;
+    xn[u] = j < p ? d.xd[(int64_t)s1 * p + j] : 0.0;
+  }
+  double y_n = ycls ? d.y[(int64_t)s1 * Ky + tid] : 0.0;
+  double m_n = cls ? d.M[tid + (int64_t)s1 * K] : 0.0;
+
+#ifdef SGDNET_PHASE_TIMING
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define WIDE_STAMP(i) do { const unsigned long long now_ = clock64(); ph[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define WIDE_STAMP(i) ((void)0)
+#endif
+  do {
+    for (unsigned it = 0; it < nit; ++it, ++t) {
+#ifdef SGDNET_PHASE_TIMING
+      unsigned long long last_ = clock64();
+#endif
+      const uint32_t s = s1;                                         // :152
+      s1 = s2;
+      s2 = d.stream[clampt(t + 2)];
+      // (response and gradient memory are requested before the row: the memory counter retires in order,
+      // so whoever waits for them does not also wait for the row)
+      const double y_c = y_n, m_c = m_n;
+      y_n = ycls ? d.y[(int64_t)s1 * Ky + tid] : 0.0;
+      m_n = cls ? d.M[tid + (int64_t)s1 * K] : 0.0;                  // stale if s1 == s: replaced below
+      double xc[kU];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) xc[u] = xn[u];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const int64_t j = tid + (int64_t)u * T;
+        xn[u] = j < p ? d.xd[(int64_t)s1 * p + j] : 0.0;
+      }
+
+      // ---- x . w: own features, wavefront sum, one slot per wavefront (:154) ----------------
+      double acc[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
+      for (int64_t j0 = tid; j0 < p; j0 += (int64_t)kU * T) {
+        double xv[kU], wv[kU][KMAX];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int64_t j = j0 + (int64_t)u * T;
+          xv[u] = (j0 == tid) ? xc[u] : (j < p ? d.xd[(int64_t)s * p + j] : 0.0);
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) wv[u][k] = (k < K && j < p) ? wld(j * K + k) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k)
+            if (k < K) acc[k] += wv[u][k] * xv[u];
+      }
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (k < K) {
+          const double tot = wave_sum_dpp(acc[k]);
+          if (lane == 0) part[wave * KMAX + k] = tot;
+        }
+      }
+      WIDE_STAMP(0);
+      // the scale bookkeeping does not depend on the gradient: done while the class threads work
+      const double wscale_lp = wscale;
+      if (wscale < kSmall) {                                         // :162-166
+        for (int64_t j = tid; j < p; j += T)
+          for (int k = 0; k < K; ++k) wst(j * K + k, wld(j * K + k) * wscale);
+        wscale = 1.0;
+      }
+      wscale *= wscale_update;                                       // :168
+      const double f = gamma / wscale;
+      const double tau = bg / wscale;
+      WIDE_STAMP(1);
+      lds_barrier();
+      WIDE_STAMP(2);
+
+      if (cls) {
+        // ---- linear predictor and gradient of class tid (:154-156); the other classes' values come by
+        //      readlane (the class threads are lanes 0..K-1 of wavefront 0), in ascending class order
+        double tot = 0.0;
+        for (int wv = 0; wv < nw; ++wv) tot += part[wv * KMAX + tid];
+        const double lp_own = tot * wscale_lp + sb_own;
+        double g;
+        if (family == SGDNET_GAUSSIAN) {
+          g = lp_own - y_c;
+        } else if (family == SGDNET_BINOMIAL) {
+          g = 1.0 - y_c - 1.0 / (1.0 + SGD_EXP(lp_own));
+        } else if (family == SGDNET_MULTINOMIAL) {
+          double mx = readlane_d(lp_own, 0);
+#pragma unroll
+          for (int k = 1; k < KMAX; ++k) {
+            const double v = readlane_d(lp_own, k);
+            if (k < K) mx = v > mx ? v : mx;
+          }
+          const double e = SGD_EXP(lp_own - mx);
+          double se = 0.0;
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            const double v = readlane_d(e, k);
+            if (k < K) se += v;
+          }
+          const double lse = SGD_LOG(se) + mx;
+          const double y0 = readlane_d(y_c, 0);                      // the class label lives in thread 0
+          g = SGD_EXP(lp_own - lse);
+          if ((unsigned)tid == (unsigned)(y0 + 0.5)) g -= 1.0;
+        } else {
+          g = lp_own - y_c;
+        }
+        double gck = g - m_c;                                        // :157
+        d.M[tid + (int64_t)s * K] = g;                               // :158
+        if (s1 == s) m_n = g;
+        sgc[tid] = gck;
+        if (d.fit_intercept) {                                       // :170-173
+          gck = div_by_n(gck, n_d, rn_d);
+          const double gbk = sgb_own + gck;
+          sgb_own = gbk;
+          sb_own -= gamma * (gbk + gck);
+        }
+      }
+      WIDE_STAMP(3);
+      lds_barrier();
+      WIDE_STAMP(4);
+      double gc[KMAX];
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) gc[k] = k < K ? sgc[k] : 0.0;
+
+      for (int64_t j0 = tid; j0 < p; j0 += (int64_t)kU * T) {
+        double xv[kU], wv[kU][KMAX], gv[kU][KMAX];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int64_t j = j0 + (int64_t)u * T;
+          xv[u] = (j0 == tid) ? xc[u] : (j < p ? d.xd[(int64_t)s * p + j] : 0.0);
+#pragma unroll
+          for (int k = 0; k < KMAX; ++k) {
+            const bool on = k < K && j < p;
+            wv[u][k] = on ? wld(j * K + k) : 0.0;
+            gv[u][k] = on ? gld(j * K + k) : 0.0;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+          const int64_t j = j0 + (int64_t)u * T;
+          if (j < p) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+              if (k < K) wv[u][k] -= gc[k] * xv[u] * f;              // :176
+            penalty_regs<KMAX>(penalty, K, wv[u], gv[u], f, bg, tau, wscale);   // :179-180
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+              if (k < K) {
+                gv[u][k] += div_by_n(gc[k] * xv[u], n_d, rn_d);      // :183
+                wst(j * K + k, wv[u][k]);
+                gst(j * K + k, gv[u][k]);
+              }
+            }
+          }
+        }
+      }
+      WIDE_STAMP(5);
+    }
+
+    // ---- end of the epoch: fold the scale (:188-189), ConvergenceCheck (:208) ----------------------
+    double max_change = 0.0, max_size = 0.0;
+    bool finite = true;
+    for (int64_t j = tid; j < p; j += T) {
+      for (int k = 0; k < K; ++k) {
+        const int64_t i = j * K + k;
+        const double v = wld(i) * wscale;
+        wst(i, v);
+        finite = finite && (fabs(v) <= 1.79769313486231570815e+308);
+        max_change = fmax(max_change, fabs(v - d.w_prev[i]));
+        max_size = fmax(max_size, fabs(v));
+        d.w_prev[i] = v;
+      }
+    }
+    wscale = 1.0;
+    max_change = wave_max(max_change);
+    max_size = wave_max(max_size);
+    const bool wave_bad = __ballot(!finite) != 0ull;
+    if (lane == 0) {
+      red[wave] = max_change;
+      red[kNW + wave] = max_size;
+      red[2 * kNW + wave] = wave_bad ? 1.0 : 0.0;
+    }
+    lds_barrier();
+    double mc = 0.0, ms = 0.0, bad = 0.0;
+    for (int wv = 0; wv < nw; ++wv) {
+      mc = fmax(mc, red[wv]);
+      ms = fmax(ms, red[kNW + wv]);
+      bad += red[2 * kNW + wv];
+    }
+    const bool all_zero = (ms == 0.0) && (mc == 0.0);
+    const bool no_change = (ms != 0.0) && (mc / ms <= ctl.tol);
+    converged = (bad == 0.0 && (all_zero || no_change)) ? 1 : 0;
+    ++it_outer;
+    lds_barrier();                                                   // red is rewritten at the end of the next epoch
+  } while (!converged && it_outer < ctl.max_epochs);
+
+  if (kStage) {
+    for (int64_t j = tid; j < p; j += T)
+      for (int k = 0; k < K; ++k) {
+        d.w[j * K + k] = wl[j * K + k];
+        d.G[j * K + k] = Gl[j * K + k];
+      }
+  }
+  if (cls) {
+    d.b[tid] = sb_own;
+    d.gb[tid] = sgb_own;
+  }
+  if (tid == 0) {
+    ctl.out[0] = (int)it_outer;
+    ctl.out[1] = converged;
+#ifdef SGDNET_PHASE_TIMING
+    if (d.dbg)
+      for (int i = 0; i < 6; ++i) d.dbg[i] += ph[i];
+#endif
+  }
+#undef WIDE_STAMP
+}
+
+// --------------------------------------------------------------------------
 // Dense variant for SMALL problems (the reference's own data sets: iris, abalone, heart, wine,
 // student -- K*p <= 64 coefficients, a few thousand samples): the same iteration in the same
 // arithmetic order as saga_dense_exact_kernel, restructured around what bounds a one-wavefront
@@ -511,13 +892,6 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
 // One epoch of abalone (4177 x 9, gaussian): 9.1 ms with saga_dense_exact_kernel, ~0.6 ms here.
 // --------------------------------------------------------------------------
 constexpr int kSmallPf = 8;
-
-__device__ __forceinline__ double readlane_d(double v, int src) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
 
 // kFamily / kPenalty: compile-time copies of d.family / the lambda's penalty, kK1: one class.  A single
 // wavefront is bound by the number of instructions it has to issue per iteration (the generic body
@@ -780,6 +1154,52 @@ int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& 
   hipLaunchKernelGGL(saga_sparse_exact_kernel, dim3(1), dim3(kWave), lds_bytes, st, d, lam, ctl);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
+}
+
+// Workgroup size and LDS of the wide dense kernel; 0 threads: not eligible (more than 16 classes).
+// One class and 2..4 classes: 512 threads (256 VGPRs each); 5..16 classes: 256 threads (K-vectors of
+// w, g_sum and the gradient change in registers).
+static int wide_kmax(const SagaDev& d) { return d.K == 1 ? 1 : (d.K <= 4 ? 4 : 16); }
+static int wide_cap(const SagaDev& d) { return d.K <= 4 ? 512 : 256; }
+
+int dense_exact_wide_threads(const SagaDev& d) {
+  if (!d.xd || d.K > 16) return 0;
+  int64_t t = (d.p + kWave - 1) / kWave * kWave;
+  if (t > wide_cap(d)) t = wide_cap(d);
+  return (int)t;
+}
+
+size_t dense_exact_wide_lds_bytes(const SagaDev& d, bool stage_state) {
+  const int kmax = wide_kmax(d), nwmax = wide_cap(d) / kWave;
+  size_t b = sizeof(double) * (size_t)(nwmax * kmax + kmax + 3 * nwmax);
+  if (stage_state) b += sizeof(double) * 2 * (size_t)d.K * (size_t)d.p;
+  return (b + 15) & ~size_t(15);
+}
+
+template <int KMAX, int kT, int kU, bool kStage>
+static int launch_wide_t(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, int T,
+                         hipStream_t st) {
+  SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_dense_exact_wide_kernel<KMAX, kT, kU, kStage>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  hipLaunchKernelGGL((saga_dense_exact_wide_kernel<KMAX, kT, kU, kStage>), dim3(1), dim3(T), lds_bytes, st, d, lam, ctl);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_dense_exact_wide(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                            hipStream_t st) {
+  const int T = dense_exact_wide_threads(d);
+  if (T <= 0) {
+    set_error("wide dense exact kernel: more than 16 classes");
+    return SGDNET_EUNSUPPORTED;
+  }
+  const bool stage = ctl.use_lds != 0;
+  if (d.K == 1) return stage ? launch_wide_t<1, 512, 8, true>(d, lam, ctl, lds_bytes, T, st)
+                             : launch_wide_t<1, 512, 8, false>(d, lam, ctl, lds_bytes, T, st);
+  if (d.K <= 4) return stage ? launch_wide_t<4, 512, 2, true>(d, lam, ctl, lds_bytes, T, st)
+                             : launch_wide_t<4, 512, 2, false>(d, lam, ctl, lds_bytes, T, st);
+  return stage ? launch_wide_t<16, 256, 1, true>(d, lam, ctl, lds_bytes, T, st)
+               : launch_wide_t<16, 256, 1, false>(d, lam, ctl, lds_bytes, T, st);
 }
 
 int launch_dense_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,

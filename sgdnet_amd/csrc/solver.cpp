@@ -278,6 +278,24 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
   return SGDNET_OK;
 }
 
+// Dense x whose K x p accumulator fits no LDS (saga_batched.hip "tiled"): the gather leaves the
+// batch's gradient changes in d.gcb and D is formed feature tile by feature tile.
+int ensure_dense_tiled(sgdnet_solver* s, int64_t batch) {
+  SagaDev& d = s->d;
+  if (!d.xd || d.K > 16 || sizeof(double) * (size_t)d.K * (size_t)d.p <= 80 * 1024) return SGDNET_OK;
+  if (batch > s->bin_batch || !s->bin_bufs[1]) {
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    if (s->bin_bufs[1]) (void)hipFree(s->bin_bufs[1]);
+    s->bin_bufs[1] = nullptr;
+    SGD_HIP_TRY(hipMalloc(&s->bin_bufs[1], sizeof(double) * (size_t)batch * (size_t)d.K));
+    s->bin_batch = batch;
+    drop_graph(s);
+  }
+  d.gcb = static_cast<double*>(s->bin_bufs[1]);
+  d.KS = d.K;
+  return SGDNET_OK;
+}
+
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   if (s->d.V > 1 && vs_eligible(s->d, (int)batch)) {
@@ -304,7 +322,8 @@ int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   }
   if (batch > draws) batch = draws;
   {
-    const int rcb = ensure_binned(s, batch);
+    int rcb = ensure_binned(s, batch);
+    if (!rcb) rcb = ensure_dense_tiled(s, batch);
     if (rcb) return rcb;
   }
   // scratch must cover the full batches AND the tail batch, whose launch geometry (and even
@@ -472,10 +491,11 @@ int check_batched_ok(const sgdnet_solver* s) {
     return SGDNET_EUNSUPPORTED;
   }
   if (!s->sparse) {
-    // dense x: one LDS copy of the K x p accumulator per workgroup (saga_batch_gather_dense_kernel)
-    if ((int64_t)s->d.K * s->d.p > 10240) {
-      set_error("batched mode on dense x needs n_classes * n_features <= 10240 (got %lld); use exact mode",
-                (long long)((int64_t)s->d.K * s->d.p));
+    // dense x: one LDS copy of the K x p accumulator per workgroup (saga_batch_gather_dense_kernel), or
+    // the tiled form when that copy fits no LDS (K <= 16)
+    if ((int64_t)s->d.K * s->d.p > 10240 && s->d.K > 16) {
+      set_error("batched mode on dense x with n_classes * n_features > 10240 needs n_classes <= 16 (got %d); use exact mode",
+                s->d.K);
       return SGDNET_EUNSUPPORTED;
     }
     return SGDNET_OK;
@@ -1200,11 +1220,15 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     // small dense problems: the register-resident kernel (saga_exact.hip); SGDNET_EXACT_SMALL=0 keeps the general one
     static const int small_ok = [] { const char* e = getenv("SGDNET_EXACT_SMALL"); return e ? atoi(e) : 1; }();
     const size_t lds_small = (!s->sparse && small_ok) ? dense_exact_small_lds_bytes(s->d, draws_per_epoch) : 0;
-    const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true);
+    // wider dense rows (up to 16 classes): the workgroup-per-iteration kernel; SGDNET_EXACT_WIDE=0 keeps the one-wavefront one
+    static const int wide_ok = [] { const char* e = getenv("SGDNET_EXACT_WIDE"); return e ? atoi(e) : 1; }();
+    const bool wide = !s->sparse && !lds_small && wide_ok && dense_exact_wide_threads(s->d) > 0;
+    const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true)
+                                      : (wide ? dense_exact_wide_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true));
     const bool stage = lds_full <= lds_cap;
     const size_t lds = stage ? lds_full
                              : (s->sparse ? sparse_exact_lds_bytes(s->d, false)
-                                          : dense_exact_lds_bytes(s->d, false));
+                                          : (wide ? dense_exact_wide_lds_bytes(s->d, false) : dense_exact_lds_bytes(s->d, false)));
     if (lds > lds_cap) {
       set_error("exact mode: per-iteration scratch (%zu bytes) exceeds LDS", lds);
       return SGDNET_EUNSUPPORTED;
@@ -1228,6 +1252,7 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       ctl.out = s->out_dev;
       rc = s->sparse ? launch_sparse_exact(s->d, s->lam_dev, ctl, lds, s->st)
                      : (lds_small ? launch_dense_exact_small(s->d, s->lam.penalty, s->lam_dev, ctl, lds_small, s->st)
+                        : wide    ? launch_dense_exact_wide(s->d, s->lam_dev, ctl, lds, s->st)
                                   : launch_dense_exact(s->d, s->lam_dev, ctl, lds, s->st));
       if (rc) return rc;
       int out[2] = {0, 0};
@@ -1239,6 +1264,17 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         if (rc) return rc;
         losses[done] = sum / (double)s->d.n;
       }
+#ifdef SGDNET_PHASE_TIMING
+      if (wide && s->d.dbg && out[0] > 0) {   // development aid: shader-clock cycles of thread 0 per phase of the wide kernel
+        unsigned long long ph[6];
+        SGD_HIP_TRY(hipMemcpy(ph, s->d.dbg, sizeof(ph), hipMemcpyDeviceToHost));
+        (void)hipMemset(s->d.dbg, 0, sizeof(ph));
+        const double its = (double)out[0] * (double)draws_per_epoch;
+        fprintf(stderr, "[sgdnet] wide exact kernel, cycles per iteration (thread 0): loads+dot+sum %.0f, scale %.0f, barrier A %.0f, "
+                        "class %.0f, barrier B %.0f, step %.0f\n",
+                (double)ph[0] / its, (double)ph[1] / its, (double)ph[2] / its, (double)ph[3] / its, (double)ph[4] / its, (double)ph[5] / its);
+      }
+#endif
       done += (unsigned)out[0];
       converged = out[1];
       stream_offset += (int64_t)out[0] * draws_per_epoch;

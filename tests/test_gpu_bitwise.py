@@ -1,7 +1,8 @@
-"""Exact mode, bit for bit.  The HIP exact kernels replay the reference iteration in the reference's
-arithmetic order (-ffp-contract=off); with the plain-IEEE exp/log of include/sgdnet_detmath.h in the family
-gradients on both sides, every state array after several epochs is IDENTICAL to the CPU restatement built
-with -DORC_DET_MATH (oracle/liboracle_det.so) -- not close: equal."""
+"""Exact mode, bit for bit.  The one-wavefront HIP exact kernels (sparse x; dense x with K*p <= 64) replay the
+reference iteration in the reference's arithmetic order (-ffp-contract=off); with the plain-IEEE exp/log of
+include/sgdnet_detmath.h in the family gradients on both sides, every state array after several epochs is
+IDENTICAL to the CPU restatement built with -DORC_DET_MATH (oracle/liboracle_det.so) -- not close: equal.
+The workgroup kernel for wider dense rows sums the dot product as a tree: equal to rounding."""
 import numpy as np
 import pytest
 
@@ -49,11 +50,14 @@ def test_exact_kernels_are_bit_identical_to_the_det_oracle(sa, det, family, K, p
         assert np.array_equal(got[2][name], ref[2][name]), name
 
 
-def test_general_dense_kernel_and_convergence_epochs(sa, det):
-    from test_gpu_parity import make_problem
-    x, y = make_problem("multinomial", 4, 700, 40, None, seed=5, dense=True)          # K*p = 160: the general dense kernel
+def test_wide_dense_kernel_and_convergence_epochs(sa, det):
+    # K*p = 160: beyond the register-resident kernel.  The workgroup kernel (saga_dense_exact_wide_kernel)
+    # adds the dot product up as a tree instead of feature by feature -- the one place where the order of
+    # additions differs from the restatement -- so the states agree to rounding, not bit for bit
+    from test_gpu_parity import make_problem, relerr
+    x, y = make_problem("multinomial", 4, 700, 40, None, seed=5, dense=True)
     ref, got = run(sa, det, x, y, family="multinomial", K=4, penalty="elasticnet", gamma=0.02, alpha=1e-3, beta=1e-3,
                    epochs=300, tol=1e-3)
     assert ref[0] == got[0] and ref[0] < 300                                           # same stopping epoch
     for name in STATE:
-        assert np.array_equal(got[2][name], ref[2][name]), name
+        assert relerr(got[2][name], ref[2][name]) < 1e-10, name

@@ -146,6 +146,55 @@ def test_dense_batched_matches_batched_oracle(sa, oracle, family, K, penalty, p,
     S.close()
 
 
+@pytest.mark.parametrize("family,K,penalty,p,n,batch", [
+    ("gaussian", 1, "elasticnet", 10300, 700, 128), ("binomial", 1, "ridge", 11000, 500, 37),
+    ("multinomial", 3, "elasticnet", 3500, 900, 200), ("mgaussian", 2, "grouplasso", 5200, 800, 800),
+    ("multinomial", 10, "elasticnet", 1100, 1500, 64), ("multinomial", 16, "ridge", 700, 1500, 1000)])
+def test_dense_tiled_form_matches_batched_oracle(sa, oracle, family, K, penalty, p, n, batch):
+    # dense x whose K x p accumulator fits no LDS (n_classes * n_features > 10 240): gradient changes
+    # of the batch to a buffer, D = X_batch^T gc by feature tiles, global sweep -- same batched
+    # iteration as the oracle's, repeats within a batch included (batch close to n)
+    assert K * p > 10240
+    x, y = make_problem(family, K, n, p, None, seed=13, dense=True)
+    stream = oracle.Rng(6).stream(n, n * 2)
+    kw = dict(family=family, penalty=penalty, gamma=0.4 / p, alpha=1e-3, beta=0.0 if penalty == "ridge" else 2e-3)
+    st = oracle.new_state(K, p, n)
+    oracle.saga(sp.csc_matrix(x), y, st, max_iter=2, tol=0.0, stream=stream, batch=batch, **kw)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K)
+    S.set_penalty(penalty, kw["gamma"], kw["alpha"], kw["beta"])
+    S.upload_stream(stream)
+    ep, _ = S.run(mode="batched", batch=batch, max_epochs=2, tol=0.0)
+    assert ep == 2
+    for k in STATE:
+        assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
+    S.close()
+
+
+def test_wide_dense_fit_in_batched_mode_satisfies_the_kkt_conditions(sa):
+    # p > 10 240 through sgdnet(): round 1 fell back to the exact iteration here (0.8 ms per draw at this
+    # width).  The CPU oracle needs minutes for this shape, so the optimum is checked by its optimality
+    # conditions.  Objective in the units of y (the reference fits y / sd(y) with lambda / sd(y),
+    # src/sgdnet.cpp Rescale): RSS / (2n) + lambda ((1 - alpha) / (2 sd(y)) |b|^2 + alpha |b|_1)
+    rng = np.random.default_rng(4)
+    n, p = 1500, 10500
+    X = 0.1 * rng.standard_normal((n, p))
+    bt = np.zeros(p)
+    bt[:20] = 10 * rng.standard_normal(20)
+    y = X @ bt + 0.1 * rng.standard_normal(n) + 0.7
+    lam, a = 0.3, 0.3
+    fit = sa.sgdnet(X, y, seed=3, mode="batched", family="gaussian", alpha=a, lambda_=[lam], standardize=False,
+                    thresh=1e-10, maxit=4000)
+    assert fit.return_codes[0] == 0
+    w, b = fit.beta[:, 0], fit.a0[0]
+    r = X @ w + b - y
+    g = X.T @ r / n + lam * (1 - a) * w / y.std()
+    nz = w != 0
+    assert 3 <= nz.sum() <= 200
+    assert abs(r.mean()) < 1e-6
+    assert np.abs(g[nz] + lam * a * np.sign(w[nz])).max() < 1e-8 * lam
+    assert (np.abs(g[~nz]) <= lam * a * (1 + 1e-8)).all()
+
+
 def test_dense_fit_batched_reaches_the_exact_optimum(sa, oracle):
     rng = np.random.default_rng(3)
     n, p = 4000, 12
@@ -340,9 +389,9 @@ def test_unsupported_and_stream_errors(sa):
         S.run(mode="exact", max_epochs=1)          # 200 draws needed, 100 resident
     assert e.value.code == -6
     S.close()
-    # dense x whose K x p accumulator exceeds a workgroup's LDS copy has no batched path
-    x, y = make_problem("gaussian", 1, 64, 10300, None, seed=1, dense=True)
-    S = sa.SagaSolver(x, y, family="gaussian", n_classes=1)
+    # dense x with more than 16 classes whose K x p accumulator exceeds a workgroup's LDS copy has no batched path
+    x, y = make_problem("mgaussian", 18, 64, 600, None, seed=1, dense=True)
+    S = sa.SagaSolver(x, y, family="mgaussian", n_classes=18)
     S.set_penalty("ridge", 1e-5, 1e-3, 0.0)
     S.upload_stream(np.zeros(64, dtype=np.uint32))
     with pytest.raises(SgdnetError) as e:
