@@ -533,6 +533,14 @@ __device__ __forceinline__ double div_by_n(double a, double n, double rn) {
   return __builtin_fma(rem, rn, q0);
 }
 
+// the same, for the kernels that promise the reference's bits: below 1e-280 the remainder could underflow
+// and the plain division is used (elsewhere the result IS the correctly rounded quotient: rn is the correctly
+// rounded reciprocal of an integer-valued n, q0 is within an ulp, the remainder is exact)
+__device__ __forceinline__ double div_by_n_exact(double a, double n, double rn) {
+  if (fabs(a) < 1e-280) return a / n;
+  return div_by_n(a, n, rn);
+}
+
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
@@ -614,8 +622,13 @@ __global__ __launch_bounds__(kT) void saga_dense_exact_wide_kernel(SagaDev d, co
   double* part = wide_smem;
   double* sgc = part + kNW * KMAX;
   double* red = sgc + KMAX;
+  // staged state is padded to whole chunks of T features (padding stays zero: x is 0 there), so its LDS
+  // accesses need no per-thread guard, only the uniform "chunk exists" test
+  const int64_t C = (p + T - 1) / T;
+  const int64_t KPpad = (int64_t)K * C * T;
   double* wl = red + 3 * kNW;
-  double* Gl = wl + KP;
+  double* Gl = wl + KPpad;
+  (void)KP;
   // w(j, k) / g_sum(j, k) of an own feature
   auto wld = [&](int64_t i) -> double { return kStage ? wl[i] : d.w[i]; };
   auto gld = [&](int64_t i) -> double { return kStage ? Gl[i] : d.G[i]; };
@@ -623,12 +636,17 @@ __global__ __launch_bounds__(kT) void saga_dense_exact_wide_kernel(SagaDev d, co
   auto gst = [&](int64_t i, double v) { if (kStage) Gl[i] = v; else d.G[i] = v; };
   if (kStage) {
     // element (k, j) is staged by the thread that owns feature j
-    for (int64_t j = tid; j < p; j += T)
+    for (int64_t j = tid; j < C * T; j += T)
       for (int k = 0; k < K; ++k) {
-        wl[j * K + k] = d.w[j * K + k];
-        Gl[j * K + k] = d.G[j * K + k];
+        wl[j * K + k] = j < p ? d.w[j * K + k] : 0.0;
+        Gl[j * K + k] = j < p ? d.G[j * K + k] : 0.0;
       }
   }
+  // x(sample, j) without a branch: clamped address, zero beyond the row
+  auto xload = [&](uint32_t smp, int64_t j) -> double {
+    const double v = d.xd[(int64_t)smp * p + (j < p ? j : p - 1)];
+    return j < p ? v : 0.0;
+  };
   for (int64_t j = tid; j < p; j += T)
     for (int k = 0; k < K; ++k) d.w_prev[j * K + k] = d.w[j * K + k];   // saga-dense.h:142
   const bool cls = tid < K;                                            // thread k owns class k
@@ -660,7 +678,7 @@ __global__ __launch_bounds__(kT) void saga_dense_exact_wide_kernel(SagaDev d, co
 #pragma unroll
   for (int u = 0; u < kU; ++u) {
     const int64_t j = tid + (int64_t)u * T;
-    xn[u] = j < p ? d.xd[(int64_t)s1 * p + j] : 0.0;
+    xn[u] = xload(s1, j);
   }
   double y_n = ycls ? d.y[(int64_t)s1 * Ky + tid] : 0.0;
   double m_n = cls ? d.M[tid + (int64_t)s1 * K] : 0.0;
@@ -690,21 +708,27 @@ __global__ __launch_bounds__(kT) void saga_dense_exact_wide_kernel(SagaDev d, co
 #pragma unroll
       for (int u = 0; u < kU; ++u) {
         const int64_t j = tid + (int64_t)u * T;
-        xn[u] = j < p ? d.xd[(int64_t)s1 * p + j] : 0.0;
+        xn[u] = xload(s1, j);
       }
 
       // ---- x . w: own features, wavefront sum, one slot per wavefront (:154) ----------------
       double acc[KMAX];
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) acc[k] = 0.0;
-      for (int64_t j0 = tid; j0 < p; j0 += (int64_t)kU * T) {
+      for (int64_t c0 = 0; c0 < C; c0 += kU) {
         double xv[kU], wv[kU][KMAX];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          const int64_t j = j0 + (int64_t)u * T;
-          xv[u] = (j0 == tid) ? xc[u] : (j < p ? d.xd[(int64_t)s * p + j] : 0.0);
+          const int64_t j = tid + (c0 + u) * T;
+          const bool on = kStage ? (c0 + u < C) : (j < p);           // staged: uniform
+          xv[u] = (c0 == 0) ? xc[u] : xload(s, j);
 #pragma unroll
-          for (int k = 0; k < KMAX; ++k) wv[u][k] = (k < K && j < p) ? wld(j * K + k) : 0.0;
+          for (int k = 0; k < KMAX; ++k) wv[u][k] = 0.0;
+          if (on) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k)
+              if (k < K) wv[u][k] = wld(j * K + k);
+          }
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u)
@@ -784,23 +808,33 @@ __global__ __launch_bounds__(kT) void saga_dense_exact_wide_kernel(SagaDev d, co
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) gc[k] = k < K ? sgc[k] : 0.0;
 
-      for (int64_t j0 = tid; j0 < p; j0 += (int64_t)kU * T) {
+      for (int64_t c0 = 0; c0 < C; c0 += kU) {
         double xv[kU], wv[kU][KMAX], gv[kU][KMAX];
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          const int64_t j = j0 + (int64_t)u * T;
-          xv[u] = (j0 == tid) ? xc[u] : (j < p ? d.xd[(int64_t)s * p + j] : 0.0);
+          const int64_t j = tid + (c0 + u) * T;
+          const bool on = kStage ? (c0 + u < C) : (j < p);
+          xv[u] = (c0 == 0) ? xc[u] : xload(s, j);
 #pragma unroll
           for (int k = 0; k < KMAX; ++k) {
-            const bool on = k < K && j < p;
-            wv[u][k] = on ? wld(j * K + k) : 0.0;
-            gv[u][k] = on ? gld(j * K + k) : 0.0;
+            wv[u][k] = 0.0;
+            gv[u][k] = 0.0;
+          }
+          if (on) {
+#pragma unroll
+            for (int k = 0; k < KMAX; ++k) {
+              if (k < K) {
+                wv[u][k] = wld(j * K + k);
+                gv[u][k] = gld(j * K + k);
+              }
+            }
           }
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
-          const int64_t j = j0 + (int64_t)u * T;
-          if (j < p) {
+          const int64_t j = tid + (c0 + u) * T;
+          const bool on = kStage ? (c0 + u < C) : (j < p);
+          if (on) {
 #pragma unroll
             for (int k = 0; k < KMAX; ++k)
               if (k < K) wv[u][k] -= gc[k] * xv[u] * f;              // :176
@@ -933,7 +967,8 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
   constexpr int penalty = kPenalty;
   const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
   const double wscale_update = 1.0 - alpha * gamma;                    // :131
-  const double n_d = d.n_total;
+  const double n_d = d.n_total, rn_d = 1.0 / n_d;
+  const double bg = beta * gamma * 1.0;                                // penalties.h: beta * gamma * scaling
   double wscale = 1.0;                                                 // :129
   unsigned it_outer = 0;
   int converged = 0;
@@ -961,6 +996,17 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
     double m_old = cls ? Ml[k + (size_t)s * K] : 0.0;
     double y_cur = yl[(size_t)s * Ky + ((Ky > 1 && cls) ? k : 0)];
     for (unsigned it0 = 0; it0 < nit; it0 += kSmallPf) {
+      // The scale w_scale, and with it gamma / w_scale and beta gamma / w_scale, follow a data-independent
+      // sequence (:162-168): lane l < kSmallPf runs the block's l + 1 multiplications (the same products in
+      // the same order as one lane would form them) and the two divisions of iteration l -- two division
+      // sequences per block instead of two per iteration.  A block in which the reset (:162-166) would
+      // fire takes the step-by-step path.
+      double ws_l = wscale;
+#pragma unroll
+      for (int q = 0; q < kSmallPf; ++q) ws_l = (q <= lane) ? ws_l * wscale_update : ws_l;
+      const bool block_plain = (wscale >= kSmall) && (__ballot(lane < kSmallPf - 1 && ws_l < kSmall) == 0ull);
+      const double f_l = gamma / ws_l;
+      const double tau_l = bg / ws_l;
 #pragma unroll
       for (int u = 0; u < kSmallPf; ++u) {
         const unsigned it = it0 + u;
@@ -976,8 +1022,10 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
         // (eight coefficients are read from LDS together, then added in order)
         double acc = 0.0;
         if (kK1) {
-          // one class: lane j holds w_j and x_j, the ascending sum runs over v_readlane operands
-          for (int jj = 0; jj < p; ++jj) acc += readlane_d(w, jj) * readlane_d(x, jj);
+          // one class: lane j holds w_j and x_j; every lane forms its product, the ascending sum runs over
+          // v_readlane operands (product rounded, then added: the reference's operations)
+          const double wx = w * x;
+          for (int jj = 0; jj < p; ++jj) acc += readlane_d(wx, jj);
         } else {
           for (int j0 = 0; j0 < p; j0 += 8) {
             double wv[8];
@@ -1009,13 +1057,22 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
           gc = g - m_old;
           Ml[k + (size_t)s * K] = g;
         }
-        if (wscale < kSmall) {                                          // :162-166
-          w *= wscale;
-          wscale = 1.0;
+        double f, tau;
+        if (block_plain) {
+          wscale = readlane_d(ws_l, u);                                 // :168, formed at the block's head
+          f = readlane_d(f_l, u);
+          tau = readlane_d(tau_l, u);
+        } else {
+          if (wscale < kSmall) {                                        // :162-166
+            w *= wscale;
+            wscale = 1.0;
+          }
+          wscale *= wscale_update;                                      // :168
+          f = gamma / wscale;
+          tau = bg / wscale;
         }
-        wscale *= wscale_update;                                        // :168
         if (d.fit_intercept && cls) {                                   // :170-173
-          const double gck = gc / n_d;
+          const double gck = div_by_n_exact(gc, n_d, rn_d);
           const double gbk = sgb + gck;
           sgb = gbk;
           sb -= gamma * (gbk + gck);
@@ -1023,13 +1080,11 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
         // ---- all coefficients: gradient step, penalty, gradient average (:176-183) ----
         // class k's change on every (k, j) lane
         const double gck = kK1 ? readlane_d(gc, 0) : __shfl(gc, k, kWave);
-        const double f = gamma / wscale;
         const double f2 = f;        // penalties.h: (gamma / w_scale) * scaling with scaling == 1.0: the same double
         w -= gck * x * f;                                               // :176
         if (penalty == SGDNET_RIDGE) {                                  // penalty(w, j, wscale, 1.0, g_sum), :179-180
           w -= f2 * G;
         } else if (penalty == SGDNET_ELASTICNET) {
-          const double tau = beta * gamma * 1.0 / wscale;
           w = soft_threshold(w - f2 * G, tau);
         } else {
           const double v = w - f2 * G;
@@ -1041,11 +1096,11 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
             nrm += vv * vv;
           }
           nrm = sqrt(nrm);
-          const double factor = beta * gamma * 1.0 / nrm;
+          const double factor = bg / nrm;
           w = factor < 1.0 ? v * (1.0 - factor / wscale) : 0.0;
           wave_sync(true);
         }
-        G += gck * x / n_d;                                             // :183
+        G += div_by_n_exact(gck * x, n_d, rn_d);                        // :183
         if (!active) { w = 0.0; G = 0.0; }
         if (!kK1) wl[lane] = w;
         // next iteration's operands (behind this iteration's gradient-memory store)
@@ -1172,7 +1227,11 @@ int dense_exact_wide_threads(const SagaDev& d) {
 size_t dense_exact_wide_lds_bytes(const SagaDev& d, bool stage_state) {
   const int kmax = wide_kmax(d), nwmax = wide_cap(d) / kWave;
   size_t b = sizeof(double) * (size_t)(nwmax * kmax + kmax + 3 * nwmax);
-  if (stage_state) b += sizeof(double) * 2 * (size_t)d.K * (size_t)d.p;
+  if (stage_state) {   // padded to whole chunks of T features
+    const size_t T = (size_t)dense_exact_wide_threads(d);
+    const size_t ppad = ((size_t)d.p + T - 1) / T * T;
+    b += sizeof(double) * 2 * (size_t)d.K * ppad;
+  }
   return (b + 15) & ~size_t(15);
 }
 
