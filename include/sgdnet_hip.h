@@ -339,6 +339,17 @@ int sgdnet_score_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32
 int sgdnet_score_dense(const double* x, int64_t n, int64_t p, const double* y, int y_rows, int family,
                        int n_classes, const double* a0, const double* beta, int n_lambda, int measure, int device,
                        double* out);
+/* type.measure = "auc" of score.sgdnet_binomial (R/score.R:98-99; auc() :203-233, the weighted branch the
+ * two-column indicator matrix selects).  y: class codes 0 / 1.  tie: the reference orders equal probabilities
+ * by stats::runif(2n) drawn per lambda -- pass those draws, 2n per lambda (entry i for a class-0 sample i,
+ * entry n + i for a class-1 sample), or NULL to break ties by position in the stacked vector (class-0 entries
+ * first, then sample order).  out: one area per lambda. */
+#define SGDNET_MEASURE_AUC      4   /* binomial; through sgdnet_score_*: no tie vector */
+int sgdnet_auc_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+                      const double* y, const double* a0, const double* beta, int n_lambda, const double* tie,
+                      int device, double* out);
+int sgdnet_auc_dense(const double* x, int64_t n, int64_t p, const double* y, const double* a0, const double* beta,
+                     int n_lambda, const double* tie, int device, double* out);
 int sgdnet_predict_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx,
                           const double* values, int n_classes, const double* a0, const double* beta,
                           int n_lambda, int device, double* link);

@@ -7,7 +7,10 @@
 // kernel: a wavefront owns a sample, lane c owns the (lambda, class) pair c, the coefficient
 // matrix is re-laid (p, lambda, class) so that one non-zero of the sample meets 64 contiguous
 // coefficients, and the per-sample losses are reduced per lambda without leaving the kernel.
+#include <cmath>
 #include <vector>
+
+#include <hipcub/hipcub.hpp>
 
 #include "common.hpp"
 #include "device_math.hpp"
@@ -155,6 +158,54 @@ __global__ __launch_bounds__(kScoreBlock) void score_kernel(ScoreArgs a) {
   }
 }
 
+// ---- AUC (R/score.R:98-99, auc() :203-233) -------------------------------------------------------------
+// score.sgdnet_binomial hands auc() the two-column indicator matrix, so the reference takes its weighted
+// branch: the 2n stacked entries (prob, prob) with weights (y == class 0, y == class 1) are ordered by
+// (prob, runif(2n)) and the area is sum over class-1 entries of the class-0 weight sorted before them,
+// divided by n0 n1.  Entries of weight zero change nothing, so sample i takes part once, with the tie
+// breaker tie[i] when it is of class 0 and tie[n + i] when it is of class 1 (no tie vector: position in the
+// stacked vector, i.e. class-0 entries first).
+// Two stable radix sorts (tie breaker, then probability), an exclusive scan of the class-0 flags, and an
+// integer sum: exact, whatever the order of the atomic adds.
+__device__ __forceinline__ unsigned long long ordered_bits(double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+__global__ __launch_bounds__(256) void auc_keys_kernel(const double* link, int64_t n, int L, int l, const double* y,
+                                                       const double* tie, unsigned long long* key_tie,
+                                                       unsigned* idx) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  idx[i] = (unsigned)i;
+  // no tie vector: the order of the stacked vector itself (every class-0 entry before every class-1 entry)
+  key_tie[i] = tie ? ordered_bits(y[i] < 0.5 ? tie[i] : tie[n + i])
+                   : (((y[i] < 0.5) ? 0ull : 1ull) << 32) | (unsigned long long)i;
+  (void)link; (void)L; (void)l;
+}
+
+// probability of the samples in the order of idx: R/predict.sgdnet.R type = "response", 1 / (1 + exp(-eta))
+__global__ __launch_bounds__(256) void auc_prob_kernel(const double* link, int64_t n, int L, int l, const unsigned* idx,
+                                                       unsigned long long* key_prob) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= n) return;
+  const double eta = link[(int64_t)idx[q] * L + l];
+  key_prob[q] = ordered_bits(1.0 / (1.0 + exp(-eta)));
+}
+
+__global__ __launch_bounds__(256) void auc_flags_kernel(const double* y, int64_t n, const unsigned* idx, unsigned* neg) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q < n) neg[q] = y[idx[q]] < 0.5 ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void auc_sum_kernel(const unsigned* neg, const unsigned* before, int64_t n,
+                                                      unsigned long long* u) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  unsigned long long v = (q < n && neg[q] == 0u) ? (unsigned long long)before[q] : 0ull;
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(u, v);
+}
+
 struct DevBufs {
   std::vector<void*> all;
   ~DevBufs() {
@@ -176,11 +227,14 @@ struct DevBufs {
 
 int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
               const double* x_dense, const double* y, int y_rows, int family, int n_classes, const double* a0,
-              const double* beta, int n_lambda, int measure, int device, double* out, double* link) {
+              const double* beta, int n_lambda, int measure, int device, double* out, double* link,
+              const double* tie = nullptr) {
+  const bool auc = measure == SGDNET_MEASURE_AUC;
   if (n < 1 || p < 1 || n_lambda < 1 || n_classes < 1 || !a0 || !beta || (!out && !link) ||
       (out && (!y || y_rows < 1)) || family < SGDNET_GAUSSIAN || family > SGDNET_MGAUSSIAN ||
-      measure < SGDNET_MEASURE_DEVIANCE || measure > SGDNET_MEASURE_CLASS ||
+      measure < SGDNET_MEASURE_DEVIANCE || measure > SGDNET_MEASURE_AUC ||
       (measure == SGDNET_MEASURE_CLASS && family != SGDNET_BINOMIAL && family != SGDNET_MULTINOMIAL) ||
+      (auc && (family != SGDNET_BINOMIAL || n_classes != 1 || !out || link || n >= (1ll << 31))) ||
       (!x_dense && !(rowptr && colidx && values))) {
     set_error("sgdnet_score/predict: bad argument");
     return SGDNET_EINVAL;
@@ -245,7 +299,38 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
     return rc;
   if (out && (rc = bufs.upload<double>(&out_d, nullptr, (size_t)n_lambda, st))) return rc;
   if (out) SGD_HIP_TRY(hipMemsetAsync(out_d, 0, sizeof(double) * n_lambda, st));
-  if (link && (rc = bufs.upload<double>(&link_d, nullptr, (size_t)n * K * chunk, st))) return rc;
+  if ((link || auc) && (rc = bufs.upload<double>(&link_d, nullptr, (size_t)n * K * chunk, st))) return rc;
+  // AUC scratch: keys, permutation, flags, prefix counts, one integer sum per lambda, radix sort / scan storage
+  unsigned long long *key_a = nullptr, *key_b = nullptr, *u_d = nullptr;
+  unsigned *idx_a = nullptr, *idx_b = nullptr, *neg_d = nullptr, *before_d = nullptr;
+  double* tie_d = nullptr;
+  void* tmp_d = nullptr;
+  size_t tmp_bytes = 0;
+  int64_t n1 = 0;
+  if (auc) {
+    for (int64_t i = 0; i < n; ++i) {
+      if (y[i] != 0.0 && y[i] != 1.0) {
+        set_error("sgdnet_score: auc needs class codes 0 / 1 in y");
+        return SGDNET_EINVAL;
+      }
+      n1 += y[i] == 1.0;
+    }
+    if ((rc = bufs.upload<unsigned long long>(&key_a, nullptr, (size_t)n, st)) ||
+        (rc = bufs.upload<unsigned long long>(&key_b, nullptr, (size_t)n, st)) ||
+        (rc = bufs.upload<unsigned long long>(&u_d, nullptr, (size_t)n_lambda, st)) ||
+        (rc = bufs.upload<unsigned>(&idx_a, nullptr, (size_t)n, st)) || (rc = bufs.upload<unsigned>(&idx_b, nullptr, (size_t)n, st)) ||
+        (rc = bufs.upload<unsigned>(&neg_d, nullptr, (size_t)n, st)) || (rc = bufs.upload<unsigned>(&before_d, nullptr, (size_t)n, st)))
+      return rc;
+    if (tie && (rc = bufs.upload<double>(&tie_d, nullptr, (size_t)2 * n, st))) return rc;
+    SGD_HIP_TRY(hipMemsetAsync(u_d, 0, sizeof(unsigned long long) * n_lambda, st));
+    size_t b1 = 0, b2 = 0;
+    SGD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, key_a, key_b, idx_a, idx_b, (int)n, 0, 64, st));
+    SGD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, b2, neg_d, before_d, (int)n, st));
+    tmp_bytes = b1 > b2 ? b1 : b2;
+    char* tq = nullptr;
+    if ((rc = bufs.upload<char>(&tq, nullptr, tmp_bytes, st))) return rc;
+    tmp_d = tq;
+  }
   int64_t grid = (n + 3) / 4;
   if (grid > 8192) grid = 8192;
   for (int l0 = 0; l0 < n_lambda; l0 += chunk) {
@@ -256,7 +341,7 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
     a.L = L;
     a.a0 = a0_d + K * l0;
     a.B = B;
-    a.out = out ? out_d + l0 : nullptr;
+    a.out = (out && !auc) ? out_d + l0 : nullptr;
     a.link = link_d;
     const size_t lds = sizeof(double) * (size_t)(kScoreBlock / 64) * L * K;
     if (x_dense)
@@ -264,6 +349,23 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
     else
       hipLaunchKernelGGL(score_kernel<true>, dim3((unsigned)grid), dim3(kScoreBlock), lds, st, a);
     SGD_HIP_TRY(hipGetLastError());
+    if (auc) {
+      const unsigned g = (unsigned)((n + 255) / 256);
+      for (int l = 0; l < L; ++l) {
+        if (tie) SGD_HIP_TRY(hipMemcpyAsync(tie_d, tie + (size_t)2 * n * (l0 + l), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(auc_keys_kernel, dim3(g), dim3(256), 0, st, link_d, n, L, l, a.y, tie_d, key_a, idx_a);
+        // stable order by the tie breaker first, then by the probability
+        SGD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp_d, tmp_bytes, key_a, key_b, idx_a, idx_b, (int)n, 0, 64, st));
+        const unsigned* order = idx_b;
+        hipLaunchKernelGGL(auc_prob_kernel, dim3(g), dim3(256), 0, st, link_d, n, L, l, order, key_a);
+        unsigned* sorted = idx_a;
+        SGD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp_d, tmp_bytes, key_a, key_b, order, sorted, (int)n, 0, 64, st));
+        hipLaunchKernelGGL(auc_flags_kernel, dim3(g), dim3(256), 0, st, a.y, n, sorted, neg_d);
+        SGD_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp_d, tmp_bytes, neg_d, before_d, (int)n, st));
+        hipLaunchKernelGGL(auc_sum_kernel, dim3(g), dim3(256), 0, st, neg_d, before_d, n, u_d + l0 + l);
+        SGD_HIP_TRY(hipGetLastError());
+      }
+    }
     if (link) {
       // host layout: link[(i * n_lambda + l) * K + k]
       SGD_HIP_TRY(hipMemcpy2DAsync(link + K * l0, sizeof(double) * K * n_lambda, link_d, sizeof(double) * K * L,
@@ -271,7 +373,14 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
       SGD_HIP_TRY(hipStreamSynchronize(st));
     }
   }
-  if (out) {
+  if (auc) {
+    std::vector<unsigned long long> u((size_t)n_lambda);
+    SGD_HIP_TRY(hipMemcpyAsync(u.data(), u_d, sizeof(unsigned long long) * n_lambda, hipMemcpyDeviceToHost, st));
+    SGD_HIP_TRY(hipStreamSynchronize(st));
+    // exp(log(sum) - log(n1) - log(n0)), as R/score.R:225-227 forms it
+    for (int l = 0; l < n_lambda; ++l)
+      out[l] = std::exp(std::log((double)u[(size_t)l]) - std::log((double)n1) - std::log((double)(n - n1)));
+  } else if (out) {
     SGD_HIP_TRY(hipMemcpyAsync(out, out_d, sizeof(double) * n_lambda, hipMemcpyDeviceToHost, st));
     SGD_HIP_TRY(hipStreamSynchronize(st));
     // R/score.R: mean over the samples; mgaussian: colSums over the samples, mean over the responses
@@ -312,6 +421,19 @@ int sgdnet_predict_dense(const double* x, int64_t n, int64_t p, int n_classes, c
                          int n_lambda, int device, double* link) {
   return sgdnet::run_score(n, p, nullptr, nullptr, nullptr, x, nullptr, 0, SGDNET_GAUSSIAN, n_classes, a0, beta,
                            n_lambda, SGDNET_MEASURE_DEVIANCE, device, nullptr, link);
+}
+
+int sgdnet_auc_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+                      const double* y, const double* a0, const double* beta, int n_lambda, const double* tie,
+                      int device, double* out) {
+  return sgdnet::run_score(n, p, rowptr, colidx, values, nullptr, y, 1, SGDNET_BINOMIAL, 1, a0, beta, n_lambda,
+                           SGDNET_MEASURE_AUC, device, out, nullptr, tie);
+}
+
+int sgdnet_auc_dense(const double* x, int64_t n, int64_t p, const double* y, const double* a0, const double* beta,
+                     int n_lambda, const double* tie, int device, double* out) {
+  return sgdnet::run_score(n, p, nullptr, nullptr, nullptr, x, y, 1, SGDNET_BINOMIAL, 1, a0, beta, n_lambda,
+                           SGDNET_MEASURE_AUC, device, out, nullptr, tie);
 }
 
 }  // extern "C"

@@ -38,9 +38,11 @@ def auc(y01, prob, weights=None, tie_break=None):
     return float(np.exp(wauc - np.log(sumw1) - np.log(sumw2)))
 
 
-def _score_device(fit, x, y, type_measure, s, device):
+def _score_device(fit, x, y, type_measure, s, device, tie_break=None):
     """sgdnet_score_* (score.hip): linear predictors, per-sample losses and their means in one
-    kernel on the GPU; x never leaves sample-major form and no (n, n_lambda) array is built."""
+    kernel on the GPU; x never leaves sample-major form and no (n, n_lambda) array is built.
+    "auc": sgdnet_auc_* -- probabilities, two stable radix sorts (tie breaker, probability), a scan of
+    the class-0 flags and an integer sum per lambda, all on the device."""
     import ctypes as C
     import scipy.sparse as sp
     from . import _lib
@@ -69,7 +71,28 @@ def _score_device(fit, x, y, type_measure, s, device):
     Lh = _lib.load()
     common = (dptr(yy), C.c_int(y_rows), C.c_int(FAMILIES[fam]), C.c_int(K), dptr(a0), dptr(beta), C.c_int(L),
               C.c_int(MEASURES[type_measure]), C.c_int(device), dptr(out))
-    if sp.issparse(x):
+    tie = None
+    if type_measure == "auc":
+        n_new = yy.shape[1]
+        if tie_break is not None:
+            tie = np.ascontiguousarray(np.asarray(tie_break, dtype=np.float64).T.reshape(-1)
+                                       if np.ndim(tie_break) == 2 else np.tile(np.asarray(tie_break, dtype=np.float64), L))
+            if tie.size != 2 * n_new * L:
+                raise ValueError("tie_break needs 2 n entries (or a (2 n, n_lambda) array)")
+        common = (dptr(yy), dptr(a0), dptr(beta), C.c_int(L), dptr(tie) if tie is not None else None, C.c_int(device),
+                  dptr(out))
+    if type_measure == "auc" and sp.issparse(x):
+        X = sp.csr_matrix(x, dtype=np.float64)
+        X.sort_indices()
+        ptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
+        idx = np.ascontiguousarray(X.indices, dtype=np.int32)
+        val = np.ascontiguousarray(X.data, dtype=np.float64)
+        check(Lh.sgdnet_auc_sparse(C.c_int64(X.shape[0]), C.c_int64(p), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                   idx.ctypes.data_as(C.POINTER(C.c_int32)), dptr(val), *common))
+    elif type_measure == "auc":
+        X = np.ascontiguousarray(x, dtype=np.float64)
+        check(Lh.sgdnet_auc_dense(dptr(X), C.c_int64(X.shape[0]), C.c_int64(p), *common))
+    elif sp.issparse(x):
         X = sp.csr_matrix(x, dtype=np.float64)
         X.sort_indices()
         if X.shape[1] != p:
@@ -87,24 +110,20 @@ def _score_device(fit, x, y, type_measure, s, device):
     return out
 
 
-def score(fit, x, y, type_measure="deviance", s=None, device=None):
+def score(fit, x, y, type_measure="deviance", s=None, device=None, tie_break=None):
     """score.sgdnet_<family>: one value per lambda (or per entry of s).
-    device: evaluate on that GPU (every measure except "auc", which needs a sort of the
-    probabilities and stays in numpy on device-computed predictions)."""
+    device: evaluate on that GPU.  tie_break ("auc" only): the reference orders equal probabilities by
+    stats::runif(2n) drawn per lambda; pass those draws (2n values used for every lambda, or a (2n, n_lambda)
+    array) to reproduce it, default: sample order."""
     fam = fit.family
     if type_measure not in _MEASURES[fam]:
         raise ValueError("'arg' should be one of " + ", ".join(f"'{m}'" for m in _MEASURES[fam]))
     s = fit.lambda_ if s is None else s
     y = np.asarray(y)
     if device is not None:
-        if type_measure == "auc":
-            ph = predict(fit, x, s, type="response", device=device)
-            levels = np.unique(y)
-            Y = (y.reshape(-1, 1) == levels.reshape(1, -1)).astype(np.float64)
-            return np.array([auc(Y, ph[:, i]) for i in range(ph.shape[1])])
         if type_measure == "deviance" and fam in ("gaussian", "mgaussian"):
             type_measure = "mse"                                  # R/score.R:63, 180: the same number
-        return _score_device(fit, x, y, type_measure, s, device)
+        return _score_device(fit, x, y, type_measure, s, device, tie_break)
     if fam == "gaussian":                                         # R/score.R:55-70
         yh = predict(fit, x, s)
         d = yh - y.reshape(-1, 1)
@@ -120,7 +139,9 @@ def score(fit, x, y, type_measure="deviance", s=None, device=None):
         ph = predict(fit, x, s, type="response")
         y1, y2 = Y[:, 0:1], Y[:, 1:2]
         if type_measure == "auc":
-            return np.array([auc(Y, ph[:, i]) for i in range(ph.shape[1])])
+            tb = None if tie_break is None else np.asarray(tie_break, dtype=np.float64)
+            return np.array([auc(Y, ph[:, i], tie_break=None if tb is None else (tb[:, i] if tb.ndim == 2 else tb))
+                             for i in range(ph.shape[1])])
         if type_measure == "mse":
             return np.mean((ph + y1 - 1) ** 2 + (ph - y2) ** 2, axis=0)
         if type_measure == "mae":

@@ -158,6 +158,32 @@ def test_device_predict_and_score_match_the_host_mirror(sa, family, sparse):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("sparse", [False, True])
+def test_device_auc_breaks_ties_like_the_reference(sa, sparse):
+    # R/score.R auc(): equal probabilities are ordered by runif(2n) drawn per lambda.  Held-out rows with
+    # many exact duplicates (and the intercept-only first lambda, where every probability ties): the device
+    # sort reproduces the host mirror for a given draw, for one draw shared by all lambdas, and without one
+    import scipy.sparse as sp
+    rng = np.random.default_rng(21)
+    n, p = 900, 15
+    X = np.round(rng.standard_normal((n, p)) * (rng.random((n, p)) < 0.4), 1)
+    X[600:] = X[rng.integers(500, 600, 300)]                       # duplicates among the held-out rows
+    y = (rng.random(n) < 1 / (1 + np.exp(-X[:, 0] + X[:, 1]))).astype(int)
+    Xin = sp.csc_matrix(X) if sparse else X
+    fit = sa.sgdnet(Xin[:500], y[:500], family="binomial", alpha=0.8, nlambda=12, thresh=1e-6, standardize=False)
+    xt, yt = Xin[500:], y[500:]
+    m, L = yt.size, len(fit.lambda_)
+    per_lambda = rng.random((2 * m, L))
+    shared = rng.random(2 * m)
+    for tb in (None, shared, per_lambda):
+        host = sa.score(fit, xt, yt, "auc", tie_break=tb)
+        dev = sa.score(fit, xt, yt, "auc", device=0, tie_break=tb)
+        assert np.allclose(host, dev, rtol=1e-13, atol=0), (host, dev)
+    assert not np.allclose(sa.score(fit, xt, yt, "auc", tie_break=shared), sa.score(fit, xt, yt, "auc"))   # ties matter here
+    assert abs(host[0] - 0.5) < 0.15                                # intercept only: the area of a coin flip
+
+
+@pytest.mark.gpu
 def test_device_score_with_many_lambdas_and_classes_is_chunked(sa):
     # more (lambda, class) pairs than one launch holds: the C entry point walks the path in chunks
     rng = np.random.default_rng(13)
