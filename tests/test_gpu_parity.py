@@ -243,6 +243,40 @@ def test_exact_wscale_reset_branch(sa, oracle):
         assert relerr(got[k], st[k]) < TOL_EXACT, k
 
 
+@pytest.mark.parametrize("family,K,penalty,n,p,fit_intercept", [
+    ("gaussian", 1, "elasticnet", 50, 65, True),        # one feature past a wavefront
+    ("binomial", 1, "ridge", 40, 513, True),            # one feature past the 512-thread workgroup: two chunks
+    ("binomial", 1, "elasticnet", 300, 1500, False),    # no intercept
+    ("multinomial", 16, "elasticnet", 300, 5, True),    # K * p just beyond the register-resident kernel
+    ("multinomial", 3, "ridge", 200, 1100, True),       # 512 threads, three chunks, staged in LDS
+    ("mgaussian", 5, "grouplasso", 120, 70, True),      # 256-thread variant, group lasso on register columns
+    ("mgaussian", 2, "grouplasso", 150, 300, True),
+    ("gaussian", 1, "elasticnet", 30, 9800, True),      # 2 K p doubles exceed the LDS: state in global memory
+])
+def test_wide_dense_exact_kernel_edge_shapes(sa, oracle, family, K, penalty, n, p, fit_intercept):
+    # saga_dense_exact_wide_kernel (workgroup per iteration) against the oracle's iteration in stream order;
+    # the sample stream repeats samples back to back (register forwarding of the gradient memory)
+    x, y = make_problem(family, K, n, p, None, seed=17, dense=True)
+    stream = oracle.Rng(4).stream(n, 3 * n)
+    stream[5:9] = stream[5]
+    stream[n - 1] = stream[n]                             # across the epoch boundary
+    a, b = (2e-3, 0.0) if penalty == "ridge" else (1e-3, 2e-3)
+    ref, got = run_both(sa, oracle, x, y, family=family, K=K, penalty=penalty, gamma=0.3 / p, alpha=a, beta=b,
+                        epochs=3, fit_intercept=fit_intercept, stream=stream)
+    for name in STATE:
+        assert relerr(got[2][name], ref[2][name]) < TOL_EXACT, name
+
+
+def test_wide_dense_exact_kernel_scale_reset(sa, oracle):
+    # alpha * gamma = 0.4: w_scale falls below SMALL every ~65 iterations (saga-dense.h:162-166) in the
+    # workgroup kernel, whose threads each fold the scale into their own features
+    x, y = make_problem("gaussian", 1, 400, 200, None, seed=19, dense=True)
+    ref, got = run_both(sa, oracle, x, y, family="gaussian", K=1, penalty="ridge", gamma=0.002, alpha=200.0, beta=0.0,
+                        epochs=2)
+    for name in STATE:
+        assert relerr(got[2][name], ref[2][name]) < TOL_EXACT, name
+
+
 def test_sparse_exact_implicit_centring(sa, oracle):
     # standardize=TRUE on sparse x: the dense O(p) terms of saga-sparse.h:127-128,276-277
     x, y = make_problem("binomial", 1, 1200, 40, 0.1, seed=10)
