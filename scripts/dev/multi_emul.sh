@@ -5,7 +5,7 @@
 export SGDNET_BENCH_BACKEND=gloo SGDNET_BENCH_ONE_GPU=1
 for cfg in "$@"; do
   set -- $cfg; N=$1; V=$2
-  timeout -k 10 900 python3 bench.py $EXTRA --gpus $N --vshards $V --steps 2 --warmup 1 --no-cpu-baseline --conv-max-epochs 150 2>/dev/null | tail -1 | python3 -c "
+  timeout -k 10 900 python3 bench.py $EXTRA --gpus $N --vshards $V --steps 2 --warmup 1 --no-cpu-baseline --conv-max-epochs ${CONV_MAX:-150} 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d.get('convergence',{})
 print('N=$N V=$V ranks_seen', d.get('n_ranks_seen'), 'merge:', d['config']['merge'][:90], '| epochs to 1e-6:', c.get('epochs'), 'converged', c.get('converged'))"

@@ -37,6 +37,32 @@ __device__ __forceinline__ void wave_sync(bool lds_only) {
   }
 }
 
+__device__ __forceinline__ double readlane_d(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Multinomial gradient of class `lane` (families.h:244-260, math.h:25-33) when lane k < K holds the linear
+// predictor of class k: one exp per class LANE instead of K + 1 per lane -- the other classes' terms arrive by
+// v_readlane and are added in ascending class order, so every intermediate is the double the reference forms.
+__device__ __forceinline__ double softmax_gradient_lanes(double lp, int K, int lane, double y_label) {
+  const bool cls = lane < K;
+  double mx = readlane_d(lp, 0);
+  for (int kk = 1; kk < K; ++kk) {
+    const double v = readlane_d(lp, kk);
+    mx = v > mx ? v : mx;
+  }
+  const double e = SGD_EXP((cls ? lp : mx) - mx);
+  double se = 0.0;
+  for (int kk = 0; kk < K; ++kk) se += readlane_d(e, kk);
+  const double lse = SGD_LOG(se) + mx;
+  double g = SGD_EXP((cls ? lp : lse) - lse);
+  if ((unsigned)lane == (unsigned)(y_label + 0.5)) g -= 1.0;
+  return g;
+}
+
 // ConvergenceCheck (src/utils.h:240-262), executed by the whole wave.
 __device__ __forceinline__ int convergence_check(const double* w, double* w_prev, int64_t len,
                                                  double tol, int lane) {
@@ -205,6 +231,15 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
 
       // gradient, gradient memory  :279-282
       const double y_first = __shfl(y_c, 0, kWave);   // single-response families: y of the draw
+      if (d.family == SGDNET_MULTINOMIAL && K <= kWave) {
+        const double g = softmax_gradient_lanes(lane < K ? slp[lane] : 0.0, K, lane, y_first);
+        if (lane < K) {
+          const int64_t mi = lane + (int64_t)s * K;
+          sgc[lane] = g - m_c;
+          d.M[mi] = g;
+          if (s1 == s) m_1 = g;
+        }
+      } else
       for (int k = lane; k < K; k += kWave) {
         const bool first = k < kWave;     // classes >= 64 are not register-carried
         double g;
@@ -434,6 +469,15 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
       }
       wave_sync(lds_only);
 
+      if (d.family == SGDNET_MULTINOMIAL && small_k) {               // :156-159, one exp per class lane
+        const double g = softmax_gradient_lanes(lane < K ? slp[lane] : 0.0, K, lane, sy[0]);
+        if (lane < K) {
+          const int64_t mi = lane + (int64_t)s * K;
+          sgc[lane] = g - m_cur;
+          d.M[mi] = g;
+          if (has_next && s1 == s) mn = g;
+        }
+      } else
       for (int k = lane; k < K; k += kWave) {                        // :156-159
         const double g = family_gradient_k(d.family, K, k, slp, small_k ? sy : d.y + (int64_t)s * d.Ky);
         const int64_t mi = k + (int64_t)s * K;
@@ -516,13 +560,6 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
 // Difference to the reference order: the dot product is summed as a tree instead of feature by
 // feature (rounding only, ~1e-16 relative; the parity tests hold at 1e-10).
 // --------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_d(double v, int src) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
 // a / n for a constant n (an integer count held as a double), rn = RN(1 / n): quotient estimate, exact
 // remainder, one correction (Markstein) -- three instructions instead of the ~30 of an IEEE division
 // sequence.  Correctly rounded whenever the remainder does not underflow; the wide kernel's parity
@@ -1048,9 +1085,7 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
         } else if (kFamily == SGDNET_MGAUSSIAN) {
           g = lp - (cls ? y_cur : 0.0);
         } else {
-          if (cls) slp[lane] = lp;
-          wave_sync(true);
-          if (cls) g = family_gradient_k(SGDNET_MULTINOMIAL, K, k, slp, &y_cur);
+          g = softmax_gradient_lanes(lp, K, lane, y_cur);
         }
         double gc = 0.0;
         if (cls) {                                                      // :156-159
