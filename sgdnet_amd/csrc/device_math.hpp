@@ -61,6 +61,37 @@ __device__ __forceinline__ void penalty_apply(int penalty, int K, double* wj, co
   }
 }
 
+// The same with q = gamma / w_scale formed once by the caller (gamma / w_scale * scaling is that quotient
+// times scaling: the same doubles), for kernels that apply the penalty several times per iteration.
+__device__ __forceinline__ void penalty_apply_q(int penalty, int K, double* wj, const double* gj, double w_scale,
+                                                double scaling, double q, double gamma, double beta) {
+  const double f = q * scaling;
+  if (penalty == SGDNET_RIDGE) {
+    for (int k = 0; k < K; ++k) wj[k] -= f * gj[k];
+  } else if (penalty == SGDNET_ELASTICNET) {
+    const double tau = beta * gamma * scaling / w_scale;
+    for (int k = 0; k < K; ++k) {
+      double v = wj[k] - f * gj[k];
+      wj[k] = soft_threshold(v, tau);
+    }
+  } else {
+    double nrm = 0.0;
+    for (int k = 0; k < K; ++k) {
+      double v = wj[k] - f * gj[k];
+      wj[k] = v;
+      nrm += v * v;
+    }
+    nrm = sqrt(nrm);
+    const double factor = beta * gamma * scaling / nrm;
+    if (factor < 1.0) {
+      const double m = 1.0 - factor / w_scale;
+      for (int k = 0; k < K; ++k) wj[k] *= m;
+    } else {
+      for (int k = 0; k < K; ++k) wj[k] = 0.0;
+    }
+  }
+}
+
 // LogSumExp over K linear predictors, ascending order.
 __device__ __forceinline__ double log_sum_exp(const double* lp, int K) {
   double mx = lp[0];

@@ -44,6 +44,24 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// a / n for a constant n (an integer count held as a double), rn = RN(1 / n): quotient estimate, exact
+// remainder, one correction (Markstein) -- three instructions instead of the ~30 of an IEEE division
+// sequence.  Correctly rounded whenever the remainder does not underflow; the wide kernel's parity
+// is to rounding, not bit for bit.
+__device__ __forceinline__ double div_by_n(double a, double n, double rn) {
+  const double q0 = a * rn;
+  const double rem = __builtin_fma(-q0, n, a);
+  return __builtin_fma(rem, rn, q0);
+}
+
+// the same, for the kernels that promise the reference's bits: below 1e-280 the remainder could underflow
+// and the plain division is used (elsewhere the result IS the correctly rounded quotient: rn is the correctly
+// rounded reciprocal of an integer-valued n, q0 is within an ulp, the remainder is exact)
+__device__ __forceinline__ double div_by_n_exact(double a, double n, double rn) {
+  if (fabs(a) < 1e-280) return a / n;
+  return div_by_n(a, n, rn);
+}
+
 // Multinomial gradient of class `lane` (families.h:244-260, math.h:25-33) when lane k < K holds the linear
 // predictor of class k: one exp per class LANE instead of K + 1 per lane -- the other classes' terms arrive by
 // v_readlane and are added in ascending class order, so every intermediate is the double the reference forms.
@@ -135,7 +153,7 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
   const int penalty = lamp->penalty;
   const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
   const double wscale_update = 1.0 - alpha * gamma;                  // :234
-  const double n_d = d.n_total;
+  const double n_d = d.n_total, rn_d = 1.0 / n_d;
   double wscale = 1.0;                                               // :227
 
   unsigned it_outer = 0;
@@ -192,11 +210,12 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
       }
 
       // LaggedUpdate(it_inner): catch-up of the sample's features  :263-272
+      const double q_before = gamma / wscale;     // gamma / w_scale of every penalty call until the scale moves
       if (mine) {
         const int64_t j = idx_c;
         const unsigned lagged = it - lag[j];
         if (lagged != 0) {
-          penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
+          penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_before, gamma, beta);
           lag[j] = it;
         }
       }
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
         const int64_t j = d.idx[q];
         const unsigned lagged = it - lag[j];
         if (lagged != 0) {
-          penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
+          penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_before, gamma, beta);
           lag[j] = it;
         }
       }
@@ -212,6 +231,15 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
 
       // linear predictor: lane k accumulates in ascending feature order  :274
       const int head = (q1 - q0) < kWave ? (int)(q1 - q0) : kWave;
+      if (K == 1 && q1 - q0 <= kWave) {
+        // one response, the whole row in the lanes: every lane forms its product (it caught up its own
+        // feature just above), the ascending sum runs over v_readlane operands -- product rounded, then
+        // added, the reference's operations -- instead of one lane walking the row through LDS
+        const double wx = mine ? val_c * w[idx_c] : 0.0;
+        double acc = 0.0;
+        for (int e = 0; e < head; ++e) acc += readlane_d(wx, e);
+        if (lane == 0) slp[0] = acc * wscale + sb[0];
+      } else
       for (int k = lane; k < K; k += kWave) {
         double acc = 0.0;
         for (int e = 0; e < head; ++e) acc += sval[e] * w[k + (int64_t)sidx[e] * K];
@@ -267,11 +295,12 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
       }
 
       wscale *= wscale_update;                                       // :297
+      const double q_after = gamma / wscale;
       wave_sync(lds_only);
 
       if (d.fit_intercept) {                                         // :300-304
         for (int k = lane; k < K; k += kWave) {
-          const double gck = sgc[k] / n_d;
+          const double gck = div_by_n_exact(sgc[k], n_d, rn_d);
           const double gbk = sgb[k] + gck;
           sgb[k] = gbk;
           sb[k] -= gamma * (gbk * 0.01 + gck);
@@ -280,7 +309,7 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
 
       // AddWeighted(w, ..., -gamma/wscale)  :306-313
       {
-        const double scaling = -gamma / wscale;
+        const double scaling = -q_after;            // -gamma / wscale: the quotient's sign flipped, the same double
         if (mine) {
           const int64_t j = idx_c;
           for (int k = 0; k < K; ++k) w[k + j * K] += val_c * sgc[k] * scaling;
@@ -308,7 +337,7 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
           const int64_t j = idx_c;
           const unsigned lagged = (it + 1) - lag[j];
           if (lagged != 0) {
-            penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
+            penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_after, gamma, beta);
             lag[j] = it + 1;
           }
           for (int k = 0; k < K; ++k) G[k + j * K] += val_c * sgc[k] * scaling;
@@ -317,7 +346,7 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
           const int64_t j = d.idx[q];
           const unsigned lagged = (it + 1) - lag[j];
           if (lagged != 0) {
-            penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
+            penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_after, gamma, beta);
             lag[j] = it + 1;
           }
           const double v = d.val[q];
@@ -560,24 +589,6 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_kernel(SagaDev d, cons
 // Difference to the reference order: the dot product is summed as a tree instead of feature by
 // feature (rounding only, ~1e-16 relative; the parity tests hold at 1e-10).
 // --------------------------------------------------------------------------
-// a / n for a constant n (an integer count held as a double), rn = RN(1 / n): quotient estimate, exact
-// remainder, one correction (Markstein) -- three instructions instead of the ~30 of an IEEE division
-// sequence.  Correctly rounded whenever the remainder does not underflow; the wide kernel's parity
-// is to rounding, not bit for bit.
-__device__ __forceinline__ double div_by_n(double a, double n, double rn) {
-  const double q0 = a * rn;
-  const double rem = __builtin_fma(-q0, n, a);
-  return __builtin_fma(rem, rn, q0);
-}
-
-// the same, for the kernels that promise the reference's bits: below 1e-280 the remainder could underflow
-// and the plain division is used (elsewhere the result IS the correctly rounded quotient: rn is the correctly
-// rounded reciprocal of an integer-valued n, q0 is within an ulp, the remainder is exact)
-__device__ __forceinline__ double div_by_n_exact(double a, double n, double rn) {
-  if (fabs(a) < 1e-280) return a / n;
-  return div_by_n(a, n, rn);
-}
-
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
