@@ -57,7 +57,7 @@ extern "C" {
 /* execution mode of the SAGA loop */
 #define SGDNET_MODE_EXACT   0  /* the reference iteration, one draw at a time, in stream order */
 #define SGDNET_MODE_BATCHED 1  /* `batch` consecutive draws against one snapshot (sparse x: up to 64 classes;
-                                  dense x: up to 16 classes); sgdnet_fit_*
+                                  dense x: up to 16 classes, 17..64 through the sparse form with every entry stored); sgdnet_fit_*
                                   fall back to the exact iteration outside that */
 #define SGDNET_MODE_AUTO    2  /* sgdnet_fit_* only: batched wherever it is implemented (see above), exact otherwise.  Same optimum, not the reference's
                                   iteration order; SGDNET_MODE_EXACT stays the default. */

@@ -601,9 +601,9 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   int mode = ctl->mode;
   int64_t batch = ctl->batch;
-  // SGDNET_MODE_BATCHED means "batched where it is implemented": more than 64 classes, and dense
-  // x with more than 16, run the exact iteration instead (a global options(sgdnet.mode = "batched")
-  // in R must not make such fits fail)
+  // SGDNET_MODE_BATCHED means "batched where it is implemented": more than 64 classes run the exact
+  // iteration instead (a global options(sgdnet.mode = "batched") in R must not make such fits fail);
+  // dense x with 17..64 classes was handed to the sparse entry point by sgdnet_fit_dense
   if (mode == SGDNET_MODE_AUTO) mode = SGDNET_MODE_BATCHED;
   if (mode == SGDNET_MODE_BATCHED && (K > 64 || (!X.sparse && K > 16))) mode = SGDNET_MODE_EXACT;
   if (mode == SGDNET_MODE_BATCHED) {
@@ -1043,6 +1043,25 @@ int sgdnet_fit_dense(const double* x, int64_t n, int64_t p, const double* y, int
   }
   rc = validate_response(ctl, y, n);
   if (rc) return rc;
+  if ((ctl->mode == SGDNET_MODE_BATCHED || ctl->mode == SGDNET_MODE_AUTO) && ctl->n_classes > 16 &&
+      ctl->n_classes <= 64 && n * p < (int64_t)2147483647) {
+    // Batched mode, dense x, 17..64 classes: the dense batched kernels stop at 16 classes, the sparse
+    // binned form (a wavefront per draw) goes to 64.  A column-major dense matrix IS a CSC matrix with
+    // every entry stored -- the values are x itself -- and sparse and dense inputs describe the same
+    // model (standardisation included: scale + implicit centring against explicit centring), so the fit is
+    // routed there instead of falling back to the one-wavefront exact iteration.
+    std::vector<int32_t> colptr((size_t)p + 1), rowidx((size_t)(n * p));
+    for (int64_t j = 0; j <= p; ++j) colptr[(size_t)j] = (int32_t)(j * n);
+    for (int64_t j = 0; j < p; ++j)
+      for (int64_t i = 0; i < n; ++i) rowidx[(size_t)(j * n + i)] = (int32_t)i;
+    sgdnet_csc csc{};
+    csc.n_rows = n;
+    csc.n_cols = p;
+    csc.colptr = colptr.data();
+    csc.rowidx = rowidx.data();
+    csc.values = x;
+    return sgdnet_fit_sparse(&csc, y, y_cols, ctl, out);
+  }
   Features X;
   X.sparse = false;
   X.n = n;

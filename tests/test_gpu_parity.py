@@ -880,8 +880,8 @@ def test_extreme_shapes_batched_and_exact(sa, oracle, family, K, n, p, dens, bat
 
 def test_more_than_sixteen_classes(sa, oracle):
     """17..64 classes: sparse x runs the binned form with a wavefront per draw (per-epoch parity with the
-    batched oracle, then the fit driver against the exact optimum); dense x and K > 64 keep the exact
-    iteration behind mode = "batched"."""
+    batched oracle, then the fit driver against the exact optimum); dense x goes the same way with every
+    entry stored; K > 64 keeps the exact iteration behind mode = "batched"."""
     # kernels: K = 18 and K = 40, elastic net and group lasso, tail batch, small p (the table would fit LDS)
     for family, K, penalty in (("multinomial", 18, "elasticnet"), ("mgaussian", 40, "grouplasso")):
         x, y = make_problem(family, K, 3000, 50, 0.2, seed=12)
@@ -901,12 +901,27 @@ def test_more_than_sixteen_classes(sa, oracle):
     assert fit.return_codes[0] == 0
     for k in range(K):
         assert np.abs(fit.beta[k][:, 0] - ref["beta"][k, :, 0]).max() < 1e-7
-    kw["thresh"] = 1e-6
-    ref = oracle.fit(np.asarray(X.todense()), y, seed=2, **kw)
-    fit = sa.sgdnet(np.asarray(X.todense()), y, seed=2, mode="batched", **kw)         # dense: the exact iteration
+    # dense x with 17..64 classes in batched mode: handed to the sparse binned form with every entry stored
+    # (round 1 and most of round 2: the exact iteration) -- same optimum, also with standardisation
+    for std in (False, True):
+        kw["standardize"] = std
+        Xd = np.asarray(X.todense()) + (0.3 if std else 0.0)
+        ref = oracle.fit(Xd, y, seed=2, thresh=1e-10, **{k_: v for k_, v in kw.items() if k_ != "thresh"})
+        fit = sa.sgdnet(Xd, y, seed=2, mode="batched", batch=64, thresh=1e-10, **{k_: v for k_, v in kw.items() if k_ != "thresh"})
+        assert fit.return_codes[0] == 0 and fit.npasses != ref["npasses"]
+        for k in range(K):
+            assert np.abs(fit.beta[k][:, 0] - ref["beta"][k, :, 0]).max() < 1e-7, (std, k)
+        a0 = ref["a0"][:, 0] - ref["a0"][:, 0].mean()              # R/sgdnet.R:409-410 centres the class intercepts
+        assert np.abs(fit.a0[:, 0] - a0).max() < 1e-7
+    # more than 64 classes keep the exact iteration behind mode = "batched"
+    K2 = 66
+    y2 = rng.integers(0, K2, n)
+    y2[:K2] = np.arange(K2)
+    y2[K2:2 * K2] = np.arange(K2)
+    kw2 = dict(family="multinomial", alpha=0.5, lambda_=[0.02], standardize=False, maxit=3000, thresh=1e-6)
+    ref = oracle.fit(np.asarray(X.todense()), y2, seed=2, **kw2)
+    fit = sa.sgdnet(np.asarray(X.todense()), y2, seed=2, mode="batched", **kw2)
     assert fit.npasses == ref["npasses"]
-    for k in range(K):
-        assert relerr(fit.beta[k][:, 0], ref["beta"][k, :, 0]) < 1e-8 or np.abs(ref["beta"][k, :, 0]).max() < 1e-12
 
 
 # ---------------------------------------------------------------------------------------------
