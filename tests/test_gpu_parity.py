@@ -377,6 +377,35 @@ def test_fit_paths_match_oracle(sa, oracle, family, sparse, standardize):
         assert len(got) == len(want) and relerr(got, want) < 1e-9
 
 
+@pytest.mark.parametrize("family", ["gaussian", "binomial", "multinomial", "mgaussian"])
+@pytest.mark.parametrize("standardize", [True, False])
+def test_fit_paths_on_wider_dense_rows_match_oracle(sa, oracle, family, standardize):
+    # the default (exact) mode through sgdnet() on dense rows beyond the register-resident kernel: the
+    # workgroup kernel under the lambda-path driver (several epochs per launch, draws consumed contiguously
+    # across epochs and lambdas, warm starts) against the oracle's fit under the same set.seed()
+    rng = np.random.default_rng(24)
+    n, p = 300, 90
+    x = rng.standard_normal((n, p)) * rng.uniform(0.5, 2.0, p) + rng.uniform(-1, 1, p)
+    z = x[:, :6] @ rng.uniform(-1, 1, (6, 3)) + 0.3
+    y = {"gaussian": z[:, 0] + 0.1 * rng.standard_normal(n),
+         "binomial": (rng.random(n) < 1 / (1 + np.exp(-z[:, 0]))).astype(float),
+         "multinomial": np.argmax(z + rng.gumbel(size=z.shape), axis=1).astype(float),
+         "mgaussian": z[:, :2] + 0.1 * rng.standard_normal((n, 2))}[family]
+    kw = dict(family=family, alpha=0.6, thresh=1e-5, standardize=standardize)
+    ref0 = oracle.fit(x, y, seed=3, nlambda=8, maxit=1, **kw)
+    lam = ref0["lambda"][1:]                                    # below lambda_max, as in test_fit_paths_match_oracle
+    fit = sa.sgdnet(x, y, seed=3, debug=True, lambda_=lam, **kw)
+    ref = oracle.fit(x, y, seed=3, debug=True, lambda_=lam, **kw)
+    assert fit.npasses == ref["npasses"]
+    beta = np.stack(fit.beta) if isinstance(fit.beta, list) else fit.beta[None]
+    assert relerr(beta, ref["beta"]) < 1e-8
+    a0 = ref["a0"] - ref["a0"].mean(axis=0, keepdims=True) if family == "multinomial" else ref["a0"]
+    assert relerr(np.atleast_2d(fit.a0), a0) < 1e-8
+    assert relerr(fit.dev_ratio, ref["dev_ratio"]) < 1e-8
+    for got, want in zip(fit.diagnostics["loss"], ref["losses"]):
+        assert len(got) == len(want) and relerr(got, want) < 1e-9
+
+
 def test_fit_batched_mode_reaches_the_exact_optimum(sa, oracle):
     # BASELINE config 3 shape scaled down: the relaxed mode is checked at tight convergence
     from sgdnet_amd import data as D
