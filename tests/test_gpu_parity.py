@@ -834,6 +834,34 @@ def test_cv_sgdnet_runs_the_reference_protocol(sa, oracle):
     assert np.allclose(cv2.cv_summary[:, 2], cv.cv_summary[:, 2], rtol=5e-3)
 
 
+def test_cv_sgdnet_auc_draws_its_tie_breakers_from_the_shared_generator(sa):
+    # R/cv_sgdnet.R with type.measure = "auc": every fold's score() calls auc() once per lambda, and auc()
+    # orders equal probabilities by stats::runif(2 n) from R's global generator -- draws that also move the
+    # stream the NEXT fold's fit starts from.  The protocol replayed by hand with one generator gives the table.
+    rng0 = np.random.default_rng(6)
+    n, p = 240, 5
+    X = np.round(rng0.standard_normal((n, p)), 0)                # coarse x: many tied probabilities
+    y = (rng0.random(n) < 1 / (1 + np.exp(-X[:, 0]))).astype(int)
+    kw = dict(family="binomial", nlambda=5, thresh=1e-5)
+    cv = sa.cv_sgdnet(X, y, alpha=1.0, nfolds=3, type_measure="auc", seed=11, **kw)
+    assert cv.name == "AUC" and cv.cv_raw[0].shape == (3, 5)
+    r = sa.RRng(11)
+    full = sa.sgdnet(X, y, alpha=1.0, rng=r, **kw)
+    from sgdnet_amd.cv import r_cut
+    foldid = r_cut(r.sample(n), 3)
+    assert np.array_equal(foldid, cv.foldid)
+    for j in range(3):
+        train = foldid == j + 1
+        fit = sa.sgdnet(X[train], y[train], alpha=1.0, lambda_=full.lambda_, rng=r, family="binomial", thresh=1e-5)
+        m = int((~train).sum())
+        tie = r.unif(2 * m * 5).reshape(5, 2 * m).T
+        want = sa.score(fit, X[~train], y[~train], "auc", tie_break=tie)
+        assert np.allclose(cv.cv_raw[0][j], want, rtol=1e-12), j
+    # on the device path too (sgdnet_auc_* with the same draws)
+    cvd = sa.cv_sgdnet(X, y, alpha=1.0, nfolds=3, type_measure="auc", seed=11, **kw)
+    assert np.allclose(cvd.cv_raw[0], cv.cv_raw[0], rtol=1e-12)
+
+
 @pytest.mark.parametrize("family,K,penalty,batch", [
     ("binomial", 1, "elasticnet", 64), ("binomial", 1, "elasticnet", 6000), ("multinomial", 3, "elasticnet", 500),
     ("multinomial", 3, "elasticnet", 6000), ("multinomial", 10, "ridge", 500), ("mgaussian", 2, "grouplasso", 6000)])
