@@ -1,0 +1,96 @@
+"""Differential sweep: random small problems through every kernel family (exact: register-resident, workgroup,
+one-wavefront, sparse; batched: LDS, atomic, binned, dense, tiled) against the CPU oracle's restatement of the
+same iteration on the same sample stream.  Shapes are drawn around the dispatch boundaries (K*p = 64, p = 64 /
+512, K = 16 / 17, batch = 1 / n)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+STATE = ("w", "intercept", "g_sum", "g_memory", "g_sum_intercept")
+
+
+@pytest.fixture(scope="module")
+def sa():
+    import torch  # noqa: F401
+    import sgdnet_amd
+    if sgdnet_amd.load().sgdnet_device_count() < 1:
+        pytest.fail("GPU tests need a HIP device; the backend has no CPU fallback")
+    return sgdnet_amd
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import pyoracle as po
+    return po
+
+
+def _case(seed):
+    r = np.random.default_rng(1000 + seed)
+    family = ["gaussian", "binomial", "multinomial", "mgaussian"][seed % 4]
+    K = 1 if family in ("gaussian", "binomial") else int(r.choice([2, 3, 4, 5, 9, 16, 17, 20]))
+    p = int(r.choice([1, 2, 3, 4, 7, 16, 21, 22, 63, 64, 65, 130, 511, 513, 700]))
+    if K * p > 6000:
+        p = max(1, 6000 // K)
+    n = int(r.choice([5, 17, 64, 150, 400]))
+    dense = bool(r.random() < 0.55)
+    penalty = "grouplasso" if family == "mgaussian" and r.random() < 0.6 else str(r.choice(["ridge", "elasticnet"]))
+    fit_intercept = bool(r.random() < 0.8)
+    mode = "exact" if r.random() < 0.5 else "batched"
+    batch = int(r.choice([1, 3, 16, 64, n, 4 * n])) if mode == "batched" else 0
+    centre = bool((not dense) and r.random() < 0.3)              # sparse standardize = TRUE: implicit centring
+    heavy_ridge = bool(r.random() < 0.15)                        # alpha * gamma = 0.3: the w_scale reset fires
+    return dict(family=family, K=K, p=p, n=n, dense=dense, penalty=penalty, fit_intercept=fit_intercept, mode=mode,
+                batch=batch, centre=centre, heavy_ridge=heavy_ridge, seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(240))
+def test_random_problem_matches_the_oracle(sa, oracle, seed):
+    c = _case(seed)
+    r = np.random.default_rng(seed)
+    n, p, K, family = c["n"], c["p"], c["K"], c["family"]
+    if c["mode"] == "batched" and c["dense"] and K > 16:
+        pytest.skip("dense x with more than 16 classes has no batched kernel (sgdnet_fit_dense routes it to the sparse form)")
+    dens = 1.0 if c["dense"] else float(r.choice([0.05, 0.3, 0.9]))
+    X = r.standard_normal((p, n)) * (r.random((p, n)) < dens)
+    if not c["dense"]:
+        X[:, X.any(axis=0) == 0] = 0.0
+        X[r.integers(0, p, n), np.arange(n)] += 0.5             # no empty sample
+    B = r.standard_normal((K, p)) * 0.5
+    lp = B @ X
+    if family == "gaussian":
+        y = lp[0:1] + 0.1 * r.standard_normal((1, n))
+    elif family == "binomial":
+        y = (r.random((1, n)) < 1 / (1 + np.exp(-lp[0:1]))).astype(float)
+    elif family == "multinomial":
+        y = np.argmax(lp + r.gumbel(size=lp.shape), axis=0).astype(float).reshape(1, n)
+    else:
+        y = lp + 0.1 * r.standard_normal(lp.shape)
+    x = np.asfortranarray(X) if c["dense"] else sp.csc_matrix(X)
+    y = np.asfortranarray(y)
+    L = float((X ** 2).sum(axis=0).max()) + 1.0
+    gamma = 0.3 / L
+    a, b = (2e-3, 0.0) if c["penalty"] == "ridge" else (1e-3, 2e-3)
+    if c["heavy_ridge"]:
+        a = 0.3 / gamma
+    cvec = r.normal(0, 0.05, p) if c["centre"] else None
+    epochs = 2
+    stream = oracle.Rng(seed).stream(n, n * epochs)
+    if n > 8:
+        stream[3:6] = stream[3]                                    # a sample drawn three times in a row
+    st = oracle.new_state(K, p, n)
+    oracle.saga(x if not c["dense"] else sp.csc_matrix(X) if c["mode"] == "batched" else x, y, st, family=family,
+                penalty=c["penalty"], gamma=gamma, alpha=a, beta=b, fit_intercept=c["fit_intercept"], max_iter=epochs,
+                tol=0.0, stream=stream, batch=c["batch"] if c["mode"] == "batched" else 0,
+                standardize=cvec is not None, x_center_scaled=cvec)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K, fit_intercept=c["fit_intercept"], x_center_scaled=cvec)
+    S.set_penalty(c["penalty"], gamma, a, b)
+    S.upload_stream(stream)
+    ep, _ = S.run(mode=c["mode"], batch=c["batch"], max_epochs=epochs, tol=0.0)
+    assert ep == epochs, c
+    tol = 1e-9 if c["mode"] == "batched" else 1e-10
+    for name in STATE:
+        got, want = S.get(name), st[name]
+        err = float(np.abs(np.asarray(got) - np.asarray(want)).max() / max(1e-300, np.abs(want).max()))
+        assert err < tol or np.abs(want).max() < 1e-300, (c, name, err)
+    S.close()
