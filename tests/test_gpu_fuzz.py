@@ -94,3 +94,37 @@ def test_random_problem_matches_the_oracle(sa, oracle, seed):
         err = float(np.abs(np.asarray(got) - np.asarray(want)).max() / max(1e-300, np.abs(want).max()))
         assert err < tol or np.abs(want).max() < 1e-300, (c, name, err)
     S.close()
+
+
+@pytest.mark.parametrize("seed", range(32))
+def test_random_fit_matches_the_oracle_fit(sa, oracle, seed):
+    # the lambda-path driver in its default (exact) mode against the oracle's fit under the same set.seed():
+    # random family / storage / standardisation / intercept / mixing / shape, a short path below lambda_max
+    r = np.random.default_rng(5000 + seed)
+    family = ["gaussian", "binomial", "multinomial", "mgaussian"][seed % 4]
+    n = int(r.choice([40, 120, 300]))
+    p = int(r.choice([2, 5, 12, 30, 70, 140]))
+    sparse = bool(r.random() < 0.5)
+    x = r.standard_normal((n, p)) * r.uniform(0.5, 2.0, p) * (r.random((n, p)) < (0.4 if sparse else 1.0))
+    x[np.arange(n), r.integers(0, p, n)] += 0.7
+    z = x[:, : min(p, 4)] @ r.uniform(-1, 1, (min(p, 4), 3)) + 0.2
+    y = {"gaussian": z[:, 0] + 0.1 * r.standard_normal(n),
+         "binomial": (r.random(n) < 1 / (1 + np.exp(-z[:, 0]))).astype(float),
+         "multinomial": np.argmax(z + r.gumbel(size=z.shape), axis=1).astype(float),
+         "mgaussian": z[:, :2] + 0.1 * r.standard_normal((n, 2))}[family]
+    if family in ("binomial", "multinomial"):
+        y[: 3] = [0, 1, 2 if family == "multinomial" else 1]     # every class present
+    xx = sp.csc_matrix(x) if sparse else x
+    kw = dict(family=family, alpha=float(r.choice([0.0, 0.3, 1.0])), thresh=float(r.choice([1e-3, 1e-5])),
+              standardize=bool(r.random() < 0.5), intercept=bool(r.random() < 0.8))
+    ref0 = oracle.fit(xx, y, seed=seed, nlambda=6, maxit=1, **kw)
+    lam = ref0["lambda"][1:]
+    fit = sa.sgdnet(xx, y, seed=seed, lambda_=lam, **kw)
+    ref = oracle.fit(xx, y, seed=seed, lambda_=lam, **kw)
+    assert fit.npasses == ref["npasses"], (kw, n, p, sparse)
+    beta = np.stack(fit.beta) if isinstance(fit.beta, list) else fit.beta[None]
+    scale = max(np.abs(ref["beta"]).max(), 1e-12)
+    assert np.abs(beta - ref["beta"]).max() < 1e-8 * scale, (kw, n, p, sparse)
+    a0 = ref["a0"] - ref["a0"].mean(axis=0, keepdims=True) if family == "multinomial" else ref["a0"]
+    assert np.abs(np.atleast_2d(fit.a0) - a0).max() < 1e-8 * max(np.abs(a0).max(), 1.0)
+    assert np.allclose(fit.dev_ratio, ref["dev_ratio"], rtol=1e-8, atol=1e-10)
