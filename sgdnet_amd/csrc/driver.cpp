@@ -40,6 +40,9 @@ struct PhaseTimer {
   }
 };
 
+constexpr int64_t kRetryWindowMin = 16;     // shortest window the divergence restarts go down to
+thread_local bool t_batched_diverged = false;   // set when a batched fit gave up: mode = auto then reruns the fit in exact mode
+
 struct Features {
   bool sparse = false;
   int64_t n = 0, p = 0;
@@ -811,11 +814,16 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
           if (vshards > 1) {
             vshards = 0;
             rc = sgdnet_solver_set_virtual_shards(S, 0);
-          } else if (batch > 64) {
-            batch = std::max<int64_t>(64, batch / 4);
+          } else if (batch > kRetryWindowMin) {
+            // the rule's own floor is 64 draws; a fit that blows up there (few, strongly scaled dense
+            // features) gets a shorter window before batched mode is given up
+            batch = std::max<int64_t>(kRetryWindowMin, batch / 4);
             auto_window = batch;
+            if (getenv("SGDNET_TRACE"))
+              fprintf(stderr, "[sgdnet]   lambda %d: non-finite coefficients -> window %lld, again\n", li, (long long)batch);
           } else {
             set_error("batched mode diverged (non-finite coefficients) at the smallest window; use mode = exact");
+            t_batched_diverged = true;
             return SGDNET_EUNSUPPORTED;
           }
           if (!rc) rc = solver_reset_state(S, b0.data());
@@ -936,10 +944,42 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
 }  // namespace
 
+// mode = auto promises a fit: when the batched iteration gives up (non-finite coefficients even at the
+// shortest window) the whole fit is run again in exact mode
+template <class F>
+static int with_exact_fallback(const sgdnet_control* ctl, F fit) {
+  t_batched_diverged = false;
+  int rc = fit(ctl);
+  if (rc == SGDNET_EUNSUPPORTED && t_batched_diverged && ctl && ctl->mode == SGDNET_MODE_AUTO) {
+    if (getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet] mode = auto: batched iteration gave up, fitting again in exact mode\n");
+    sgdnet_control exact = *ctl;
+    exact.mode = SGDNET_MODE_EXACT;
+    exact.batch = 0;
+    t_batched_diverged = false;
+    rc = fit(&exact);
+  }
+  return rc;
+}
+
 extern "C" {
+
+static int fit_sparse_impl(const sgdnet_csc* x, const double* y, int y_cols, const sgdnet_control* ctl,
+                           sgdnet_result* out);
+static int fit_dense_impl(const double* x, int64_t n, int64_t p, const double* y, int y_cols,
+                          const sgdnet_control* ctl, sgdnet_result* out);
 
 int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols, const sgdnet_control* ctl,
                       sgdnet_result* out) {
+  return with_exact_fallback(ctl, [&](const sgdnet_control* c) { return fit_sparse_impl(x, y, y_cols, c, out); });
+}
+
+int sgdnet_fit_dense(const double* x, int64_t n, int64_t p, const double* y, int y_cols,
+                     const sgdnet_control* ctl, sgdnet_result* out) {
+  return with_exact_fallback(ctl, [&](const sgdnet_control* c) { return fit_dense_impl(x, n, p, y, y_cols, c, out); });
+}
+
+static int fit_sparse_impl(const sgdnet_csc* x, const double* y, int y_cols, const sgdnet_control* ctl,
+                           sgdnet_result* out) {
   int rc = validate(ctl, out, y_cols);
   if (rc) return rc;
   if (!x || !y || x->n_rows <= 0 || x->n_cols <= 0 || !x->colptr || !x->rowidx || !x->values) {
@@ -1033,8 +1073,8 @@ int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols, const sg
   return fit_common(X, y, y_cols, ctl, out);
 }
 
-int sgdnet_fit_dense(const double* x, int64_t n, int64_t p, const double* y, int y_cols,
-                     const sgdnet_control* ctl, sgdnet_result* out) {
+static int fit_dense_impl(const double* x, int64_t n, int64_t p, const double* y, int y_cols,
+                          const sgdnet_control* ctl, sgdnet_result* out) {
   int rc = validate(ctl, out, y_cols);
   if (rc) return rc;
   if (!x || !y || n <= 0 || p <= 0) {

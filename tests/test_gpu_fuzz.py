@@ -2,6 +2,8 @@
 one-wavefront, sparse; batched: LDS, atomic, binned, dense, tiled) against the CPU oracle's restatement of the
 same iteration on the same sample stream.  Shapes are drawn around the dispatch boundaries (K*p = 64, p = 64 /
 512, K = 16 / 17, batch = 1 / n)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -130,7 +132,9 @@ def test_random_fit_matches_the_oracle_fit(sa, oracle, seed):
     assert np.allclose(fit.dev_ratio, ref["dev_ratio"], rtol=1e-8, atol=1e-10)
 
 
-@pytest.mark.parametrize("seed", range(24))
+# seeds 88 and 91 (few strongly scaled dense features): the rule's 64-draw floor blows up; the driver restarts
+# with a 16-draw window, and mode = "auto" would rerun the fit in exact mode if that failed too
+@pytest.mark.parametrize("seed", sorted(set(range(int(os.environ.get("SGDNET_FUZZ_BATCHED_FITS", 24)))) | {88, 91}))
 def test_random_fit_in_batched_mode_reaches_the_oracle_optimum(sa, oracle, seed):
     # mode = "auto" (automatic window, virtual shards off at these sizes): another trajectory, the same optimum
     r = np.random.default_rng(7000 + seed)
