@@ -174,7 +174,7 @@ def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True
         idx = np.ascontiguousarray(x.indices, dtype=np.int32)
         val = np.ascontiguousarray(x.data, dtype=np.float64)
         c = np.zeros(p) if x_center_scaled is None else np.ascontiguousarray(x_center_scaled)
-        if batch and batch > 1:
+        if batch and batch >= 1:                                   # batch = 1 is the batched iteration with one draw per batch, not the exact one
             ep = L.orc_saga_sparse_batched(
                 C.byref(P), C.c_int64(batch), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
                 idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(val), _dp(c), _dp(y), Ky,

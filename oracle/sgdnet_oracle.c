@@ -1079,7 +1079,7 @@ static int fit_common(const orc_xmat* X,            /* feature-major, preprocess
     P.beta = beta[li];
     P.gamma = step_size(norm_max, alpha[li], ctl->fit_intercept, family_L_scaling(family), n);
     if (X->sparse) {
-      if (ctl->batch > 1)
+      if (ctl->batch >= 1)
         epochs = orc_saga_sparse_batched(&P, ctl->batch, sptr, sidx, sval, x_center_scaled, yt, Ky,
                                          intercept, w,
                                          M, G, gb, draws, &rc, losses);

@@ -46,7 +46,7 @@ def _case(seed):
                 batch=batch, centre=centre, heavy_ridge=heavy_ridge, seed=seed)
 
 
-@pytest.mark.parametrize("seed", range(240))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SGDNET_FUZZ_KERNEL_CASES", 600))))
 def test_random_problem_matches_the_oracle(sa, oracle, seed):
     c = _case(seed)
     r = np.random.default_rng(seed)
@@ -81,7 +81,7 @@ def test_random_problem_matches_the_oracle(sa, oracle, seed):
     if n > 8:
         stream[3:6] = stream[3]                                    # a sample drawn three times in a row
     st = oracle.new_state(K, p, n)
-    oracle.saga(x if not c["dense"] else sp.csc_matrix(X) if c["mode"] == "batched" else x, y, st, family=family,
+    ep_ref, _, _ = oracle.saga(x if not c["dense"] else sp.csc_matrix(X) if c["mode"] == "batched" else x, y, st, family=family,
                 penalty=c["penalty"], gamma=gamma, alpha=a, beta=b, fit_intercept=c["fit_intercept"], max_iter=epochs,
                 tol=0.0, stream=stream, batch=c["batch"] if c["mode"] == "batched" else 0,
                 standardize=cvec is not None, x_center_scaled=cvec)
@@ -89,7 +89,7 @@ def test_random_problem_matches_the_oracle(sa, oracle, seed):
     S.set_penalty(c["penalty"], gamma, a, b)
     S.upload_stream(stream)
     ep, _ = S.run(mode=c["mode"], batch=c["batch"], max_epochs=epochs, tol=0.0)
-    assert ep == epochs, c
+    assert ep == ep_ref, c                       # (a solution that is exactly zero and stays zero stops early in both)
     tol = 1e-9 if c["mode"] == "batched" else 1e-10
     for name in STATE:
         got, want = S.get(name), st[name]
@@ -98,7 +98,7 @@ def test_random_problem_matches_the_oracle(sa, oracle, seed):
     S.close()
 
 
-@pytest.mark.parametrize("seed", range(32))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("SGDNET_FUZZ_EXACT_FITS", 32))))
 def test_random_fit_matches_the_oracle_fit(sa, oracle, seed):
     # the lambda-path driver in its default (exact) mode against the oracle's fit under the same set.seed():
     # random family / storage / standardisation / intercept / mixing / shape, a short path below lambda_max
