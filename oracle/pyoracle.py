@@ -54,7 +54,7 @@ class _SagaParams(C.Structure):
                 ("fit_intercept", C.c_int), ("standardize", C.c_int),
                 ("gamma", C.c_double), ("alpha", C.c_double), ("beta", C.c_double),
                 ("max_iter", C.c_uint), ("tol", C.c_double), ("debug", C.c_int),
-                ("n_total", C.c_int64)]
+                ("n_total", C.c_int64), ("dense_intercept", C.c_int)]
 
 
 class _Control(C.Structure):
@@ -134,8 +134,11 @@ def batch_factors(alpha, gamma, m):
 
 def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True,
          standardize=False, x_center_scaled=None, max_iter=1, tol=0.0, stream=None, rng=None,
-         batch=0, debug=False, n_total=0, epoch_len=None):
+         batch=0, debug=False, n_total=0, epoch_len=None, dense_intercept=False):
     """Run the SAGA loop for one (gamma, alpha, beta) on sample-major data.
+
+    dense_intercept (batched restatement of a DENSE matrix handed over as CSC with every entry stored):
+    the intercept step of saga-dense.h:170-173 instead of the sparse one with its 0.01 decay.
 
     epoch_len (timing only, bench.py's bounded cpu_baseline on config 5): the inner loop runs
     epoch_len iterations per epoch instead of n_samples, drawing from the whole data set through an
@@ -158,7 +161,8 @@ def saga(x, y, state, *, family, penalty, gamma, alpha, beta, fit_intercept=True
     if epoch_len is not None:
         assert stream is not None and not batch
     P = _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n if epoch_len is None else int(epoch_len), p,
-                    int(fit_intercept), int(standardize), gamma, alpha, beta, max_iter, tol, int(debug), n_total)
+                    int(fit_intercept), int(standardize), gamma, alpha, beta, max_iter, tol, int(debug), n_total,
+                    int(dense_intercept))
     y = np.asfortranarray(y, dtype=np.float64)
     if y.ndim == 1:
         y = y.reshape(1, -1)
@@ -270,19 +274,20 @@ def fit(x, y, *, family="gaussian", alpha=1.0, nlambda=100, lambda_min_ratio=Non
     return out
 
 
-def _params(state, x, *, family, penalty, gamma, alpha, beta, fit_intercept, standardize, n_total):
+def _params(state, x, *, family, penalty, gamma, alpha, beta, fit_intercept, standardize, n_total, dense_intercept=False):
     K = state["w"].shape[0]
     p, n = x.shape
     return _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n, p, int(fit_intercept),
-                       int(standardize), gamma, alpha, beta, 1, 0.0, 0, n_total)
+                       int(standardize), gamma, alpha, beta, 1, 0.0, 0, n_total, int(dense_intercept))
 
 
 def batch_gather(x, y, state, draws, D, d0, *, family, penalty, gamma, alpha, beta,
-                 fit_intercept=True, x_center_scaled=None, n_total=0):
+                 fit_intercept=True, x_center_scaled=None, n_total=0, dense_intercept=False):
     """Gather half of one batch (orc_batch_gather): adds into D (K,p) F-order and d0 (K)."""
     x = x.tocsc()
     P = _params(state, x, family=family, penalty=penalty, gamma=gamma, alpha=alpha, beta=beta,
-                fit_intercept=fit_intercept, standardize=x_center_scaled is not None, n_total=n_total)
+                fit_intercept=fit_intercept, standardize=x_center_scaled is not None, n_total=n_total,
+                dense_intercept=dense_intercept)
     ptr = np.ascontiguousarray(x.indptr, dtype=np.int64)
     idx = np.ascontiguousarray(x.indices, dtype=np.int32)
     val = np.ascontiguousarray(x.data, dtype=np.float64)
@@ -297,12 +302,12 @@ def batch_gather(x, y, state, draws, D, d0, *, family, penalty, gamma, alpha, be
 
 
 def batch_sweep(x_shape, state, m_global, D, d0, *, family, penalty, gamma, alpha, beta,
-                fit_intercept=True, x_center_scaled=None, n_total=0):
+                fit_intercept=True, x_center_scaled=None, n_total=0, dense_intercept=False):
     """Sweep half of one batch (orc_batch_sweep): consumes and zeroes D, d0."""
     K = state["w"].shape[0]
     p, n = x_shape
     P = _SagaParams(FAMILIES[family], PENALTIES[penalty], K, n, p, int(fit_intercept),
-                    int(x_center_scaled is not None), gamma, alpha, beta, 1, 0.0, 0, n_total)
+                    int(x_center_scaled is not None), gamma, alpha, beta, 1, 0.0, 0, n_total, int(dense_intercept))
     c = None if x_center_scaled is None else np.ascontiguousarray(x_center_scaled, dtype=np.float64)
     lib().orc_batch_sweep(C.byref(P), C.c_int64(m_global), _dp(c) if c is not None else None, _dp(D),
                           _dp(d0), _dp(state["intercept"]), _dp(state["w"]), _dp(state["g_sum"]),

@@ -642,7 +642,7 @@ void orc_batch_sweep(const orc_saga_params* P, int64_t m, const double* c, doubl
   if (P->fit_intercept) {
     for (k = 0; k < K; ++k) {
       gb[k] += d0[k] / nt;
-      intercept[k] -= gamma * (gb[k] * 0.01 * (double)m + d0[k] / nt);
+      intercept[k] -= gamma * (gb[k] * (P->dense_intercept ? 1.0 : 0.01) * (double)m + d0[k] / nt);
     }
   }
   for (k = 0; k < K; ++k) d0[k] = 0.0;

@@ -80,6 +80,8 @@ typedef struct {
   int      debug;
   int64_t  n_total;       /* batched oracle only: samples of the whole (sharded) job that the
                              gradient average divides by; 0 => n_samples */
+  int      dense_intercept; /* batched oracle only: x is a dense matrix stored with every entry -- the intercept
+                               step of saga-dense.h:170-173 (no 0.01 decay) instead of saga-sparse.h:300-304 */
 } orc_saga_params;
 
 /* Sparse SAGA, sample-major CSC (column i = sample i): reference

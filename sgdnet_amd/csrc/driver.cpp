@@ -40,7 +40,13 @@ struct PhaseTimer {
   }
 };
 
-constexpr int64_t kRetryWindowMin = 16;     // shortest window the divergence restarts go down to
+// Shortest staleness window the driver uses.  The exported rule (sgdnet_auto_batch) floors at 64 draws, and
+// for dense x with a dominant common factor (or few, strongly scaled features) 2 L_max / L_F is well below
+// that: a 64-draw window then oscillates or settles on a wrong point without tripping a guard (a random
+// sweep of 30-lambda paths found deviance ratios off by 0.06-0.6).  Below 8 draws a batch is no longer
+// worth its launch: mode = auto takes the exact iteration there.
+constexpr int64_t kWindowFloor = 8;
+constexpr int64_t kRetryWindowMin = kWindowFloor;     // shortest window the divergence restarts go down to
 thread_local bool t_batched_diverged = false;   // set when a batched fit gave up: mode = auto then reruns the fit in exact mode
 
 struct Features {
@@ -356,7 +362,7 @@ double sample_gram_lmax(const double* xs, size_t m, size_t p) {
   return lmax;
 }
 
-int64_t auto_batch(const Features& X, double max_sample_sqnorm) {
+int64_t auto_batch(const Features& X, double max_sample_sqnorm, double* l_f = nullptr) {
   // largest mean squared feature value = largest diagonal entry of X'X/n
   double diag = 0.0;
   for (int64_t j = 0; j < X.p; ++j) {
@@ -433,7 +439,15 @@ int64_t auto_batch(const Features& X, double max_sample_sqnorm) {
     }
     diag = std::max(diag, lmax);
   }
+  if (l_f) *l_f = diag;
   return sgdnet_auto_batch(max_sample_sqnorm, diag);
+}
+
+// 2 L_max / L_F without the exported rule's floor of 64 (kWindowFloor instead); *raw = the unclamped value
+int64_t window_rule(double max_sample_sqnorm, double l_f, double* raw) {
+  *raw = (max_sample_sqnorm > 0.0 && l_f > 0.0) ? 2.0 * max_sample_sqnorm / l_f : 64.0;
+  if (!(*raw < 131072.0)) return 131072;
+  return *raw < (double)kWindowFloor ? kWindowFloor : (int64_t)*raw;
 }
 
 int validate(const sgdnet_control* c, const sgdnet_result* out, int y_cols) {
@@ -610,7 +624,20 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   if (mode == SGDNET_MODE_AUTO) mode = SGDNET_MODE_BATCHED;
   if (mode == SGDNET_MODE_BATCHED && (K > 64 || (!X.sparse && K > 16))) mode = SGDNET_MODE_EXACT;
   if (mode == SGDNET_MODE_BATCHED) {
-    if (batch <= 0) batch = X.dev ? sgdnet_auto_batch(norm_max, X.dev_max_mean_sq) : auto_batch(X, norm_max);
+    if (batch <= 0) {
+      double l_f = X.dev_max_mean_sq, raw = 0.0;
+      if (!X.dev) (void)auto_batch(X, norm_max, &l_f);
+      // dense x takes the dense intercept step (no 0.01 decay): the constant feature is part of the curvature the
+      // stale sum has to respect (its mean square is 1; + 1 bounds the largest eigenvalue of the augmented Gram)
+      if (!X.sparse && fit_intercept) l_f += 1.0;
+      batch = window_rule(norm_max, l_f, &raw);
+      if (ctl->mode == SGDNET_MODE_AUTO && raw < (double)kWindowFloor) {
+        if (getenv("SGDNET_TRACE"))
+          fprintf(stderr, "[sgdnet]   mode = auto: window rule gives %.1f draws (< %lld): exact iteration\n", raw, (long long)kWindowFloor);
+        mode = SGDNET_MODE_EXACT;
+        batch = 0;
+      }
+    }
   } else if (mode != SGDNET_MODE_EXACT) {
     set_error("unknown mode %d", mode);
     return SGDNET_EINVAL;
@@ -842,11 +869,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
         if (ratio > 4.0 * best_ratio && ratio > 0.05 && sz > 1e-9 && epochs > 2 && !at_lambda_max) ++worse;
         else worse = 0;
         if (ratio > 0.0) best_ratio = std::min(best_ratio, ratio);
-        if (worse >= 2 && ctl->batch <= 0 && batch > 64) {
+        if (worse >= 2 && ctl->batch <= 0 && batch > kWindowFloor) {
           if (getenv("SGDNET_TRACE"))
             fprintf(stderr, "[sgdnet]   lambda %d epoch %u: change ratio %.3g after best %.3g -> window %lld halved\n", li,
                     epochs, ratio, best_ratio, (long long)batch);
-          batch = std::max<int64_t>(64, batch / 2);
+          batch = std::max<int64_t>(kWindowFloor, batch / 2);
           // what made the window too long (correlated features) does not depend on lambda: keep
           // it -- except at lambda_max, where a handful of coefficients flicker around zero
           if (li > 0) auto_window = batch;
@@ -879,7 +906,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // null model's (w = 0, intercept only -- the point every lambda can reach) is not a fit.
     const bool worse_than_previous = li > 0 && lambda[(size_t)li] < lambda[(size_t)li - 1] && dev > prev_dev * (1.0 + 1e-3);
     const bool worse_than_null = dev > null_dev_scaled * (1.0 + 1e-3) || !std::isfinite(dev);
-    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && (worse_than_previous || worse_than_null) && batch > 64 &&
+    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && (worse_than_previous || worse_than_null) && batch > kWindowFloor &&
         retries < 8) {
       if (getenv("SGDNET_TRACE"))
         fprintf(stderr, "[sgdnet]   lambda %d: deviance %.6g (previous lambda %.6g, null model %.6g) -> window %lld / 4, again\n",
@@ -889,7 +916,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
         rc = sgdnet_solver_set_virtual_shards(S, 0);
         if (rc) return rc;
       }
-      auto_window = std::max<int64_t>(64, batch / 4);
+      auto_window = std::max<int64_t>(kWindowFloor, batch / 4);
       rc = solver_reset_state(S, b0.data());
       if (rc) return rc;
       ++retries;

@@ -10,7 +10,7 @@
 //                         D[:, j] += x_sj * gc   for j in nz(x_s)             (:306-313, :328-335)
 //   sweep  : per feature  w_j = r^m w_j - gamma LS_m G_j - gamma D_j ; prox   (:316-325 + penalties.h)
 //                         G_j += D_j / n ;  D_j = 0
-//            intercept    gb += d0/n ; b -= gamma (0.01 m gb + d0/n)          (:300-304)
+//            intercept    gb += d0/n ; b -= gamma (0.01 m gb + d0/n)          (:300-304; dense x: m gb, saga-dense.h:170-173)
 //
 // with r = 1 - alpha*gamma and LS_m = sum_{k<m} r^k (= lag_scaling[m], :229-240).
 // m == 1 is the reference iteration itself.  A sample drawn twice inside one
@@ -1492,7 +1492,8 @@ __device__ __forceinline__ void sweep_intercept(const SagaDev& d, const SweepPar
     const double dk = sh_d0[k] / q.n_d;
     const double gbk = d.gb[k] + dk;
     d.gb[k] = gbk;
-    d.b[k] -= q.gamma * (gbk * 0.01 * q.m_d + dk);
+    // sparse x: the reference's intercept decay 0.01 (saga-sparse.h:300-304); dense x: none (saga-dense.h:170-173)
+    d.b[k] -= q.gamma * (gbk * (d.xd ? 1.0 : 0.01) * q.m_d + dk);
   }
 }
 
@@ -1707,7 +1708,7 @@ __global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamPar
     const double dk = d0_s / n_d;
     const double gbk = d.vgb[v] + dk;
     d.vgb[v] = gbk;
-    d.vb[v] -= q.gamma * (gbk * 0.01 * q.m_d + dk);
+    d.vb[v] -= q.gamma * (gbk * (d.xd ? 1.0 : 0.01) * q.m_d + dk);
   }
 }
 

@@ -84,7 +84,7 @@ def test_random_problem_matches_the_oracle(sa, oracle, seed):
     ep_ref, _, _ = oracle.saga(x if not c["dense"] else sp.csc_matrix(X) if c["mode"] == "batched" else x, y, st, family=family,
                 penalty=c["penalty"], gamma=gamma, alpha=a, beta=b, fit_intercept=c["fit_intercept"], max_iter=epochs,
                 tol=0.0, stream=stream, batch=c["batch"] if c["mode"] == "batched" else 0,
-                standardize=cvec is not None, x_center_scaled=cvec)
+                standardize=cvec is not None, x_center_scaled=cvec, dense_intercept=c["dense"])
     S = sa.SagaSolver(x, y, family=family, n_classes=K, fit_intercept=c["fit_intercept"], x_center_scaled=cvec)
     S.set_penalty(c["penalty"], gamma, a, b)
     S.upload_stream(stream)

@@ -135,7 +135,7 @@ def test_dense_batched_matches_batched_oracle(sa, oracle, family, K, penalty, p,
     stream = oracle.Rng(5).stream(n, n * 3)
     kw = dict(family=family, penalty=penalty, gamma=0.4 / p, alpha=1e-3, beta=0.0 if penalty == "ridge" else 2e-3)
     st = oracle.new_state(K, p, n)
-    oracle.saga(sp.csc_matrix(x), y, st, max_iter=3, tol=0.0, stream=stream, batch=batch, **kw)
+    oracle.saga(sp.csc_matrix(x), y, st, max_iter=3, tol=0.0, stream=stream, batch=batch, dense_intercept=True, **kw)
     S = sa.SagaSolver(x, y, family=family, n_classes=K)
     S.set_penalty(penalty, kw["gamma"], kw["alpha"], kw["beta"])
     S.upload_stream(stream)
@@ -159,7 +159,7 @@ def test_dense_tiled_form_matches_batched_oracle(sa, oracle, family, K, penalty,
     stream = oracle.Rng(6).stream(n, n * 2)
     kw = dict(family=family, penalty=penalty, gamma=0.4 / p, alpha=1e-3, beta=0.0 if penalty == "ridge" else 2e-3)
     st = oracle.new_state(K, p, n)
-    oracle.saga(sp.csc_matrix(x), y, st, max_iter=2, tol=0.0, stream=stream, batch=batch, **kw)
+    oracle.saga(sp.csc_matrix(x), y, st, max_iter=2, tol=0.0, stream=stream, batch=batch, dense_intercept=True, **kw)
     S = sa.SagaSolver(x, y, family=family, n_classes=K)
     S.set_penalty(penalty, kw["gamma"], kw["alpha"], kw["beta"])
     S.upload_stream(stream)
@@ -1128,6 +1128,8 @@ def test_virtual_shards_with_implicit_centring(sa, oracle, V, n, p, batch, famil
 def _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense, c=None):
     x, y = make_problem(family, 1, n, p, 0.5 if dense else 0.1, seed=29)
     kw = dict(family=family, penalty="elasticnet", gamma=0.005, alpha=1e-4, beta=1e-4)
+    if dense:
+        kw["dense_intercept"] = True                               # dense x: saga-dense.h's intercept step
     if c is not None:
         kw["x_center_scaled"] = c
     epochs = 3
