@@ -166,3 +166,32 @@ def test_random_fit_in_batched_mode_reaches_the_oracle_optimum(sa, oracle, seed)
     beta = np.stack(fit.beta) if isinstance(fit.beta, list) else fit.beta[None]
     scale = max(np.abs(ref["beta"]).max(), 1e-12)
     assert np.abs(beta - ref["beta"]).max() < 1e-5 * scale, (kw, n, p, sparse)
+
+
+@pytest.mark.parametrize("seed", [1, 13, 33, 36, 37])
+def test_auto_mode_agrees_with_exact_on_dense_paths(sa, seed):
+    # 30-lambda paths at the default thresh on dense x (a dominant common factor in three of the five): these
+    # were off by 0.006-0.6 in deviance ratio while the batched iteration carried the sparse intercept decay and a
+    # 64-draw window floor (scripts/dev/auto_vs_exact_paths.py)
+    r = np.random.default_rng(9000 + seed)
+    family = ["gaussian", "binomial", "multinomial", "mgaussian"][seed % 4]
+    n = int(r.choice([500, 2000, 5000]))
+    p = int(r.choice([8, 40, 200, 1000]))
+    sparse = bool(r.random() < 0.6)
+    corr = float(r.choice([0.0, 0.0, 0.7, 0.95]))
+    f = r.standard_normal((n, 1))
+    x = (np.sqrt(1 - corr) * r.standard_normal((n, p)) + np.sqrt(corr) * f) * r.uniform(0.3, 3.0, p)
+    assert not sparse
+    x = x + r.uniform(-2, 2, p)
+    k0 = min(p, 6)
+    z = x[:, :k0] @ r.uniform(-1, 1, (k0, 3)) + 0.2
+    y = {"gaussian": z[:, 0] + 0.3 * r.standard_normal(n),
+         "binomial": (r.random(n) < 1 / (1 + np.exp(-z[:, 0]))).astype(float),
+         "multinomial": np.argmax(z + r.gumbel(size=z.shape), axis=1).astype(float),
+         "mgaussian": z[:, :2] + 0.3 * r.standard_normal((n, 2))}[family]
+    kw = dict(family=family, alpha=float(r.choice([0.0, 0.5, 1.0])), standardize=bool(r.random() < 0.6), nlambda=30)
+    ex = sa.sgdnet(x, y, seed=seed, **kw)
+    au = sa.sgdnet(x, y, seed=seed, mode="auto", **kw)
+    assert not np.any(np.asarray(au.return_codes) != 0)
+    assert np.abs(np.asarray(au.dev_ratio) - np.asarray(ex.dev_ratio)).max() < 3e-3
+    assert au.npasses < 2.0 * ex.npasses + 50
