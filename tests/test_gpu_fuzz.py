@@ -195,3 +195,45 @@ def test_auto_mode_agrees_with_exact_on_dense_paths(sa, seed):
     assert not np.any(np.asarray(au.return_codes) != 0)
     assert np.abs(np.asarray(au.dev_ratio) - np.asarray(ex.dev_ratio)).max() < 3e-3
     assert au.npasses < 2.0 * ex.npasses + 50
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_device_predict_and_score_match_the_host_mirror(sa, seed):
+    # score.hip against the numpy mirror of R/predict.sgdnet.R / R/score.R: random family, storage, shape,
+    # every measure of the family (AUC with per-lambda tie breakers), whole path and interpolated lambdas
+    from sgdnet_amd.score import _MEASURES
+    r = np.random.default_rng(11000 + seed)
+    family = ["gaussian", "binomial", "multinomial", "mgaussian"][seed % 4]
+    n, p = int(r.choice([60, 300, 1500])), int(r.choice([1, 3, 17, 70, 300]))
+    K = int(r.choice([3, 5, 12])) if family == "multinomial" else (int(r.choice([2, 4])) if family == "mgaussian" else 1)
+    sparse = bool(r.random() < 0.5)
+    x = np.round(r.standard_normal((n, p)), 1) * (r.random((n, p)) < (0.3 if sparse else 1.0))
+    x[np.arange(n), r.integers(0, p, n)] += 0.5
+    z = x[:, : min(p, 4)] @ r.uniform(-1, 1, (min(p, 4), max(K, 2))) + 0.1
+    if family == "gaussian":
+        y = z[:, 0] + 0.2 * r.standard_normal(n)
+    elif family == "binomial":
+        y = (r.random(n) < 1 / (1 + np.exp(-z[:, 0]))).astype(int)
+        y[:2] = [0, 1]
+    elif family == "multinomial":
+        y = np.argmax(z[:, :K] + r.gumbel(size=(n, K)), axis=1) if z.shape[1] >= K else r.integers(0, K, n)
+        y[:K] = np.arange(K)
+    else:
+        y = z[:, :K] + 0.2 * r.standard_normal((n, K)) if z.shape[1] >= K else r.standard_normal((n, K))
+    xin = sp.csc_matrix(x) if sparse else x
+    ntr = n // 2
+    fit = sa.sgdnet(xin[:ntr], y[:ntr], family=family, alpha=0.6, nlambda=9, thresh=1e-4, mode="auto")
+    xt, yt = xin[ntr:], y[ntr:]
+    if family in ("binomial", "multinomial") and len(np.unique(yt)) < len(np.unique(y[:ntr])):
+        pytest.skip("a class is missing from the held-out half")
+    for typ in ("link", "response"):
+        a, b = sa.predict(fit, xt, type=typ), sa.predict(fit, xt, type=typ, device=0)
+        assert a.shape == b.shape and np.allclose(a, b, rtol=1e-10, atol=1e-12), typ
+    L = len(fit.lambda_)
+    for sel in (None, fit.lambda_[[0, L // 2]] * 0.93):
+        Ls = L if sel is None else 2
+        for measure in _MEASURES[family]:
+            tb = r.random((2 * (n - ntr), Ls)) if measure == "auc" else None
+            host = sa.score(fit, xt, yt, measure, s=sel, tie_break=tb)
+            dev = sa.score(fit, xt, yt, measure, s=sel, device=0, tie_break=tb)
+            assert host.shape == dev.shape and np.allclose(host, dev, rtol=1e-9, atol=1e-12), (measure, host, dev)
