@@ -629,7 +629,10 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       if (!X.dev) (void)auto_batch(X, norm_max, &l_f);
       // dense x takes the dense intercept step (no 0.01 decay): the constant feature is part of the curvature the
       // stale sum has to respect (its mean square is 1; + 1 bounds the largest eigenvalue of the augmented Gram)
-      if (!X.sparse && fit_intercept) l_f += 1.0;
+      // (standardised dense features are centred: the constant direction is orthogonal to them and the largest
+      //  eigenvalue is max(L_F, 1); otherwise the coupling through the column means is bounded by + 1 after the
+      //  step-size normalisation by the largest row)
+      if (!X.sparse && fit_intercept) l_f = ctl->standardize ? std::max(l_f, 1.0) : l_f + 1.0;
       batch = window_rule(norm_max, l_f, &raw);
       if (ctl->mode == SGDNET_MODE_AUTO && raw < (double)kWindowFloor) {
         if (getenv("SGDNET_TRACE"))
