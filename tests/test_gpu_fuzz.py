@@ -119,11 +119,18 @@ def test_random_fit_matches_the_oracle_fit(sa, oracle, seed):
     xx = sp.csc_matrix(x) if sparse else x
     kw = dict(family=family, alpha=float(r.choice([0.0, 0.3, 1.0])), thresh=float(r.choice([1e-3, 1e-5])),
               standardize=bool(r.random() < 0.5), intercept=bool(r.random() < 0.8))
-    ref0 = oracle.fit(xx, y, seed=seed, nlambda=6, maxit=1, **kw)
+    if family in ("gaussian", "mgaussian") and r.random() < 0.4:
+        kw["standardize_response"] = True
+    if r.random() < 0.25:
+        kw["maxit"] = int(r.choice([1, 3, 10]))                 # lambdas that stop at max_iter: return_code 1
+    ref0 = oracle.fit(xx, y, seed=seed, nlambda=6, **{**kw, "maxit": 1})
     lam = ref0["lambda"][1:]
+    if r.random() < 0.25:
+        lam = lam[r.permutation(lam.size)]                      # a user-supplied sequence in any order
     fit = sa.sgdnet(xx, y, seed=seed, lambda_=lam, **kw)
     ref = oracle.fit(xx, y, seed=seed, lambda_=lam, **kw)
     assert fit.npasses == ref["npasses"], (kw, n, p, sparse)
+    assert np.array_equal(np.asarray(fit.return_codes), np.asarray(ref["return_codes"])), (kw, n, p, sparse)
     beta = np.stack(fit.beta) if isinstance(fit.beta, list) else fit.beta[None]
     scale = max(np.abs(ref["beta"]).max(), 1e-12)
     assert np.abs(beta - ref["beta"]).max() < 1e-8 * scale, (kw, n, p, sparse)
