@@ -46,6 +46,7 @@ struct PhaseTimer {
 // sweep of 30-lambda paths found deviance ratios off by 0.06-0.6).  Below 8 draws a batch is no longer
 // worth its launch: mode = auto takes the exact iteration there.
 constexpr int64_t kWindowFloor = 8;
+constexpr int64_t kMaxBatchesPerEpoch = 16384;
 constexpr int64_t kRetryWindowMin = kWindowFloor;     // shortest window the divergence restarts go down to
 thread_local bool t_batched_diverged = false;   // set when a batched fit gave up: mode = auto then reruns the fit in exact mode
 
@@ -634,9 +635,12 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       //  step-size normalisation by the largest row)
       if (!X.sparse && fit_intercept) l_f = ctl->standardize ? std::max(l_f, 1.0) : l_f + 1.0;
       batch = window_rule(norm_max, l_f, &raw);
-      if (ctl->mode == SGDNET_MODE_AUTO && raw < (double)kWindowFloor) {
+      // ... and so does an epoch of more than kMaxBatchesPerEpoch batches (a short window on many samples): the
+      // captured epoch would be a graph of several 10^4 launches, each a few microseconds of fixed cost
+      if (ctl->mode == SGDNET_MODE_AUTO && (raw < (double)kWindowFloor || n / batch > kMaxBatchesPerEpoch)) {
         if (getenv("SGDNET_TRACE"))
-          fprintf(stderr, "[sgdnet]   mode = auto: window rule gives %.1f draws (< %lld): exact iteration\n", raw, (long long)kWindowFloor);
+          fprintf(stderr, "[sgdnet]   mode = auto: window rule gives %.1f draws (%lld batches per epoch): exact iteration\n", raw,
+                  (long long)(n / batch));
         mode = SGDNET_MODE_EXACT;
         batch = 0;
       }
