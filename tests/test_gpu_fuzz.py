@@ -244,3 +244,46 @@ def test_random_device_predict_and_score_match_the_host_mirror(sa, seed):
             host = sa.score(fit, xt, yt, measure, s=sel, tie_break=tb)
             dev = sa.score(fit, xt, yt, measure, s=sel, device=0, tie_break=tb)
             assert host.shape == dev.shape and np.allclose(host, dev, rtol=1e-9, atol=1e-12), (measure, host, dev)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_wide_dense_rows_in_exact_mode(sa, oracle, seed):
+    # the workgroup exact kernel on rows of thousands of features: LDS-staged state (padded to whole chunks),
+    # state in global memory (2 K p doubles beyond the LDS), 1 / 2..4 / 5..16 class variants, several batches of
+    # chunks per thread, few samples (repeats back to back)
+    r = np.random.default_rng(23000 + seed)
+    family = ["gaussian", "binomial", "multinomial", "mgaussian"][seed % 4]
+    K = 1 if family in ("gaussian", "binomial") else int(r.choice([2, 4, 5, 16]))
+    p = int(r.choice([1500, 4100, 9000, 12500])) // (1 if K == 1 else (2 if K <= 4 else K))
+    n = int(r.choice([12, 40, 90]))
+    X = r.standard_normal((p, n))
+    B = r.standard_normal((K, p)) * (r.random((K, p)) < 0.02)
+    lp = B @ X
+    if family == "gaussian":
+        y = lp[0:1] + 0.1 * r.standard_normal((1, n))
+    elif family == "binomial":
+        y = (r.random((1, n)) < 1 / (1 + np.exp(-lp[0:1]))).astype(float)
+    elif family == "multinomial":
+        y = np.argmax(lp + r.gumbel(size=lp.shape), axis=0).astype(float).reshape(1, n)
+    else:
+        y = lp + 0.1 * r.standard_normal(lp.shape)
+    x, y = np.asfortranarray(X), np.asfortranarray(y)
+    penalty = "grouplasso" if family == "mgaussian" and r.random() < 0.6 else str(r.choice(["ridge", "elasticnet"]))
+    gamma = 0.3 / (float((X ** 2).sum(axis=0).max()) + 1.0)
+    a, b = (2e-3, 0.0) if penalty == "ridge" else (1e-3, 2e-3)
+    fit_intercept = bool(r.random() < 0.8)
+    stream = oracle.Rng(seed).stream(n, 3 * n)
+    stream[2:5] = stream[2]
+    st = oracle.new_state(K, p, n)
+    ep_ref, _, _ = oracle.saga(x, y, st, family=family, penalty=penalty, gamma=gamma, alpha=a, beta=b,
+                               fit_intercept=fit_intercept, max_iter=3, tol=0.0, stream=stream)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K, fit_intercept=fit_intercept)
+    S.set_penalty(penalty, gamma, a, b)
+    S.upload_stream(stream)
+    ep, _ = S.run(mode="exact", max_epochs=3, tol=0.0)
+    assert ep == ep_ref
+    for name in STATE:
+        got, want = S.get(name), st[name]
+        err = float(np.abs(np.asarray(got) - np.asarray(want)).max() / max(1e-300, np.abs(want).max()))
+        assert err < 1e-10 or np.abs(want).max() < 1e-300, (family, K, p, n, penalty, name, err)
+    S.close()
