@@ -358,7 +358,10 @@ int sgdnet_predict_dense(const double* x, int64_t n, int64_t p, int n_classes, c
 
 /* Default staleness window of the batched mode: about 2 * L_max / L_F, where L_max is the
  * largest squared sample norm and L_F is bounded below by the largest mean squared feature
- * value (the diagonal of X'X/n); clamped to [64, 131072].  DESIGN.md "Choosing the batch". */
+ * value (the diagonal of X'X/n); clamped to [64, 131072].  DESIGN.md "Choosing the batch".
+ * sgdnet_fit_* apply the same rule with the largest eigenvalue of X'X/n where it is cheap (dense x: power
+ * iteration, plus the constant feature), let it go down to 8 draws, and under SGDNET_MODE_AUTO take the exact
+ * iteration when the rule asks for less than that or an epoch would be more than 16384 batches. */
 int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq);
 
 #ifdef __cplusplus
