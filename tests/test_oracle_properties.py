@@ -316,3 +316,28 @@ def test_batch_factors_match_cumulative_table(oracle):
         assert rm == pytest.approx(r ** m, rel=1e-13)
         assert lsm == pytest.approx(ls[m], rel=1e-12)
     assert oracle.batch_factors(0.0, gamma, 9) == (1.0, 9.0)
+
+
+def test_batched_intercept_step_sparse_and_dense_rule(oracle):
+    # orc_batch_sweep: gb += d0 / n; b -= gamma (c m gb + d0 / n) with the reference's decay c = 0.01 for sparse x
+    # (saga-sparse.h:300-304) and c = 1 for a dense matrix handed over with every entry stored (saga-dense.h:170-173);
+    # nothing else depends on the flag
+    rng = np.random.default_rng(5)
+    K, p, n, m, gamma = 3, 7, 50, 9, 0.05
+    out = {}
+    for dense in (False, True):
+        st = oracle.new_state(K, p, n)
+        st["intercept"][:] = rng.standard_normal(K) * 0 + np.array([0.3, -0.2, 0.1])
+        st["g_sum_intercept"][:] = np.array([0.02, -0.01, 0.05])
+        st["w"][...] = np.asfortranarray(np.arange(K * p, dtype=float).reshape(K, p) / 50.0)
+        D = np.asfortranarray(np.linspace(-1, 1, K * p).reshape(K, p))
+        d0 = np.array([0.4, -0.7, 0.2])
+        b0, gb0 = st["intercept"].copy(), st["g_sum_intercept"].copy()
+        oracle.batch_sweep((p, n), st, m, D, d0.copy(), family="mgaussian", penalty="ridge", gamma=gamma, alpha=1e-3, beta=0.0,
+                           dense_intercept=dense)
+        gb = gb0 + d0 / n
+        c = 1.0 if dense else 0.01
+        assert np.allclose(st["g_sum_intercept"], gb, rtol=1e-15)
+        assert np.allclose(st["intercept"], b0 - gamma * (gb * c * m + d0 / n), rtol=1e-14)
+        out[dense] = (st["w"].copy(), st["g_sum"].copy())
+    assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
