@@ -287,3 +287,37 @@ def test_random_wide_dense_rows_in_exact_mode(sa, oracle, seed):
         err = float(np.abs(np.asarray(got) - np.asarray(want)).max() / max(1e-300, np.abs(want).max()))
         assert err < 1e-10 or np.abs(want).max() < 1e-300, (family, K, p, n, penalty, name, err)
     S.close()
+
+
+def test_concurrent_fits_from_threads_equal_the_sequential_ones(sa):
+    # cv_sgdnet fans fits out over threads (one per entry of `devices`, several may share a GPU): the library keeps
+    # per-call state only (per-device kernel attributes, a mutex around the jump polynomials, thread-local error
+    # text).  Exact-mode fits are deterministic, so 24 fits run by 6 threads must equal the same fits run in turn.
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = []
+    for seed in range(24):
+        r = np.random.default_rng(31000 + seed)
+        family = ["gaussian", "binomial", "multinomial", "mgaussian"][seed % 4]
+        n, p = int(r.choice([80, 300])), int(r.choice([4, 30, 120]))
+        sparse = bool(r.random() < 0.5)
+        x = r.standard_normal((n, p)) * (r.random((n, p)) < (0.4 if sparse else 1.0))
+        x[np.arange(n), r.integers(0, p, n)] += 0.7
+        z = x[:, : min(p, 4)] @ r.uniform(-1, 1, (min(p, 4), 3)) + 0.2
+        y = {"gaussian": z[:, 0] + 0.1 * r.standard_normal(n),
+             "binomial": (r.random(n) < 1 / (1 + np.exp(-z[:, 0]))).astype(float),
+             "multinomial": np.argmax(z + r.gumbel(size=z.shape), axis=1).astype(float),
+             "mgaussian": z[:, :2] + 0.1 * r.standard_normal((n, 2))}[family]
+        if family in ("binomial", "multinomial"):
+            y[:3] = [0, 1, 2 if family == "multinomial" else 1]
+        jobs.append((sp.csc_matrix(x) if sparse else x, y, dict(family=family, alpha=0.5, nlambda=6, seed=seed)))
+
+    def run(job):
+        x, y, kw = job
+        f = sa.sgdnet(x, y, **kw)
+        return np.concatenate([np.ravel(b) for b in (f.beta if isinstance(f.beta, list) else [f.beta])]), np.ravel(f.a0), f.npasses
+
+    want = [run(j) for j in jobs]
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        got = list(pool.map(run, jobs))
+    for (b0, a0, n0), (b1, a1, n1) in zip(want, got):
+        assert n0 == n1 and np.array_equal(b0, b1) and np.array_equal(a0, a1)
