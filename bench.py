@@ -211,7 +211,7 @@ def main():
     # N > 1: every rank's draws for all epochs are generated on the host before the timed region
     # (the per-merge-segment layout of sharded ranks is not produced on the device yet).
     pipe = (world == 1 and not force_merge and os.environ.get("SGDNET_BENCH_RESIDENT_STREAM") != "1")
-    gens = int(os.environ.get("SGDNET_RNG_GENERATORS", "0")) or (
+    gens = int(os.environ.get("SGDNET_BENCH_RNG_GENERATORS", "0")) or (
         min(32, max(8, n_local // 300000)) if n_local >= 200000 else 1)
     if V > 1:
         from sgdnet_amd.parallel import shard_bounds as sb

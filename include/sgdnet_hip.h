@@ -32,7 +32,10 @@
 extern "C" {
 #endif
 
-#define SGDNET_ABI_VERSION 1
+/* 2: sgdnet_control carries losses_sink / losses_ctx, sgdnet_set_option exists.  A caller compiled against
+ * another version must not pass its structs: the shim and the Python binding compare sgdnet_abi_version()
+ * with this constant when they load the library. */
+#define SGDNET_ABI_VERSION 2
 
 /* error codes */
 #define SGDNET_OK          0
@@ -141,6 +144,33 @@ typedef struct sgdnet_result {
 int sgdnet_abi_version(void);
 const char* sgdnet_last_error(void);
 int sgdnet_device_count(void);
+
+/* ------------------------------------------------------------------------ */
+/* Process-wide backend options.  These are the ONLY switches that change    */
+/* how sgdnet_fit_* runs a fit; the library reads no environment variable    */
+/* for that (SGDNET_TRACE prints progress to stderr and changes nothing;     */
+/* kernel A/B switches exist only in -DSGDNET_EXPERIMENTS builds).           */
+/*   "virtual_shards"     -1 (default): the driver's rule -- one-response    */
+/*                        batched fits of >= 200 000 samples run as up to 8  */
+/*                        averaged replicas; 0 or 1: never;    */
+/*                        2..8: that many wherever the kernels allow it      */
+/*   "rng_generators"     0 (default): 8..32 generators side by side on R's  */
+/*                        one stream for epochs of >= 200 000 draws, else 1; */
+/*                        1..64: that many                                   */
+/*   "window_eigenvalue"  1 (default): the automatic window of sparse x uses */
+/*                        the largest eigenvalue of X'X/n (power iteration); */
+/*                        0: its diagonal bound only                         */
+/*   "host_setup"         0 (default): standardisation, lambda_max, transpose*/
+/*                        and packing run on the device for sparse x and for */
+/*                        dense x of >= 4e6 elements; 1: host loops          */
+/*   "exact_epoch_blocks" 1 (default): exact mode with the built-in generator*/
+/*                        runs several epochs per launch; 0: one per launch  */
+/* Unknown names and out-of-range values return SGDNET_EINVAL.  Options are  */
+/* read when a fit starts; changing them during a fit on another thread      */
+/* affects later fits only.                                                  */
+/* ------------------------------------------------------------------------ */
+int sgdnet_set_option(const char* name, int value);
+int sgdnet_get_option(const char* name, int* value);
 
 /* replaces _sgdnet_SgdnetSparse (src/RcppExports.cpp:24-34 -> src/sgdnet.cpp:369-375) */
 int sgdnet_fit_sparse(const sgdnet_csc* x, const double* y, int y_cols,

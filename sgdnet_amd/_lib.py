@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("SGDNET_LIB_PATH") or os.path.join(_HERE, "lib", "libs
 
 # every symbol include/sgdnet_hip.h declares
 EXPORTS = [
-    "sgdnet_abi_version", "sgdnet_last_error", "sgdnet_device_count",
+    "sgdnet_abi_version", "sgdnet_last_error", "sgdnet_device_count", "sgdnet_set_option", "sgdnet_get_option",
     "sgdnet_fit_sparse", "sgdnet_fit_dense",
     "sgdnet_rng_seed", "sgdnet_rng_unif", "sgdnet_rng_fill", "sgdnet_rng_jump_poly", "sgdnet_rng_jump",
     "sgdnet_solver_create", "sgdnet_solver_destroy", "sgdnet_solver_set_penalty",
@@ -32,6 +32,7 @@ EXPORTS = [
     "sgdnet_auc_sparse", "sgdnet_auc_dense",
     "sgdnet_solver_rng_open", "sgdnet_solver_rng_next", "sgdnet_solver_rng_done", "sgdnet_solver_rng_close",
 ]
+ABI_VERSION = 2   # include/sgdnet_hip.h: SGDNET_ABI_VERSION
 MEASURES = {"deviance": 0, "mse": 1, "mae": 2, "class": 3, "auc": 4}
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
@@ -115,7 +116,12 @@ def load():
         raise OSError(f"{LIB_PATH} not found: run ./build.sh (or __graft_entry__.build()); "
                       "the SAGA backend has no CPU fallback")
     L = C.CDLL(LIB_PATH)
+    if L.sgdnet_abi_version() != ABI_VERSION:          # the structs below are laid out for this version
+        raise OSError(f"{LIB_PATH} has ABI version {L.sgdnet_abi_version()}, this binding was written for "
+                      f"{ABI_VERSION} (include/sgdnet_hip.h: SGDNET_ABI_VERSION): rebuild with ./build.sh")
     L.sgdnet_last_error.restype = C.c_char_p
+    L.sgdnet_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.sgdnet_get_option.argtypes = [C.c_char_p, C.POINTER(C.c_int)]
     L.sgdnet_rng_unif.restype = C.c_double
     L.sgdnet_solver_delta_len.restype = C.c_int64
     L.sgdnet_solver_destroy.restype = None

@@ -15,9 +15,31 @@
 #define SGD_ABLATE(d, bits) false
 #endif
 
+#include <stdlib.h>
+
 namespace sgdnet {
 
 void set_error(const char* fmt, ...);
+
+// Kernel A/B switches of the experiments behind DESIGN.md 5 (SGDNET_GATHER, SGDNET_LANES8, SGDNET_COMPACT,
+// SGDNET_W_LDS, SGDNET_BINNED, SGDNET_BIN_RANGES, SGDNET_LDS_GRID, SGDNET_EXACT_SMALL / _WIDE, SGDNET_REC_ALIGN):
+// environment variables in -DSGDNET_EXPERIMENTS builds, constants in the shipped library -- a user's
+// environment cannot change which kernel a fit runs.  What a user may tune is sgdnet_set_option
+// (include/sgdnet_hip.h).
+#ifdef SGDNET_EXPERIMENTS
+inline int exp_env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+inline const char* exp_env_str(const char* name) { return getenv(name); }
+#else
+inline int exp_env_int(const char*, int dflt) { return dflt; }
+inline const char* exp_env_str(const char*) { return nullptr; }
+#endif
+
+// sgdnet_set_option values (solver.cpp)
+enum Option { kOptVirtualShards = 0, kOptRngGenerators, kOptWindowEigenvalue, kOptHostSetup, kOptExactEpochBlocks, kOptCount };
+int option(Option o);
 
 #define SGD_HIP_TRY(expr)                                                              \
   do {                                                                                 \
@@ -74,9 +96,14 @@ struct SagaDev {
   int rec_cap;        // entries held by the main record
   int rec_val_off;    // byte offset of val[] inside a record
   // compact two-plane records of the K == 1 LDS gather (saga_batched.hip) or nullptr
-  const char* cP;     // n x 128 B: response + first 12 entries, 16-bit feature ids
-  const char* cQ;     // n x 128 B: entries 12..23 of the rows that have them
-  const uint32_t* clong;  // bitmap of the rows with more than 12 entries
+  char* cP;           // n x 128 B: first cE entries (16-bit feature ids), response, gradient memory
+  const char* cQ;     // n x 128 B: entries cE .. cE + 11 of the rows that have them
+  const uint32_t* cmeta;  // 2 bits per sample: row longer than cE entries, response != 0
+  int cE;             // entries in plane P: 12 (binomial: the response rides in the tagged draw) or 11
+  int m_rec;          // one-response sparse fits: the gradient memory is inside the records (cP + 120), not in M
+  char* m_base;       // ... its address for sample s is m_base + s * m_stride: (M, 8) or (cP + 120, 128)
+  int m_stride;
+  uint32_t* tstream;  // tagged draws of the current epoch: sample | long row | response | first occurrence in its batch
   // solver state (K fastest, like the reference's ArrayXXd K x p / K x n)
   double* w;
   double* G;      // g_sum
@@ -121,6 +148,7 @@ struct LamParams {
   int64_t m_full, m_tail;
   // epoch bookkeeping for graph replays
   int64_t stream_base;   // offset of the current epoch in the resident stream
+  int64_t tstream_base;  // ... and of its tagged draws in SagaDev::tstream (0 unless the sample-order pipeline tagged them ahead)
   int64_t draws_per_epoch;
   int batch_seq;         // running batch id (claims)
   // ConvergenceCheck scratch: bit patterns of max|dw| and max|w|
@@ -173,7 +201,13 @@ int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st);
 int launch_vs_cw(const SagaDev& d, hipStream_t st);
 bool vs_eligible(const SagaDev& d, int m);
 bool compact_eligible(const SagaDev& d);
-int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* longmap, hipStream_t st);
+int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* meta, hipStream_t st);
+int compact_entries(const SagaDev& d);
+int launch_m_move(const SagaDev& d, int to_record, hipStream_t st);
+// lam != nullptr: the epoch's offsets are read on the device (captured epoch graphs); else the explicit ones
+int launch_stream_tag(const SagaDev& d, const LamParams* lam, int64_t m, int64_t draws, hipStream_t st,
+                      int64_t stream_off = 0, int64_t tstream_off = 0);
+bool tagged_gather(const SagaDev& d, int m);
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
 int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st);
@@ -184,6 +218,7 @@ int lds_target_grid(const SagaDev& d);   // workgroups of the LDS-privatised gat
 bool binned_active(const SagaDev& d, int m);
 int launch_col_count(const SagaDev& d, int64_t nnz, unsigned* counts, hipStream_t st);
 int launch_wpad_refresh(const SagaDev& d, hipStream_t st);
+int launch_range_moment(const SagaDev& d, const uint16_t* feat_range, unsigned long long* sumsq, int R, hipStream_t st);
 size_t binned_max_range_features(int K);
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,
@@ -193,6 +228,7 @@ int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_sa
 bool mt_jump_poly(uint64_t J, uint32_t* out624);
 void mt_jump_host(const sgdnet_rng* in, const uint32_t* poly624, sgdnet_rng* out);
 int launch_rng_jump(const uint32_t* state_in, uint32_t* state_out, const uint32_t* poly_dev, int gens,
-                    hipStream_t st);
+                    hipStream_t st, int max_wgs = 0);
+int rng_generators_per_workgroup();
 
 }  // namespace sgdnet

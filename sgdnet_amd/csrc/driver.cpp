@@ -568,10 +568,10 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     if (rcd) return rcd;
   } else if (X.dev) {
     // transpose, row norms and record packing on the device; y rides inside the records
-    static const int align = [] { const char* e = getenv("SGDNET_REC_ALIGN"); return e ? atoi(e) : 128; }();
+    static const int align = exp_env_int("SGDNET_REC_ALIGN", 128);
     int rcd = device_setup_finish(*X.dev, yt.data(), Ky, ctl->standardize ? 1 : 0, align, X.st, &norm_max);
     if (rcd) return rcd;
-    if (ctl->mode != SGDNET_MODE_EXACT && ctl->batch <= 0 && !getenv("SGDNET_NO_LMAX")) {   // the automatic window needs L_F itself
+    if (ctl->mode != SGDNET_MODE_EXACT && ctl->batch <= 0 && option(kOptWindowEigenvalue)) {   // the automatic window needs L_F itself
       double lmax = 0.0;
       rcd = device_gram_lmax(*X.dev, ctl->standardize ? 1 : 0, X.st, &lmax);
       if (rcd) return rcd;
@@ -684,13 +684,20 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
 
   rc = sgdnet_solver_set_state(S, 1, b0.data());
   if (rc) return rc;
+  if (mode == SGDNET_MODE_BATCHED && K > 16 && !solver_batched_available(S, batch)) {
+    // 17..64 classes have one batched form, the binned one, and it needs feature ranges (at most 2048 of them)
+    if (ctl->mode == SGDNET_MODE_BATCHED && getenv("SGDNET_TRACE"))
+      fprintf(stderr, "[sgdnet]   %d classes on %lld features: no batched form, exact iteration\n", K, (long long)p);
+    mode = SGDNET_MODE_EXACT;
+    batch = 0;
+  }
 
   DrawSource draws(ctl);
   int vshards = 0;
   // Virtual shards (include/sgdnet_hip.h): with enough samples per feature the batched fit of
   // one response runs as up to 8 locally normalised replicas over sample ranges, averaged on the
   // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
-  // at the benchmark shapes.  SGDNET_VSHARDS=0 switches it off, =V forces V.
+  // at the benchmark shapes.  sgdnet_set_option("virtual_shards", 0) switches it off, V forces V.
   // The shard kernels read a per-shard layout of the sample order: the built-in generator and
   // the unif callback produce it (DrawSource::fill), an explicit sample_stream cannot.
   if (mode == SGDNET_MODE_BATCHED && K == 1 && draws.shardable()) {
@@ -700,7 +707,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // or not at all when its replicas are averaged)
     if (n >= 200000)
       while (V < 8 && (int64_t)(2 * V) * 100 * p <= n) V *= 2;
-    if (const char* e = getenv("SGDNET_VSHARDS")) V = atoi(e);
+    if (option(kOptVirtualShards) >= 0) V = option(kOptVirtualShards);
     if (V >= 2 && V <= 8) {
       rc = sgdnet_solver_set_virtual_shards(S, V);
       if (rc && rc != SGDNET_EUNSUPPORTED) return rc;
@@ -716,7 +723,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   // longer one launch + one host round trip per epoch.  The stream is consumed contiguously across
   // epochs and lambdas, so the generator ends exactly where the reference's would: the final state is
   // the block's start state stepped by the draws that were used.
-  const bool exact_blocks = draws.internal() && mode == SGDNET_MODE_EXACT && !ctl->debug && !getenv("SGDNET_EXACT_PER_EPOCH");
+  const bool exact_blocks = draws.internal() && mode == SGDNET_MODE_EXACT && !ctl->debug && option(kOptExactEpochBlocks);
   const bool pipe = draws.internal() && !exact_blocks;
   struct {
     sgdnet_rng start;
@@ -738,11 +745,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // mode keep a single generator.  SGDNET_RNG_GENERATORS overrides.
     int gens = 1;
     if (mode == SGDNET_MODE_BATCHED) {
-      const char* e = getenv("SGDNET_RNG_GENERATORS");
+      const int forced = option(kOptRngGenerators);
       // a generator's workgroup cannot share a CU with a gather workgroup (LDS and registers are
       // taken), so a long-running generator costs every overlapping gather launch a second round:
       // C4 epochs 1.07 / 0.93 / 0.86 ms with 8 / 16 / 32 generators (0.85 with the stream resident)
-      gens = e ? atoi(e) : (n >= 200000 ? (int)std::min<int64_t>(32, std::max<int64_t>(8, n / 300000)) : 1);
+      gens = forced > 0 ? forced : (n >= 200000 ? (int)std::min<int64_t>(32, std::max<int64_t>(8, n / 300000)) : 1);
     }
     rc = solver_rng_open(S, &draws.rng, n, gens);
     if (rc) return rc;
@@ -811,6 +818,27 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       if (ctl->debug && losses.size() < (size_t)epochs + 1) losses.resize(std::max<size_t>(64, 2 * losses.size()));
       rc = sgdnet_solver_run(S, mode, batch, stream_off, n, want_epochs, ctl->tol, &ran, &converged,
                              ctl->debug ? losses.data() + epochs : nullptr);
+      if (rc == SGDNET_EUNSUPPORTED && solver_bin_overflowed(S)) {
+        // binned form: a feature range got more entries in one batch than its bin holds, the epoch is void.
+        // More room (or, in the end, the atomic form) and this lambda again from the null model; with more
+        // than 16 classes and no room left there is no batched form: mode = auto then fits in exact mode.
+        if (pipe) {
+          int rcr = solver_rng_release(S);
+          if (rcr) return rcr;
+        }
+        rc = solver_grow_bins(S);
+        if (rc) {
+          t_batched_diverged = true;
+          return rc;
+        }
+        if (getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet]   lambda %d: a bin overflowed -> more room, again\n", li);
+        rc = solver_reset_state(S, b0.data());
+        if (rc) return rc;
+        worse = 0;
+        best_ratio = HUGE_VAL;
+        converged = 0;
+        continue;
+      }
       if (rc) return rc;
       if (exact_blocks) {
         blk.used += (int64_t)ran * n;
@@ -1045,7 +1073,7 @@ static int fit_sparse_impl(const sgdnet_csc* x, const double* y, int y_cols, con
       return SGDNET_EINVAL;
     }
   }
-  if (!getenv("SGDNET_HOST_SETUP")) {
+  if (!option(kOptHostSetup)) {
     // default: the per-fit O(nnz) passes run on the device (setup_device.hip)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -1140,7 +1168,7 @@ static int fit_dense_impl(const double* x, int64_t n, int64_t p, const double* y
   X.sparse = false;
   X.n = n;
   X.p = p;
-  if (n * p >= kDenseDeviceSetupElems && !getenv("SGDNET_HOST_SETUP")) {
+  if (n * p >= kDenseDeviceSetupElems && !option(kOptHostSetup)) {
     // large dense x: statistics, standardisation, lambda_max products, transpose and row norms on the
     // device (dense_setup_*), no host pass over the n * p doubles beyond the one upload
     int ndev = 0;

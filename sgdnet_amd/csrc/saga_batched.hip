@@ -121,6 +121,18 @@ __device__ __forceinline__ void cw_clear_next(const SagaDev& d, int batch_id) {
 //
 // At z = 10 a draw is one 256-B record = 2 requests (was: 2 row pointers + y + idx + val ~ 6).
 // --------------------------------------------------------------------------
+// compact records (below): 128 B per sample, the gradient memory of a one-response fit in the last 8
+constexpr int kCStride = 128;
+constexpr int kCMOff = 120;
+
+__device__ __forceinline__ double* m_slot(const SagaDev& d, int64_t s) {
+  // gradient memory of sample s for the one-response sparse kernels: inside the compact record while the
+  // solver keeps it there (solver.cpp: m_to_record / m_to_array), else the K x n array
+  // (base and stride are kept by the host: a select between the two addresses in front of the atomic
+  //  exchange sends this compiler's instcombine into a segmentation fault)
+  return reinterpret_cast<double*>(d.m_base + (size_t)s * (size_t)d.m_stride);
+}
+
 constexpr int kOvfStride = 256;
 constexpr int kOvfCap = 20;
 
@@ -224,7 +236,7 @@ __device__ __forceinline__ void saga_draw(const SagaDev& d, const uint32_t s, co
       g0 = lp[0] - y0;
     double gcv = 0.0;
     if (gl == 0) {
-      const double old = __hip_atomic_exchange(d.M + s, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double old = __hip_atomic_exchange(m_slot(d, s), g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       gcv = g0 - old;
     }
     gc[0] = __shfl(gcv, 0, kGroup);
@@ -472,7 +484,7 @@ __device__ __forceinline__ double k1_lanes8_draws(const SagaDev& d, const uint32
     if (is_owner && v_own) {
       // claim, read and update in ONE returning atomic: a repeated draw of the batch reads back
       // the value just stored (same snapshot, same g0), so its gc is exactly 0
-      const double old = __hip_atomic_exchange(d.M + s_this, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const double old = __hip_atomic_exchange(m_slot(d, s_this), g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       gcp = g0 - old;
     }
 #pragma unroll
@@ -497,64 +509,162 @@ __device__ __forceinline__ double k1_lanes8_draws(const SagaDev& d, const uint32
 }
 
 // --------------------------------------------------------------------------
-// Compact records (K == 1, p <= 65536): two planes of n x 128 B.  Plane P holds the response
-// and the first 12 entries of every row with 16-bit feature ids
-//     [ y : 8 | id[12] : 24 | val[12] : 96 ]
-// and plane Q, touched only for rows with more than 12 entries (21 % at 10 non-zeros per row),
-// holds the next 12:
-//     [ nnz : 4 | - : 4 | id[12] : 24 | val[12] : 96 ]
-// Entries 24.. of a row are read from the sample-major CSR arrays.  A draw moves 128 B for four
-// rows out of five instead of 256 B for every row -- 155 B per draw at z = 10, next to the
-// 152 algorithmic bytes.  Whether a row is long must be known BEFORE its record is requested
-// (asking the record would be a second dependent round trip), so a bitmap of the long rows
-// (n bits) is looked up one pass ahead, for sample ids that were requested two passes ahead.
-// Same lane mapping as k1_lanes8_draws: lanes 0..5 of the 8-lane group hold P's twelve entries,
-// lanes 6..7 the first four of Q; entries 16.. take the tail path.
+// Compact records (K == 1, p <= 65536) with the gradient memory inside, and a TAGGED sample order.
+//
+// Round 2's gather read a draw's record and then claimed / read / updated the sample's gradient memory
+// with one returning device-scope exchange on a separate 80 MB table: two random memory operations per
+// draw, the second one at the end of the dependent chain ids -> record -> x.w -> exp -> exchange.  What
+// the memory system charges for that was measured without any compute (scripts/microbench/
+// gather_patterns.hip, profiles/r03b_*): random 128-B lines 24 us per 2^20 draws, line + dependent
+// exchange 54 us, line + independent 8-byte load from a second table 45 us (ANY second random access costs
+// what the line costs: the fabric serves ~45 G requests/s whatever their size), line + an 8-byte store
+// INTO the line just read 43-49 us.  So the gradient memory of sample s now lives in the last 8 bytes of
+// the sample's own line (the read is free, the update is a plain fire-and-forget store), and what the
+// exchange also did -- give exactly one of a batch's repeated draws of a sample the change g - old, the
+// others 0 -- is decided before the gather runs: stream_tag_kernel marks the first occurrence of every
+// sample inside each batch (the sample order of an epoch exists before the epoch starts) and folds the
+// other per-sample bits the gather used to look up into the same 32-bit word.
+//
+//   plane P, 128 B per sample:  [ val[E] : 8 E | id[E] : 2 E (16-bit) | pad | y : 8 at 112 (E = 11) | M : 8 at 120 ]
+//       E = 12 for binomial fits (the 0/1 response rides in the tagged draw), 11 otherwise
+//   plane Q, 128 B per sample, touched only for rows with more than E entries (21 % / 30 % at 10 per row):
+//       [ nnz : 4 | - : 4 | id[12] : 24 | val[12] : 96 ]   entries E .. E + 11
+//   entries E + 12 .. of a row are read from the sample-major CSR arrays
+//   meta, 2 bits per sample: bit 0 = the row has more than E entries, bit 1 = y != 0 (binomial)
+//   tagged draw: [ 31 long row | 30 first occurrence in its batch | 29 y | 28..0 sample ]
+//
+// Lane mapping as before: lanes 0..5 of the 8-lane group hold P's entries 2 slot, 2 slot + 1, lanes 6..7
+// the first four of Q; entries E + 4 .. take the tail path.
 // --------------------------------------------------------------------------
-constexpr int kCStride = 128;
-constexpr int kCP = 12;               // entries in plane P (and in plane Q)
+constexpr int kCQ = 12;               // entries in plane Q
+constexpr int kCYOff = 112;           // response inside plane P (E = 11)
 constexpr uint32_t kLongBit = 0x80000000u;
+constexpr uint32_t kFirstBit = 0x40000000u;
+constexpr uint32_t kYBit = 0x20000000u;
+constexpr uint32_t kIdMask = 0x1fffffffu;
 
 __global__ __launch_bounds__(256) void pack_compact_kernel(const int64_t* ptr, const int32_t* idx,
-                                                           const double* val, const double* y, int64_t n,
-                                                           char* P, char* Q, uint32_t* longmap) {
+                                                           const double* val, const double* y, int64_t n, int E,
+                                                           int y_in_tag, char* P, char* Q, uint32_t* meta) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     const int64_t q0 = ptr[i];
     const int nnz = (int)(ptr[i + 1] - q0);
     char* pb = P + (size_t)i * kCStride;
-    *reinterpret_cast<double*>(pb) = y[i];
-    uint16_t* pid = reinterpret_cast<uint16_t*>(pb + 8);
-    double* pv = reinterpret_cast<double*>(pb + 32);
-    for (int e = 0; e < kCP; ++e) {
-      pid[e] = e < nnz ? (uint16_t)idx[q0 + e] : (uint16_t)0;
-      pv[e] = e < nnz ? val[q0 + e] : 0.0;
-    }
-    if (nnz > kCP) {
+    double* pv = reinterpret_cast<double*>(pb);
+    uint16_t* pid = reinterpret_cast<uint16_t*>(pb + 8 * E);
+    for (int e = 0; e < E; ++e) pv[e] = e < nnz ? val[q0 + e] : 0.0;
+    for (int e = 0; e < (kCMOff - 8 * E) / 2; ++e) pid[e] = e < E && e < nnz ? (uint16_t)idx[q0 + e] : (uint16_t)0;
+    if (!y_in_tag) *reinterpret_cast<double*>(pb + kCYOff) = y[i];
+    *reinterpret_cast<double*>(pb + kCMOff) = 0.0;
+    uint32_t bits = 0u;
+    if (nnz > E) {
       char* qb = Q + (size_t)i * kCStride;
       reinterpret_cast<int*>(qb)[0] = nnz;
       reinterpret_cast<int*>(qb)[1] = 0;
       uint16_t* qid = reinterpret_cast<uint16_t*>(qb + 8);
       double* qv = reinterpret_cast<double*>(qb + 32);
-      for (int e = 0; e < kCP; ++e) {
-        qid[e] = kCP + e < nnz ? (uint16_t)idx[q0 + kCP + e] : (uint16_t)0;
-        qv[e] = kCP + e < nnz ? val[q0 + kCP + e] : 0.0;
+      for (int e = 0; e < kCQ; ++e) {
+        qid[e] = E + e < nnz ? (uint16_t)idx[q0 + E + e] : (uint16_t)0;
+        qv[e] = E + e < nnz ? val[q0 + E + e] : 0.0;
       }
-      atomicOr(longmap + (i >> 5), 1u << (i & 31));
+      bits |= 1u;
+    }
+    if (y_in_tag && y[i] != 0.0) bits |= 2u;
+    if (bits) atomicOr(meta + (i >> 4), bits << (2 * (i & 15)));
+  }
+}
+
+// gradient memory between the K x n array and the records (a mode change, or the host reading / writing it)
+__global__ __launch_bounds__(256) void m_move_kernel(SagaDev d, int to_record) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (int64_t)gridDim.x * 256) {
+    double* r = reinterpret_cast<double*>(d.cP + (size_t)i * kCStride + kCMOff);
+    if (to_record) *r = d.M[i];
+    else d.M[i] = *r;
+  }
+}
+
+// entries E + 4 .. of a long row
+template <class F>
+__device__ __forceinline__ void row_tail_compact(const SagaDev& d, uint32_t sid, int nnz, int gl, int E, F f) {
+  const char* qb = d.cQ + (size_t)sid * kCStride;
+  for (int e = E + 4 + gl; e < nnz; e += kLanes8) {
+    if (e < E + kCQ) {
+      f((int64_t) reinterpret_cast<const uint16_t*>(qb + 8)[e - E],
+        reinterpret_cast<const double*>(qb + 32)[e - E]);
+    } else {
+      const int64_t q0 = d.ptr[sid];
+      f((int64_t)d.idx[q0 + e], d.val[q0 + e]);
     }
   }
 }
 
-// entries 16.. of a long row
-template <class F>
-__device__ __forceinline__ void row_tail_compact(const SagaDev& d, uint32_t sid, int nnz, int gl, F f) {
-  const char* qb = d.cQ + (size_t)sid * kCStride;
-  for (int e = kInReg8 + gl; e < nnz; e += kLanes8) {
-    if (e < 2 * kCP) {
-      f((int64_t) reinterpret_cast<const uint16_t*>(qb + 8)[e - kCP],
-        reinterpret_cast<const double*>(qb + 32)[e - kCP]);
-    } else {
-      const int64_t q0 = d.ptr[sid];
-      f((int64_t)d.idx[q0 + e], d.val[q0 + e]);
+// --------------------------------------------------------------------------
+// Tagging the sample order of one epoch (or merge segment): tstream[i] = draw | long | y | first.
+// "First occurrence inside its batch" needs a set over the samples a batch can draw: a bitmap in LDS, one
+// bit per sample of a SUB-RANGE of at most kTagWords * 32 = 1 277 952 samples (a virtual shard of C4 is
+// 1 250 000).  Workgroup (sub, k, v) walks batch k of shard v and handles the draws that fall into its
+// sub-range: ds_or_rtn on the sample's bit -- whoever finds the bit clear is the first -- then writes the
+// tagged word.  Which of several equal draws wins is decided by the hardware's order, and does not matter:
+// they see the same snapshot, compute the same gradient, and exactly one of them carries the change.
+// 128 draws per thread at C4; ~80 workgroups per epoch.
+// --------------------------------------------------------------------------
+constexpr int kTagBlock = 1024;
+constexpr int kTagWords = 39936;      // 159 744 B of LDS
+
+__global__ __launch_bounds__(kTagBlock) void stream_tag_kernel(SagaDev d, const LamParams* lamp, int64_t m,
+                                                               int64_t dps, int64_t stream_off, int64_t tstream_off) {
+  extern __shared__ uint32_t bm[];
+  const int sub = blockIdx.x, k = blockIdx.y, v = blockIdx.z;
+  int64_t lo = 0, size = d.n;
+  if (d.V > 1) {
+    double lo_d = 0.0;
+    for (int q = 0; q < v; ++q) lo_d += d.v_size[q];
+    lo = (int64_t)lo_d;
+    size = (int64_t)d.v_size[v];
+  }
+  const int64_t cap = (int64_t)kTagWords * 32;
+  const int64_t r_lo = lo + (int64_t)sub * cap;
+  const int64_t r_hi = r_lo + cap < lo + size ? r_lo + cap : lo + size;
+  const int words = (int)((r_hi - r_lo + 31) >> 5);
+  for (int i = threadIdx.x; i < words; i += kTagBlock) bm[i] = 0u;
+  __syncthreads();
+  const int64_t b0 = (int64_t)k * m;
+  const int64_t cnt = dps - b0 < m ? dps - b0 : m;
+  const int64_t rel = (int64_t)v * dps + b0;
+  if (lamp) {
+    stream_off = lamp->stream_base;
+    tstream_off = lamp->tstream_base;
+  }
+  const uint32_t* __restrict__ src = d.stream + stream_off + rel;
+  uint32_t* __restrict__ dst = d.tstream + tstream_off + rel;
+  const uint32_t* __restrict__ meta = d.cmeta;
+  // kTagU draws per thread and round: their ids, then their meta words, are requested together (one draw
+  // at a time the loop is a chain of two round trips per draw: 213 us per epoch at C4 instead of ~30)
+  constexpr int kTagU = 16;
+  for (int64_t i0 = threadIdx.x; i0 < cnt; i0 += (int64_t)kTagBlock * kTagU) {
+    uint32_t sv[kTagU], mt[kTagU];
+    bool in[kTagU];
+#pragma unroll
+    for (int u = 0; u < kTagU; ++u) {
+      const int64_t i = i0 + (int64_t)u * kTagBlock;
+      sv[u] = i < cnt ? src[i] : 0xffffffffu;
+    }
+#pragma unroll
+    for (int u = 0; u < kTagU; ++u) {
+      in[u] = (int64_t)sv[u] >= r_lo && (int64_t)sv[u] < r_hi;
+      mt[u] = in[u] ? meta[sv[u] >> 4] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kTagU; ++u) {
+      if (in[u]) {
+        const uint32_t s = sv[u];
+        const uint32_t o = (uint32_t)((int64_t)s - r_lo);
+        const uint32_t bit = 1u << (o & 31);
+        const uint32_t old = __hip_atomic_fetch_or(bm + (o >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t mb = (mt[u] >> (2 * (s & 15))) & 3u;
+        dst[i0 + (int64_t)u * kTagBlock] =
+            s | ((mb & 1u) ? kLongBit : 0u) | ((mb & 2u) ? kYBit : 0u) | ((old & bit) ? 0u : kFirstBit);
+      }
     }
   }
 }
@@ -596,18 +706,25 @@ struct TicketSource {
   }
 };
 
-__device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint32_t* sp, int m, int blk, int nblk,
-                                                    int* ticket_counter, double b0, const double* wv, double* Dl) {
+// sp: the TAGGED draws of this workgroup's shard-batch (stream_tag_kernel)
+__device__ __forceinline__ double k1_lanes8_tagged(const SagaDev& d, const uint32_t* sp, int m, int blk, int nblk,
+                                                   int* ticket_counter, double b0, const double* wv, double* Dl) {
   typedef double dpair_t __attribute__((ext_vector_type(2)));
   constexpr int U = 4;
+  const int E = d.cE;                           // entries in plane P: 12 (response in the tag) or 11
+  const int in_reg = E + 4;                     // entries of a row held in registers
+  const bool y_in_tag = E == 12;
   const int gl = threadIdx.x & (kLanes8 - 1);
   const int g = (threadIdx.x & 63) >> 3;        // group inside the wavefront
   const int q = gl >> 1;
   const bool is_owner = (gl & 1) == 0;
   const bool in_p = gl < 6;                     // this lane's two entries come from plane P
-  const char* plane = in_p ? d.cP : d.cQ;
   const int slot = in_p ? gl : gl - 6;
-  const uint32_t* lm = d.clong;
+  char* const P = d.cP;
+  const char* plane = in_p ? d.cP : d.cQ;
+  const int id_off = in_p ? 8 * E + 4 * slot : 8 + 4 * slot;
+  const int v_off = in_p ? 16 * slot : 32 + 16 * slot;
+  const bool half = in_p && slot == 5 && E == 11;   // entry 11 of plane P does not exist: the bytes are ids and pad
   double gct = 0.0;
   TicketSource tk;
   {
@@ -621,22 +738,31 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
   // this lane's own draw of the pass whose ticket is `base` (positions past the end stand in with
   // the ticket's first draw and are discarded)
   auto own_pos = [&](int base) { return base + U * g + q < m ? base + U * g + q : base; };
-  auto tagged = [&](uint32_t sid) { return sid | (((lm[sid >> 5] >> (sid & 31)) & 1u) ? kLongBit : 0u); };
   int b_cur = tk.next();
   if (b_cur >= m) return 0.0;
   int b_nxt = tk.next();
-  int b_nn = tk.next();
   uint32_t s_cur = sp[own_pos(b_cur)];
   uint32_t s_nxt = b_nxt < m ? sp[own_pos(b_nxt)] : 0u;
-  s_cur = tagged(s_cur);
   while (b_cur < m) {
     const bool v_own = b_cur + U * g + q < m;
     uint32_t su[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) su[u] = (uint32_t)__shfl((int)s_cur, 2 * u, kLanes8);
-    const uint32_t s_this = s_cur & ~kLongBit;
+    const uint32_t s_this = s_cur & kIdMask;
     const bool long_own = (s_cur & kLongBit) != 0;
-    const double y_own = *reinterpret_cast<const double*>(d.cP + (size_t)s_this * kCStride);
+    const bool first_own = (s_cur & kFirstBit) != 0;
+    // the owner's header: old gradient (and the response) from the line the group's entry loads fetch
+    char* const own_line = P + (size_t)s_this * kCStride;
+    double m_old = 0.0, y_own = (s_cur & kYBit) ? 1.0 : 0.0;
+    if (is_owner) {
+      if (y_in_tag) {
+        m_old = *reinterpret_cast<const double*>(own_line + kCMOff);
+      } else {
+        const dpair_t h = *reinterpret_cast<const dpair_t*>(own_line + kCYOff);
+        y_own = h.x;
+        m_old = h.y;
+      }
+    }
     int nnz_own = 0;
     if (long_own) nnz_own = *reinterpret_cast<const int*>(d.cQ + (size_t)s_this * kCStride);
     uint32_t jf[U];
@@ -644,31 +770,37 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const bool on = in_p || (su[u] & kLongBit) != 0;
-      const char* base = plane + (size_t)(su[u] & ~kLongBit) * kCStride;
+      const char* base = plane + (size_t)(su[u] & kIdMask) * kCStride;
       jf[u] = 0u;
       vf[u] = dpair_t{0.0, 0.0};
       if (on) {
-        jf[u] = *reinterpret_cast<const uint32_t*>(base + 8 + 4 * slot);
-        vf[u] = *reinterpret_cast<const dpair_t*>(base + 32 + 16 * slot);
+        jf[u] = *reinterpret_cast<const uint32_t*>(base + id_off);
+        vf[u] = *reinterpret_cast<const dpair_t*>(base + v_off);
       }
     }
-    // sample ids two passes ahead, long-row bits one pass ahead
-    const int b_n3 = b_nn < m ? tk.next() : m;
+    // tagged draws of the pass after the next one: requested before this pass's records are waited for
+    const int b_nn = b_nxt < m ? tk.next() : m;
     uint32_t s_nn = 0u;
     if (b_nn < m) s_nn = sp[own_pos(b_nn)];
-    if (b_nxt < m) s_nxt = tagged(s_nxt);
+    if (half) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        vf[u].y = 0.0;
+        jf[u] &= 0xffffu;
+      }
+    }
     double acc[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) acc[u] = vf[u].x * wv[jf[u] & 0xffffu] + vf[u].y * wv[jf[u] >> 16];
-    const bool own_tail = v_own && nnz_own > kInReg8;
+    const bool own_tail = v_own && nnz_own > in_reg;
     const bool any_tail = __ballot(own_tail) != 0;
     if (any_tail) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int nz = __shfl(own_tail ? nnz_own : 0, 2 * u, kLanes8);
-        if (nz > kInReg8) {
+        if (nz > in_reg) {
           double a = 0.0;
-          row_tail_compact(d, su[u] & ~kLongBit, nz, gl, [&](int64_t j, double v) { a += v * wv[j]; });
+          row_tail_compact(d, su[u] & kIdMask, nz, gl, E, [&](int64_t j, double v) { a += v * wv[j]; });
           acc[u] += a;
         }
       }
@@ -681,9 +813,11 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
     const double lp = t + b0;
     const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y_own - 1.0 / (1.0 + exp(lp)) : lp - y_own;
     double gcp = 0.0;
-    if (is_owner && v_own) {
-      const double old = __hip_atomic_exchange(d.M + s_this, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      gcp = g0 - old;
+    if (is_owner && v_own && first_own) {
+      // the batch's one carrier of this sample's change (src/saga-sparse.h:281-282); its repeats, marked
+      // by the tag, change nothing and write nothing (they would store the same g0)
+      gcp = g0 - m_old;
+      *reinterpret_cast<double*>(own_line + kCMOff) = g0;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -693,8 +827,8 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
         if (vf[u].y != 0.0) scatter_add<true>(Dl + (jf[u] >> 16), vf[u].y * gc);
         if (any_tail) {
           const int nz = __shfl(own_tail ? nnz_own : 0, 2 * u, kLanes8);
-          if (nz > kInReg8)
-            row_tail_compact(d, su[u] & ~kLongBit, nz, gl,
+          if (nz > in_reg)
+            row_tail_compact(d, su[u] & kIdMask, nz, gl, E,
                              [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
         }
       }
@@ -704,7 +838,6 @@ __device__ __forceinline__ double k1_lanes8_compact(const SagaDev& d, const uint
     s_nxt = s_nn;
     b_cur = b_nxt;
     b_nxt = b_nn;
-    b_nn = b_n3;
   }
   return gct;
 }
@@ -853,7 +986,7 @@ struct K1Draws {
       } else {
         // claim, read and update in ONE returning atomic: a repeated draw of the batch reads
         // back the value just stored (same snapshot, same g0), so its gc is exactly 0
-        const double old = __hip_atomic_exchange(d.M + s_sel, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double old = __hip_atomic_exchange(m_slot(d, s_sel), g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         gcp = g0 - old;
       }
     }
@@ -966,9 +1099,10 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     const double* wv = kWLds ? Dl + KP + (KP & 1) : d.w;
     const uint32_t* sp = d.stream + t0;
     if constexpr (kLanes == kLanes8) {
-      if (d.cP)
-        gct[0] = k1_lanes8_compact(d, sp, m, vblk, kVS ? d.v_bps : (int)gridDim.x, &ticket_counter, bk[0], wv,
-                                   Dl);
+      if (d.cP)    // tagged draws of this epoch (stream_tag_kernel), positions relative to the epoch's start
+        gct[0] = k1_lanes8_tagged(d, d.tstream + lamp->tstream_base + (t0 - lamp->stream_base), m, vblk,
+                                  kVS ? d.v_bps : (int)gridDim.x,
+                                  &ticket_counter, bk[0], wv, Dl);
       else
         gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
     } else if (lo + group < hi) {
@@ -1944,6 +2078,41 @@ __global__ __launch_bounds__(256) void wpad_refresh_kernel(const double* w, doub
   }
 }
 
+// Second moment of the entries one sample sends to a feature range: sumsq[r] = sum_i c_ir^2 with c_ir the
+// non-zeros of sample i inside range r.  A batch of m uniformly drawn samples sends range r a sum of m such
+// counts -- mean m * mass_r / n, variance <= m * sumsq[r] / n -- and that, not a Poisson model of independent
+// entries, is what the bins have to hold: rows that put 16 entries into one range (block-structured x)
+// arrive 16 at a time.  Feature ids ascend inside a row and ranges are contiguous, so a row is a few runs.
+__global__ __launch_bounds__(256) void range_moment_kernel(const int64_t* ptr, const int32_t* idx, int64_t n,
+                                                           const uint16_t* feat_range, unsigned long long* sumsq) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const int64_t q1 = ptr[i + 1];
+    int cur = -1;
+    unsigned long long c = 0;
+    for (int64_t q = ptr[i]; q < q1; ++q) {
+      const int r = feat_range[idx[q]];
+      if (r != cur) {
+        if (c) atomicAdd(sumsq + cur, c * c);
+        cur = r;
+        c = 0;
+      }
+      ++c;
+    }
+    if (c) atomicAdd(sumsq + cur, c * c);
+  }
+}
+
+int launch_range_moment(const SagaDev& d, const uint16_t* feat_range, unsigned long long* sumsq, int R,
+                        hipStream_t st) {
+  SGD_HIP_TRY(hipMemsetAsync(sumsq, 0, sizeof(unsigned long long) * (size_t)R, st));
+  int64_t grid = (d.n + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(range_moment_kernel, dim3((unsigned)grid), dim3(256), 0, st, d.ptr, d.idx, d.n, feat_range, sumsq);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
 // the padded copy of w the binned gather reads: refreshed at the start of every epoch (w may have
 // been set from the host, merged across GPUs or advanced by an exact-mode run in between)
 int launch_wpad_refresh(const SagaDev& d, hipStream_t st) {
@@ -2361,10 +2530,7 @@ int batched_max_classes() { return 64; }   // 17..64: sparse x only (binned form
 // a gather launch of 256 workgroups would otherwise wait for them and run a second round (C4: 930
 // epochs/s with 256 + 32, 1055 with 224 + 32).  SGDNET_LDS_GRID overrides (experiments).
 int lds_target_grid(const SagaDev& d) {
-  static const int forced = [] {
-    const char* e = getenv("SGDNET_LDS_GRID");
-    return e ? atoi(e) : 0;
-  }();
+  static const int forced = exp_env_int("SGDNET_LDS_GRID", 0);
   if (forced > 0) return forced;
   const int g = 256 - d.cu_reserve;
   return g < 64 ? 64 : g;
@@ -2392,7 +2558,7 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
   GatherPlan g{};
   const size_t table = sizeof(double) * (size_t)d.K * (size_t)d.p;
   static const int force = [] {
-    const char* e = getenv("SGDNET_GATHER");   // "lds" | "global": experiments only
+    const char* e = exp_env_str("SGDNET_GATHER");   // "lds" | "global": experiments only
     return !e ? 0 : (e[0] == 'l' ? 1 : 2);
   }();
   const int target_grid = lds_target_grid(d);
@@ -2447,7 +2613,7 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     g.draws_per_block = dpb;
     g.grid = (m + dpb - 1) / dpb;
     g.lds_bytes = table;
-    static const bool w_lds_on = [] { const char* e = getenv("SGDNET_W_LDS"); return !e || atoi(e) != 0; }();
+    static const bool w_lds_on = exp_env_int("SGDNET_W_LDS", 1) != 0;
     g.w_lds = d.K == 1 && w_lds_on && 2 * table + kLdsStaticReserve <= kLdsPerCu;
     if (g.w_lds) g.lds_bytes = 2 * table + 16;   // + alignment slack of the second table
   } else {
@@ -2465,30 +2631,78 @@ bool binned_active(const SagaDev& d, int m) { return !d.xd && plan_gather(d, m).
 // global-atomic form is used).
 // the 8-lane K == 1 form reads two entries per lane: records must hold 16 entries
 static bool lanes8_ok(const SagaDev& d) {
-  static const int allow = [] {
-    const char* e = getenv("SGDNET_LANES8");
-    return e ? atoi(e) : 1;
-  }();
+  static const int allow = exp_env_int("SGDNET_LANES8", 1);
   return allow && (d.cP || d.rec_cap >= kInReg8) && !SGD_ABLATE(d, ~0);
+}
+
+// does the gather of an m-draw batch read the tagged sample order (k1_lanes8_tagged)?
+bool tagged_gather(const SagaDev& d, int m) {
+  if (!d.cP || d.K != 1 || d.xd || !lanes8_ok(d)) return false;
+  if (d.V > 1 && vs_eligible(d, m)) return true;
+  const GatherPlan g = plan_gather(d, m);
+  return g.lds && g.w_lds;
 }
 
 // Compact planes for a K == 1 sparse problem (d.ptr / d.idx / d.val / d.y resident).
 bool compact_eligible(const SagaDev& d) {
-  static const int allow = [] {
-    const char* e = getenv("SGDNET_COMPACT");
-    return e ? atoi(e) : 1;
-  }();
+  static const int allow = exp_env_int("SGDNET_COMPACT", 1);
   if (!allow || d.K != 1 || d.Ky != 1 || d.xd || !d.ptr || d.p > 65536) return false;
   if (2 * sizeof(double) * (size_t)d.p + 16 + kLdsStaticReserve > (size_t)kLdsPerCu) return false;  // no LDS form
-  return (double)d.n * 2.0 * kCStride <= 48e9;
+  return (double)d.n * 2.0 * kCStride <= 48e9 && d.n < (int64_t)kIdMask;
 }
 
-int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* longmap, hipStream_t st) {
-  SGD_HIP_TRY(hipMemsetAsync(longmap, 0, sizeof(uint32_t) * (size_t)((d.n + 31) / 32 + 1), st));
+int compact_entries(const SagaDev& d) { return d.family == SGDNET_BINOMIAL ? 12 : 11; }
+
+int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* meta, hipStream_t st) {
+  SGD_HIP_TRY(hipMemsetAsync(meta, 0, sizeof(uint32_t) * (size_t)((d.n + 15) / 16 + 1), st));
   int64_t grid = (d.n + 255) / 256;
   if (grid > 65536) grid = 65536;
-  hipLaunchKernelGGL(pack_compact_kernel, dim3((unsigned)grid), dim3(256), 0, st, d.ptr, d.idx, d.val, d.y, d.n, P, Q,
-                     longmap);
+  const int E = compact_entries(d);
+  hipLaunchKernelGGL(pack_compact_kernel, dim3((unsigned)grid), dim3(256), 0, st, d.ptr, d.idx, d.val, d.y, d.n, E,
+                     E == 12 ? 1 : 0, P, Q, meta);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+int launch_m_move(const SagaDev& d, int to_record, hipStream_t st) {
+  int64_t grid = (d.n + 255) / 256;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL(m_move_kernel, dim3((unsigned)grid), dim3(256), 0, st, d, to_record);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+// the tagged sample order of one epoch of `draws` draws in batches of m (dps: draws per virtual shard)
+int launch_stream_tag(const SagaDev& d, const LamParams* lam, int64_t m, int64_t draws, hipStream_t st,
+                      int64_t stream_off, int64_t tstream_off) {
+  static bool attr_done_dev[64] = {};
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  const size_t lds = sizeof(uint32_t) * (size_t)kTagWords;
+  if (!attr_done_dev[cur & 63]) {
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_tag_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done_dev[cur & 63] = true;
+  }
+  const int V = d.V > 1 ? d.V : 1;
+  const int64_t dps = d.V > 1 ? draws / V : draws;
+  if (m > dps) m = dps;
+  if (m < 1 || dps < 1) return SGDNET_OK;
+  double widest = (double)d.n;
+  if (d.V > 1) {
+    widest = 0.0;
+    for (int v = 0; v < V; ++v) widest = d.v_size[v] > widest ? d.v_size[v] : widest;
+  }
+  const int64_t cap = (int64_t)kTagWords * 32;
+  const int64_t n_sub = ((int64_t)widest + cap - 1) / cap;
+  const int64_t nb = (dps + m - 1) / m;
+  if (nb > 65535 || n_sub > 65535) {
+    set_error("internal: sample-order tagging of %lld batches", (long long)nb);
+    return SGDNET_EINVAL;
+  }
+  const int64_t words = ((int64_t)widest < cap ? (int64_t)widest : cap) / 32 + 2;
+  hipLaunchKernelGGL(stream_tag_kernel, dim3((unsigned)(n_sub < 1 ? 1 : n_sub), (unsigned)nb, (unsigned)V), dim3(kTagBlock),
+                     sizeof(uint32_t) * (size_t)words, st, d, lam, m, dps, stream_off, tstream_off);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

@@ -58,6 +58,9 @@ int solver_create_adopting(const sgdnet_problem* pb, DeviceSetup& S, sgdnet_solv
 // side stream while the current epoch runs)
 int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators = 1);
 int solver_reset_state(sgdnet_solver* s, const double* b0);
+bool solver_bin_overflowed(const sgdnet_solver* s);
+int solver_grow_bins(sgdnet_solver* s);
+bool solver_batched_available(sgdnet_solver* s, int64_t batch);
 int solver_rng_prefetch(sgdnet_solver* s);
 int solver_rng_acquire(sgdnet_solver* s, int64_t* offset);
 int solver_rng_release(sgdnet_solver* s);

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <string>
 #include <chrono>
+#include <atomic>
 #include <vector>
 
 #include "common.hpp"
@@ -78,13 +79,19 @@ struct sgdnet_solver {
     // kernel leaves go to `ends` and are not used
     uint32_t* poly_n = nullptr;
     uint32_t* ends = nullptr;
+    // the shape (window, draws per epoch) each slot's draws were TAGGED for on the side stream (0: not tagged)
+    int64_t tag_m[2] = {0, 0}, tag_draws[2] = {0, 0};
   } pipe;
+  // the epoch being consumed: where its draws are, and the shape they were tagged for ahead of time
+  int64_t acq_off = -1, acq_tag_m = 0, acq_tag_draws = 0;
+  bool pretagged = false;        // the epoch graph selected by ensure_graph skips the tagging launch
   int64_t nnz = 0;
   bool penalty_set = false;
   // cached epoch graph
   // captured epochs, one per (batch, draws) shape; gexec is the one selected by ensure_graph
   struct GraphEntry {
     int64_t batch, draws;
+    bool pretagged;
     hipGraph_t graph;
     hipGraphExec_t exec;
   };
@@ -102,6 +109,14 @@ struct sgdnet_solver {
   int64_t bin_batch = 0;        // the batch the bins and gcb were sized for
   void* bin_bufs[3] = {nullptr, nullptr, nullptr};   // bins, gcb, bin_off
   std::vector<double> bin_mass;  // non-zeros of every feature range
+  std::vector<double> bin_sumsq; // sum over samples of (its non-zeros inside the range)^2
+  double bin_slack = 8.0, bin_slack_built = 0.0;   // standard deviations of room in every bin
+  bool bin_disabled = false;     // a bin kept overflowing: the solver runs the atomic form (K <= 16) from now on
+  bool bin_overflowed = false;   // the last sync found an overflow (the epochs since the previous sync are void)
+  // one-response sparse fits with compact records: the batched kernels keep the gradient memory inside the
+  // records (saga_batched.hip "Compact records"), everything else (exact mode, the host) sees the K x n array
+  bool m_in_rec = false;
+  int64_t tstream_cap = 0;       // words of the tagged-draw buffer (one epoch)
 };
 
 namespace {
@@ -167,15 +182,70 @@ void drop_graph(sgdnet_solver* s) {
   s->gexec = nullptr;
 }
 
+// Where the gradient memory of a one-response sparse fit lives: inside the compact records while batched
+// epochs run (the gather reads it with the record and stores it back in place), in the K x n array for the
+// exact kernels and the host.  A move is one pass over the samples; it happens when the mode changes or the
+// host reads / writes g_memory, not per epoch.  The kernels take SagaDev by value, so captured graphs go.
+int m_to_record(sgdnet_solver* s) {
+  if (s->m_in_rec || !s->d.cP || s->d.K != 1) return SGDNET_OK;
+  int rc = launch_m_move(s->d, 1, s->st);
+  if (rc) return rc;
+  s->m_in_rec = true;
+  s->d.m_rec = 1;
+  s->d.m_base = s->d.cP + 120;
+  s->d.m_stride = 128;
+  drop_graph(s);
+  return SGDNET_OK;
+}
+
+int m_to_array(sgdnet_solver* s) {
+  if (!s->m_in_rec) return SGDNET_OK;
+  int rc = launch_m_move(s->d, 0, s->st);
+  if (rc) return rc;
+  s->m_in_rec = false;
+  s->d.m_rec = 0;
+  s->d.m_base = reinterpret_cast<char*>(s->d.M);
+  s->d.m_stride = 8;
+  drop_graph(s);
+  return SGDNET_OK;
+}
+
+// the tagged-draw buffer covers one epoch of `draws` draws
+int ensure_tstream(sgdnet_solver* s, int64_t draws) {
+  if (!s->d.cP) return SGDNET_OK;
+  if (s->pipe.open && 2 * s->pipe.n > draws) draws = 2 * s->pipe.n;   // the pipeline tags both of its slots
+  if (draws + 64 <= s->tstream_cap) return SGDNET_OK;
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  if (s->pipe.st) SGD_HIP_TRY(hipStreamSynchronize(s->pipe.st));
+  if (s->d.tstream) SGD_HIP_TRY(hipFree(s->d.tstream));
+  s->d.tstream = nullptr;
+  SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d.tstream), sizeof(uint32_t) * (size_t)(draws + 64)));
+  SGD_HIP_TRY(hipMemsetAsync(s->d.tstream, 0, sizeof(uint32_t) * (size_t)(draws + 64), s->st));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  s->tstream_cap = draws + 64;
+  s->pipe.tag_m[0] = s->pipe.tag_m[1] = 0;
+  s->acq_tag_m = 0;
+  drop_graph(s);
+  return SGDNET_OK;
+}
+
+// Was the epoch at `stream_offset` tagged ahead of time (sample-order pipeline) for the shape set_batch_shape
+// has just put into lam?  Sets lam.tstream_base and the graph variant.
+void select_tagging(sgdnet_solver* s, int64_t stream_offset, int64_t draws) {
+  s->pretagged = s->pipe.open && stream_offset == s->acq_off && s->acq_tag_m == s->lam.m_full && s->acq_tag_m > 0 &&
+                 s->acq_tag_draws == draws;
+  s->lam.tstream_base = s->pretagged ? stream_offset : 0;
+}
+
 // Binned form of the batched iteration for K x p tables that fit no LDS (saga_batched.hip
 // "Binned form").  Ranges: contiguous features of equal non-zero mass, at most
 // binned_max_range_features(K) wide; built once per solver from a device histogram of the feature
 // ids.  Bins and the gradient-change buffer are sized for the batch.
 int ensure_binned(sgdnet_solver* s, int64_t batch) {
   SagaDev& d = s->d;
-  static const int allow = [] { const char* e = getenv("SGDNET_BINNED"); return e ? atoi(e) : 1; }();
+  static const int allow = exp_env_int("SGDNET_BINNED", 1);
   // more than 16 classes: the only batched form there is (a wavefront per draw), whatever the sizes
-  const bool want = allow && s->sparse && !d.xd && d.rec && d.idx && d.K <= 64 && !d.force_global &&
+  const bool want = allow && !s->bin_disabled && s->sparse && !d.xd && d.rec && d.idx && d.K <= 64 && !d.force_global &&
                     d.p < (1ll << 31) &&
                     (d.K > 16 || (sizeof(double) * (size_t)d.K * (size_t)d.p > 80 * 1024 && batch >= 4096));
   if (!want) {
@@ -186,39 +256,46 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     return SGDNET_OK;
   }
   if (!s->bin_ranges_ready) {
+    s->bin_ranges_ready = true;                       // whatever comes out: the work below is done once
     unsigned* counts = nullptr;
-    int rc = dev_alloc(s, &counts, (size_t)d.p, false);
-    if (rc) return rc;
-    rc = launch_col_count(d, s->nnz, counts, s->st);
+    SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&counts), sizeof(unsigned) * (size_t)d.p));
+    struct Free { void* q; ~Free() { (void)hipFree(q); } } free_counts{counts};
+    int rc = launch_col_count(d, s->nnz, counts, s->st);
     if (rc) return rc;
     std::vector<unsigned> h((size_t)d.p);
     SGD_HIP_TRY(hipMemcpyAsync(h.data(), counts, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost, s->st));
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     const int64_t fmax = (int64_t)binned_max_range_features(d.K);
-    static const int target_env = [] { const char* e = getenv("SGDNET_BIN_RANGES"); return e ? atoi(e) : 0; }();
+    static const int target_env = exp_env_int("SGDNET_BIN_RANGES", 0);
     const int target = target_env > 0 ? target_env : 512;   // range sweep workgroups (3 of 512 threads fit a CU)
     const double per = std::max(1.0, (double)s->nnz / target);
     std::vector<int32_t> lo{0};
-    std::vector<uint16_t> fr((size_t)d.p);
-    double mass = 0.0;
-    int64_t width = 0;
-    for (int64_t j = 0; j < d.p; ++j) {
-      if (width > 0 && (width >= fmax || mass + 0.5 * h[(size_t)j] >= per)) {
-        lo.push_back((int32_t)j);
-        mass = 0.0;
-        width = 0;
+    {
+      double mass = 0.0;
+      int64_t width = 0;
+      for (int64_t j = 0; j < d.p; ++j) {
+        if (width > 0 && (width >= fmax || mass + 0.5 * h[(size_t)j] >= per)) {
+          lo.push_back((int32_t)j);
+          mass = 0.0;
+          width = 0;
+        }
+        mass += h[(size_t)j];
+        ++width;
       }
-      fr[(size_t)j] = (uint16_t)(lo.size() - 1);
-      mass += h[(size_t)j];
-      ++width;
+      lo.push_back((int32_t)d.p);
     }
-    lo.push_back((int32_t)d.p);
     const int R = (int)lo.size() - 1;
+    if (R > 2048) return SGDNET_OK;      // staging counters of the gather would not fit: d.R stays 0 (no binned form)
+    std::vector<uint16_t> fr((size_t)d.p);
     s->bin_mass.assign((size_t)R, 0.0);
-    for (int64_t j = 0; j < d.p; ++j) s->bin_mass[fr[(size_t)j]] += h[(size_t)j];
-    if (R > 2048) return SGDNET_OK;                  // staging counters of the gather would not fit: atomic form
     int wmax = 1;
-    for (int r = 0; r < R; ++r) wmax = std::max(wmax, (int)(lo[(size_t)r + 1] - lo[(size_t)r]));
+    for (int r = 0; r < R; ++r) {
+      wmax = std::max(wmax, (int)(lo[(size_t)r + 1] - lo[(size_t)r]));
+      for (int64_t j = lo[(size_t)r]; j < lo[(size_t)r + 1]; ++j) {
+        fr[(size_t)j] = (uint16_t)r;
+        s->bin_mass[(size_t)r] += h[(size_t)j];
+      }
+    }
     d.range_max = wmax;
     int32_t* lo_dev = nullptr;
     uint16_t* fr_dev = nullptr;
@@ -229,6 +306,21 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     if (!rc) rc = dev_alloc(s, &bc, (size_t)R, true);
     if (!rc) rc = dev_alloc(s, &be, 1, true);
     if (rc) return rc;
+    // second moment of a sample's entries per range (sizes the bins below)
+    s->bin_sumsq.assign((size_t)R, 0.0);
+    if (d.ptr) {
+      unsigned long long* sq = nullptr;
+      SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&sq), sizeof(unsigned long long) * (size_t)R));
+      Free free_sq{sq};
+      rc = launch_range_moment(d, fr_dev, sq, R, s->st);
+      if (rc) return rc;
+      std::vector<unsigned long long> hsq((size_t)R);
+      SGD_HIP_TRY(hipMemcpyAsync(hsq.data(), sq, sizeof(unsigned long long) * (size_t)R, hipMemcpyDeviceToHost, s->st));
+      SGD_HIP_TRY(hipStreamSynchronize(s->st));
+      for (int r = 0; r < R; ++r) s->bin_sumsq[(size_t)r] = (double)hsq[(size_t)r];
+    } else {
+      s->bin_sumsq = s->bin_mass;                     // no sample-major pointers: one entry per arrival
+    }
     SGD_HIP_TRY(hipStreamSynchronize(s->st));        // the uploads read host vectors that die here
     int ks = 1;
     while (ks < d.K) ks *= 2;
@@ -246,29 +338,32 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     d.feat_range = fr_dev;
     d.bin_count = bc;
     d.bin_err = be;
-    s->bin_ranges_ready = true;
     if (getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet]   binned form: %d feature ranges (<= %lld features each)\n", R, (long long)fmax);
   }
   if (d.R <= 0) return SGDNET_OK;
-  if (batch != s->bin_batch || !s->bin_bufs[0]) {
+  if (batch != s->bin_batch || !s->bin_bufs[0] || s->bin_slack != s->bin_slack_built) {
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     for (void*& q : s->bin_bufs) {
       if (q) (void)hipFree(q);
       q = nullptr;
     }
-    // a batch's draws are distinct samples picked uniformly: range r receives about
-    // batch * mass_r / n entries; capacity = that mean + 8 standard deviations + slack (a range
-    // that holds one very frequent feature gets the room it needs)
+    // Range r receives the entries of `batch` uniformly drawn samples: a sum of `batch` per-sample counts c_ir
+    // with mean mass_r / n and second moment sumsq_r / n.  Capacity = mean + slack standard deviations + room
+    // for the largest rows (slack starts at 8 and doubles when a bin has overflowed: solver_grow_bins).
     std::vector<int64_t> off((size_t)d.R + 1, 0);
     for (int r = 0; r < d.R; ++r) {
       const double mean = (double)batch * s->bin_mass[(size_t)r] / (double)d.n;
-      off[(size_t)r + 1] = off[(size_t)r] + (int64_t)(mean + 8.0 * std::sqrt(mean) + 512.0);
+      const double var = (double)batch * s->bin_sumsq[(size_t)r] / (double)d.n;
+      double cap = mean + s->bin_slack * std::sqrt(var) + 64.0 * s->bin_slack;
+      cap = std::min(cap, (double)batch * (double)d.range_max + 512.0);   // nothing can send more than this
+      off[(size_t)r + 1] = off[(size_t)r] + (int64_t)cap;
     }
     SGD_HIP_TRY(hipMalloc(&s->bin_bufs[0], (size_t)16 * (size_t)off[(size_t)d.R]));
     SGD_HIP_TRY(hipMalloc(&s->bin_bufs[1], sizeof(double) * (size_t)batch * (size_t)d.KS));
     SGD_HIP_TRY(hipMalloc(&s->bin_bufs[2], sizeof(int64_t) * off.size()));
     SGD_HIP_TRY(hipMemcpy(s->bin_bufs[2], off.data(), sizeof(int64_t) * off.size(), hipMemcpyHostToDevice));
     s->bin_batch = batch;
+    s->bin_slack_built = s->bin_slack;
     drop_graph(s);
   }
   if (!d.bins) drop_graph(s);
@@ -298,6 +393,11 @@ int ensure_dense_tiled(sgdnet_solver* s, int64_t batch) {
 
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
+  {
+    int rct = ensure_tstream(s, draws);
+    if (!rct) rct = m_to_record(s);          // batched kernels: the gradient memory rides in the records
+    if (rct) return rct;
+  }
   if (s->d.V > 1 && vs_eligible(s->d, (int)batch)) {
     // per-shard batches; the scratch is sized for the launch that carries V of them
     const int64_t dps = draws / s->d.V;
@@ -374,7 +474,12 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
   if (batch > dps) batch = dps;
   const int nb = n_batches(batch, dps);
   const int every = vs_merge_batches(s, batch);
-  int rc = launch_vs_broadcast(d, s->st);
+  int rc = SGDNET_OK;
+  if (tagged_gather(d, (int)batch) && !s->pretagged) {
+    rc = launch_stream_tag(d, s->lam_dev, batch, draws, s->st);
+    if (rc) return rc;
+  }
+  rc = launch_vs_broadcast(d, s->st);
   if (rc) return rc;
   rc = launch_vs_cw(d, s->st);
   if (rc) return rc;
@@ -419,6 +524,13 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
     const int rcw = launch_wpad_refresh(s->d, s->st);
     if (rcw) return rcw;
   }
+  {
+    const int64_t tail_m = draws - (draws / batch) * batch;
+    if (!s->pretagged && (tagged_gather(s->d, (int)batch) || (tail_m > 0 && tagged_gather(s->d, (int)tail_m)))) {
+      const int rct = launch_stream_tag(s->d, s->lam_dev, batch, draws, s->st);
+      if (rct) return rct;
+    }
+  }
   for (int k = 0; k < nb; ++k) {
     const int64_t t0 = (int64_t)k * batch;
     const int64_t m = (draws - t0 < batch) ? draws - t0 : batch;
@@ -450,11 +562,11 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
 
 int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
   for (auto& g : s->graphs)
-    if (g.batch == batch && g.draws == draws) {
+    if (g.batch == batch && g.draws == draws && g.pretagged == s->pretagged) {
       s->gexec = g.exec;
       return SGDNET_OK;
     }
-  if (s->graphs.size() >= 4) {   // a sharded epoch uses at most two shapes (segments + remainder)
+  if (s->graphs.size() >= 6) {   // a sharded epoch uses at most two shapes (segments + remainder), tagged ahead or not
     auto& old = s->graphs.front();
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     (void)hipGraphExecDestroy(old.exec);
@@ -480,7 +592,7 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return SGDNET_EHIP;
   }
-  s->graphs.push_back({batch, draws, g, ex});
+  s->graphs.push_back({batch, draws, s->pretagged, g, ex});
   s->gexec = ex;
   return SGDNET_OK;
 }
@@ -609,7 +721,7 @@ int build_records(sgdnet_solver* s, const sgdnet_problem* pb) {
   auto rec_bytes = [](int c) { return 16 + ((4 * c + 7) & ~7) + 8 * c; };
   // records are aligned to 128 B: random HBM requests on gfx950 are served in 128-B units
   // (measured: 64-B-aligned 192-B records cost 13 % more gather time than 256-B ones)
-  static const int align = [] { const char* e = getenv("SGDNET_REC_ALIGN"); return e ? atoi(e) : 128; }();
+  static const int align = exp_env_int("SGDNET_REC_ALIGN", 128);
   const int stride = (rec_bytes(cap) + align - 1) / align * align;
   while (rec_bytes(cap + 1) <= stride) ++cap;
   const int val_off = 16 + ((4 * cap + 7) & ~7);
@@ -667,9 +779,51 @@ int build_records(sgdnet_solver* s, const sgdnet_problem* pb) {
 
 }  // namespace
 
+namespace {
+struct OptionDef {
+  const char* name;
+  int dflt, lo, hi;
+};
+const OptionDef kOptionDefs[sgdnet::kOptCount] = {
+    {"virtual_shards", -1, -1, 8}, {"rng_generators", 0, 0, 64},     {"window_eigenvalue", 1, 0, 1},
+    {"host_setup", 0, 0, 1},       {"exact_epoch_blocks", 1, 0, 1},
+};
+std::atomic<int> g_options[sgdnet::kOptCount] = {{-1}, {0}, {1}, {0}, {1}};
+int find_option(const char* name) {
+  if (name)
+    for (int i = 0; i < sgdnet::kOptCount; ++i)
+      if (!strcmp(name, kOptionDefs[i].name)) return i;
+  return -1;
+}
+}  // namespace
+
+namespace sgdnet {
+int option(Option o) { return g_options[o].load(std::memory_order_relaxed); }
+}  // namespace sgdnet
+
 extern "C" {
 
 int sgdnet_abi_version(void) { return SGDNET_ABI_VERSION; }
+
+int sgdnet_set_option(const char* name, int value) {
+  const int i = find_option(name);
+  if (i < 0 || value < kOptionDefs[i].lo || value > kOptionDefs[i].hi) {
+    set_error("sgdnet_set_option: %s = %d is not an option (include/sgdnet_hip.h)", name ? name : "(null)", value);
+    return SGDNET_EINVAL;
+  }
+  g_options[i].store(value, std::memory_order_relaxed);
+  return SGDNET_OK;
+}
+
+int sgdnet_get_option(const char* name, int* value) {
+  const int i = find_option(name);
+  if (i < 0 || !value) {
+    set_error("sgdnet_get_option: unknown option %s", name ? name : "(null)");
+    return SGDNET_EINVAL;
+  }
+  *value = g_options[i].load(std::memory_order_relaxed);
+  return SGDNET_OK;
+}
 
 const char* sgdnet_last_error(void) { return g_last_error.c_str(); }
 
@@ -811,13 +965,14 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
     // an optimisation, not a requirement: without the memory for the planes the K = 1 gather
     // reads the 256-B records
     char *cP = nullptr, *cQ = nullptr;
-    uint32_t* lm = nullptr;
+    uint32_t* mt = nullptr;
     if (dev_alloc(s, &cP, (n + 1) * 128, false) == SGDNET_OK && dev_alloc(s, &cQ, (n + 1) * 128, false) == SGDNET_OK &&
-        dev_alloc(s, &lm, (n + 31) / 32 + 1, false) == SGDNET_OK) {
-      TRY(launch_pack_compact(d, cP, cQ, lm, s->st));
+        dev_alloc(s, &mt, (n + 15) / 16 + 1, false) == SGDNET_OK) {
+      TRY(launch_pack_compact(d, cP, cQ, mt, s->st));
       d.cP = cP;
       d.cQ = cQ;
-      d.clong = lm;
+      d.cmeta = mt;
+      d.cE = compact_entries(d);
     } else {
       (void)hipGetLastError();
     }
@@ -825,6 +980,8 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
   TRY(dev_alloc(s, &d.w, K * p, true));
   TRY(dev_alloc(s, &d.G, K * p, true));
   TRY(dev_alloc(s, &d.M, K * n, true));
+  d.m_base = reinterpret_cast<char*>(d.M);
+  d.m_stride = 8;
   TRY(dev_alloc(s, &d.b, K, true));
   TRY(dev_alloc(s, &d.gb, K, true));
   TRY(dev_alloc(s, &d.w_prev, K * p, true));
@@ -877,6 +1034,7 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
   if (s->d.slab) (void)hipFree(s->d.slab);
+  if (s->d.tstream) (void)hipFree(s->d.tstream);
   for (void* q : s->bin_bufs)
     if (q) (void)hipFree(q);
   for (void* q : s->vs_owned) (void)hipFree(q);
@@ -937,6 +1095,8 @@ int sgdnet_solver_get_state(sgdnet_solver* s, int which, double* host) {
   size_t count;
   int rc = state_ptr(s, which, &p, &count);
   if (rc) return rc;
+  if (which == 2) rc = m_to_array(s);
+  if (rc) return rc;
   SGD_HIP_TRY(hipMemcpyAsync(host, p, sizeof(double) * count, hipMemcpyDeviceToHost, s->st));
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   return SGDNET_OK;
@@ -948,6 +1108,8 @@ int sgdnet_solver_set_state(sgdnet_solver* s, int which, const double* host) {
   double* p;
   size_t count;
   int rc = state_ptr(s, which, &p, &count);
+  if (rc) return rc;
+  if (which == 2) rc = m_to_array(s);
   if (rc) return rc;
   SGD_HIP_TRY(hipMemcpyAsync(p, host, sizeof(double) * count, hipMemcpyHostToDevice, s->st));
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
@@ -1051,8 +1213,45 @@ int sgdnet_solver_generate_stream(sgdnet_solver* s, sgdnet_rng* rng, int64_t cou
 
 // w = g_sum = g_memory = g_sum_intercept = 0, intercept = b0 (K values): the state a fit starts
 // from (driver.cpp restarts a lambda from here when the automatic staleness window diverged)
+// Binned form, recovery from a bin overflow (driver.cpp): true when the last synchronisation found one.
+bool solver_bin_overflowed(const sgdnet_solver* s) { return s && s->bin_overflowed; }
+
+// After an overflow: twice the room in every bin (rebuilt by the next run); after three doublings the
+// solver gives the binned form up -- the atomic form takes over where there is one (n_classes <= 16),
+// otherwise SGDNET_EUNSUPPORTED (no batched form left: the caller falls back to the exact iteration).
+int solver_grow_bins(sgdnet_solver* s) {
+  s->bin_overflowed = false;
+  if (s->bin_slack < 64.0) {
+    s->bin_slack *= 2.0;
+    return SGDNET_OK;
+  }
+  s->bin_disabled = true;
+  if (s->d.K > 16) {
+    set_error("batched mode: the binned form keeps overflowing and more than 16 classes have no other batched form");
+    return SGDNET_EUNSUPPORTED;
+  }
+  return SGDNET_OK;
+}
+
+// Is there a batched form for this solver at this window?  (More than 16 classes need the binned form,
+// which needs feature ranges: at most 2048 of them, sparse x.)
+bool solver_batched_available(sgdnet_solver* s, int64_t batch) {
+  if (!s) return false;
+  if (s->d.K <= 16) return true;
+  if (s->d.K > 64 || !s->sparse) return false;
+  if (ensure_binned(s, batch < 1 ? 1 : batch) != SGDNET_OK) return false;
+  return s->d.R > 0 && !s->bin_disabled;
+}
+
 int solver_reset_state(sgdnet_solver* s, const double* b0) {
   SGD_HIP_TRY(hipSetDevice(s->device));
+  if (s->m_in_rec) {              // the array is cleared below; the records take it over again at the next batched run
+    s->m_in_rec = false;
+    s->d.m_rec = 0;
+    s->d.m_base = reinterpret_cast<char*>(s->d.M);
+    s->d.m_stride = 8;
+    drop_graph(s);
+  }
   const SagaDev& d = s->d;
   const size_t K = (size_t)d.K;
   SGD_HIP_TRY(hipMemsetAsync(d.w, 0, sizeof(double) * K * (size_t)d.p, s->st));
@@ -1102,7 +1301,11 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   P.G = generators;
   {
     // the generators' workgroups get CUs of their own: the LDS gather forms shrink their grids
-    const int reserve = generators > 1 ? generators : 0;
+    // ... kGenPerWg generators share a workgroup; where the side stream also tags the draws for the LDS gather
+    // (one 160-KB-LDS workgroup per shard and batch) it gets 16 CUs: ~0.5 ms of side work per C4 epoch
+    const int per_wg = rng_generators_per_workgroup();
+    int reserve = generators > 1 ? (generators + per_wg - 1) / per_wg : 0;
+    if (reserve > 0 && s->d.cP && reserve < 16) reserve = 16;
     if (reserve != s->d.cu_reserve) {
       SGD_HIP_TRY(hipStreamSynchronize(s->st));
       s->d.cu_reserve = reserve;
@@ -1128,8 +1331,11 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   for (int i = 0; i < 2; ++i) SGD_HIP_TRY(hipEventRecord(P.freed[i], s->st));
   P.n = n;
   P.gens = P.used = 0;
+  P.tag_m[0] = P.tag_m[1] = 0;
+  s->acq_off = -1;
+  s->acq_tag_m = 0;
   P.open = true;
-  return SGDNET_OK;
+  return ensure_tstream(s, 2 * n);
 }
 
 // enqueue the next generation (never more than one ahead of the epoch being consumed)
@@ -1143,12 +1349,26 @@ int solver_rng_prefetch(sgdnet_solver* s) {
   if (P.G > 1) {
     rc = launch_rng_fill(P.state[P.gens & 1], P.ends, (uint32_t)s->d.n, s->stream_dev + (int64_t)slot * P.n, P.n,
                          P.st, s->d.V, s->d.v_size, P.G);
-    if (!rc) rc = launch_rng_jump(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], P.poly_n, P.G, P.st);
+    // the jump's workgroups take their generators in turn: the side stream never holds more CUs than
+    // the generators' own (a wider launch would push gather workgroups into a second round)
+    if (!rc) rc = launch_rng_jump(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], P.poly_n, P.G, P.st,
+                                  std::max(1, s->d.cu_reserve));
   } else {
     rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
                          s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G);
   }
   if (rc) return rc;
+  // ... and, for the one-response LDS gather, the tags of those draws (first occurrence inside each batch, long
+  // row, response: saga_batched.hip) for the shape the last run used; an epoch that runs with another window
+  // is tagged again on the solver's stream
+  P.tag_m[slot] = P.tag_draws[slot] = 0;
+  if (s->d.cP && s->d.tstream && s->tstream_cap >= 2 * P.n && s->lam.m_full > 0 && s->lam.draws_per_epoch == P.n &&
+      tagged_gather(s->d, (int)s->lam.m_full)) {
+    rc = launch_stream_tag(s->d, nullptr, s->lam.m_full, P.n, P.st, (int64_t)slot * P.n, (int64_t)slot * P.n);
+    if (rc) return rc;
+    P.tag_m[slot] = s->lam.m_full;
+    P.tag_draws[slot] = P.n;
+  }
   SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
   ++P.gens;
   return SGDNET_OK;
@@ -1161,6 +1381,9 @@ int solver_rng_acquire(sgdnet_solver* s, int64_t* offset) {
   const int slot = (int)(P.used & 1);
   SGD_HIP_TRY(hipStreamWaitEvent(s->st, P.ready[slot], 0));
   *offset = (int64_t)slot * P.n;
+  s->acq_off = *offset;
+  s->acq_tag_m = P.tag_m[slot];
+  s->acq_tag_draws = P.tag_draws[slot];
   return SGDNET_OK;
 }
 
@@ -1212,16 +1435,18 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
   int converged = 0;
 
   if (mode == SGDNET_MODE_EXACT) {
+    rc = m_to_array(s);                       // the exact kernels read the K x n gradient memory
+    if (rc) return rc;
     if (s->sparse) {
       rc = ensure_ls_table(s, draws_per_epoch);
       if (rc) return rc;
     }
     const size_t lds_cap = 160 * 1024 - 256;
     // small dense problems: the register-resident kernel (saga_exact.hip); SGDNET_EXACT_SMALL=0 keeps the general one
-    static const int small_ok = [] { const char* e = getenv("SGDNET_EXACT_SMALL"); return e ? atoi(e) : 1; }();
+    static const int small_ok = exp_env_int("SGDNET_EXACT_SMALL", 1);
     const size_t lds_small = (!s->sparse && small_ok) ? dense_exact_small_lds_bytes(s->d, draws_per_epoch) : 0;
     // wider dense rows (up to 16 classes): the workgroup-per-iteration kernel; SGDNET_EXACT_WIDE=0 keeps the one-wavefront one
-    static const int wide_ok = [] { const char* e = getenv("SGDNET_EXACT_WIDE"); return e ? atoi(e) : 1; }();
+    static const int wide_ok = exp_env_int("SGDNET_EXACT_WIDE", 1);
     const bool wide = !s->sparse && !lds_small && wide_ok && dense_exact_wide_threads(s->d) > 0;
     const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true)
                                       : (wide ? dense_exact_wide_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true));
@@ -1288,6 +1513,7 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     rc = set_batch_shape(s, batch, draws_per_epoch);
     if (rc) return rc;
     s->lam.stream_base = stream_offset;
+    select_tagging(s, stream_offset, draws_per_epoch);
     rc = push_lam(s);
     if (rc) return rc;
     if (s->d.standardize) {
@@ -1360,6 +1586,7 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   rc = set_batch_shape(s, batch, draws_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
+  select_tagging(s, n_epochs == 1 ? stream_offset : -2, draws_per_epoch);
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1385,8 +1612,9 @@ static int check_bins(sgdnet_solver* s) {
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   if (flag) {
     SGD_HIP_TRY(hipMemsetAsync(s->d.bin_err, 0, sizeof(int), s->st));
-    set_error("batched mode (binned form): a feature range received more entries in one batch than its bin holds; "
-              "set SGDNET_BINNED=0 or pass a smaller control.batch");
+    s->bin_overflowed = true;       // sgdnet_fit_* recovers (solver_grow_bins); a direct caller sees the error
+    set_error("batched mode (binned form): a feature range received more entries in one batch than its bin holds "
+              "(the epochs since the last synchronisation are void); pass a smaller batch");
     return SGDNET_EUNSUPPORTED;
   }
   return SGDNET_OK;
@@ -1416,6 +1644,7 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   rc = set_batch_shape(s, batch, draws_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
+  select_tagging(s, stream_offset, draws_per_epoch);
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1645,6 +1874,8 @@ int sgdnet_solver_sync_begin(sgdnet_solver* s, int64_t stream_offset, int64_t dr
   int rc = check_stream(s, stream_offset, draws_local_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
+  s->lam.tstream_base = 0;
+  s->pretagged = false;
   s->lam.draws_per_epoch = draws_local_per_epoch;
   rc = push_lam(s);
   if (rc) return rc;

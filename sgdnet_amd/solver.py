@@ -69,6 +69,33 @@ class RRng:
         return out
 
 
+def set_option(name, value):
+    """sgdnet_set_option (include/sgdnet_hip.h): process-wide backend options, e.g. "virtual_shards"."""
+    check(_lib.load().sgdnet_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int()
+    check(_lib.load().sgdnet_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+class option:
+    """with sgdnet_amd.option("virtual_shards", 0): ...   -- the previous value comes back on exit."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
+
+
 def auto_batch(max_sample_sqnorm, max_feature_mean_sq):
     """Default staleness window of the batched mode (sgdnet_auto_batch of the C ABI)."""
     return int(_lib.load().sgdnet_auto_batch(float(max_sample_sqnorm), float(max_feature_mean_sq)))

@@ -287,6 +287,10 @@ static const R_CallMethodDef CallEntries[] = {
     {NULL, NULL, 0}};
 
 void R_init_sgdnet(DllInfo* dll) {
+  /* the structs this file fills are laid out for SGDNET_ABI_VERSION of the header it was compiled against */
+  if (sgdnet_abi_version() != SGDNET_ABI_VERSION)
+    Rf_error("libsgdnet_hip has ABI version %d, this shim was built for %d: rebuild the package", sgdnet_abi_version(),
+             SGDNET_ABI_VERSION);
   R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
   R_useDynamicSymbols(dll, FALSE);
 }

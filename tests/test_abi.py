@@ -28,7 +28,11 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_rng_match_r(oracle):
     import sgdnet_amd as sa
-    assert sa.load().sgdnet_abi_version() == 1
+    import re
+    from sgdnet_amd import _lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "sgdnet_hip.h")).read()
+    declared = int(re.search(r"#define SGDNET_ABI_VERSION (\d+)", hdr).group(1))
+    assert sa.load().sgdnet_abi_version() == declared == _lib.ABI_VERSION     # library, header and binding agree
     # R: set.seed(1); runif(3)
     np.testing.assert_allclose(sa.RRng(1).unif(3), [0.2655087, 0.3721239, 0.5728534], atol=5e-8)
     # product RNG == oracle RNG, draw for draw
@@ -71,3 +75,27 @@ def test_auto_batch_rule():
     assert sa.auto_batch(50.0, 1e-9) == 131072
     assert sa.auto_batch(1.0, 1.0) == 64
     assert sa.auto_batch(0.0, 0.0) == 64
+
+
+def test_backend_options_are_the_documented_ones():
+    """sgdnet_set_option is the one documented switchboard (include/sgdnet_hip.h); unknown names and values
+    outside the documented range are refused, and the shipped library reads no kernel-selection environment
+    variable (they exist in -DSGDNET_EXPERIMENTS builds only)."""
+    import sgdnet_amd as sa
+    defaults = {"virtual_shards": -1, "rng_generators": 0, "window_eigenvalue": 1, "host_setup": 0,
+                "exact_epoch_blocks": 1}
+    for name, dflt in defaults.items():
+        assert sa.get_option(name) == dflt
+        assert name in open(os.path.join(ROOT, "include", "sgdnet_hip.h")).read()
+    with sa.option("virtual_shards", 4):
+        assert sa.get_option("virtual_shards") == 4
+    assert sa.get_option("virtual_shards") == -1
+    for name, bad in (("virtual_shards", 9), ("rng_generators", -1), ("host_setup", 2), ("no_such_option", 0)):
+        with pytest.raises(sa.SgdnetError):
+            sa.set_option(name, bad)
+    src = os.path.join(ROOT, "sgdnet_amd", "csrc")
+    for f in os.listdir(src):
+        text = open(os.path.join(src, f)).read()
+        for m in re.finditer(r'getenv\("(SGDNET_[A-Z0-9_]+)"\)', text):
+            # progress printing and builds that are never shipped
+            assert m.group(1) in ("SGDNET_TRACE", "SGDNET_ABLATE", "SGDNET_PHASE_DUMP"), (f, m.group(1))

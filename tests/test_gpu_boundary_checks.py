@@ -28,12 +28,12 @@ def test_virtual_shards_through_the_unif_callback_equal_the_builtin_generator(sa
     """The R shim hands the backend unif_rand() (shim/sgdnet_shim.c); with virtual shards the
     driver must lay those draws out per shard exactly as the device generator does."""
     x, y = big
-    monkeypatch.setenv("SGDNET_RNG_GENERATORS", "1")       # one R stream on the device as well
     kw = dict(family="binomial", alpha=0.5, lambda_=[2e-3, 1e-3], standardize=False, thresh=1e-7, maxit=60,
               mode="batched")
-    ref = sa.sgdnet(x, y, seed=3, **kw)
     r = sa.RRng(3)
-    cb = sa.sgdnet(x, y, unif=lambda: float(r.unif()[0]), **kw)
+    with sa.option("rng_generators", 1):                   # one R stream on the device as well
+        ref = sa.sgdnet(x, y, seed=3, **kw)
+        cb = sa.sgdnet(x, y, unif=lambda: float(r.unif()[0]), **kw)
     assert cb.npasses == ref.npasses
     assert np.abs(cb.beta - ref.beta).max() <= 1e-12 * np.abs(ref.beta).max()
     assert np.abs(cb.a0 - ref.a0).max() <= 1e-12
@@ -118,9 +118,9 @@ def test_parallel_generators_stay_on_rs_single_stream(sa, big, monkeypatch):
               mode="batched")
     r_par = sa.RRng(3)
     par = sa.sgdnet(x, y, rng=r_par, **kw)                     # default: several generators
-    monkeypatch.setenv("SGDNET_RNG_GENERATORS", "1")
     r_one = sa.RRng(3)
-    one = sa.sgdnet(x, y, rng=r_one, **kw)
+    with sa.option("rng_generators", 1):
+        one = sa.sgdnet(x, y, rng=r_one, **kw)
     assert par.npasses == one.npasses
     assert np.abs(par.beta - one.beta).max() <= 1e-12 * np.abs(one.beta).max()
     assert par.draws_used == one.draws_used and par.draws_used >= int(par.npasses) * n

@@ -206,15 +206,9 @@ def test_small_correlated_data_in_batched_mode(sa):
     ab = np.load(os.path.join(GOLD, "abalone.npz"))
     x, y = ab["x"], ab["y"]
     ref = sa.sgdnet(x, y, lambda_=[0.01], thresh=1e-9, maxit=20000, seed=1)
-    for forced in (None, "2", "4"):
-        if forced is None:
-            _os.environ.pop("SGDNET_VSHARDS", None)
-        else:
-            _os.environ["SGDNET_VSHARDS"] = forced
-        try:
+    for forced in (-1, 2, 4):
+        with sa.option("virtual_shards", forced):
             fit = sa.sgdnet(x, y, lambda_=[0.01], thresh=1e-9, maxit=20000, seed=1, mode="batched")
-        finally:
-            _os.environ.pop("SGDNET_VSHARDS", None)
         assert fit.return_codes[0] == 0 and np.all(np.isfinite(fit.beta))
         assert np.abs(fit.beta - ref.beta).max() < 1e-5 * max(1.0, np.abs(ref.beta).max())
     path = sa.sgdnet(x, y, mode="auto", seed=1)
@@ -234,10 +228,9 @@ def test_nonnegative_sparse_features_keep_the_automatic_window_stable(sa, monkey
     X = sp.random(n, p, density=0.005, format="csc", random_state=3)
     b = rng.standard_normal(p) * (rng.random(p) < 0.1)
     y = (rng.random(n) < 1 / (1 + np.exp(-np.asarray(X @ b).ravel()))).astype(int)
-    if no_lmax:
-        monkeypatch.setenv("SGDNET_NO_LMAX", "1")                 # only the safety net
-    fit = sa.sgdnet(X, y, family="binomial", alpha=1.0, nlambda=20, thresh=1e-5, standardize=False, mode="auto",
-                    maxit=300, seed=3)
+    with sa.option("window_eigenvalue", 0 if no_lmax else 1):      # 0: only the safety net
+        fit = sa.sgdnet(X, y, family="binomial", alpha=1.0, nlambda=20, thresh=1e-5, standardize=False, mode="auto",
+                        maxit=300, seed=3)
     assert np.all(fit.return_codes == 0)
     assert np.all(np.diff(fit.dev_ratio) > -1e-6) and fit.dev_ratio[-1] > 0.05
     ref = sa.sgdnet(X, y, family="binomial", alpha=1.0, lambda_=fit.lambda_, thresh=1e-5, standardize=False,
@@ -258,9 +251,9 @@ def test_increasing_lambda_sequence_is_caught_by_the_null_model_net(sa, monkeypa
     b = rng.standard_normal(p) * (rng.random(p) < 0.1)
     y = (rng.random(n) < 1 / (1 + np.exp(-np.asarray(X @ b).ravel()))).astype(int)
     lam = np.geomspace(2e-6, 2e-4, 6)                              # increasing: smallest (hardest) lambda first
-    monkeypatch.setenv("SGDNET_NO_LMAX", "1")                      # window from the diagonal bound: ~8x too long
-    fit = sa.sgdnet(X, y, family="binomial", alpha=1.0, lambda_=lam, thresh=1e-5, standardize=False, mode="auto",
-                    maxit=300, seed=3)
+    with sa.option("window_eigenvalue", 0):                        # window from the diagonal bound: ~8x too long
+        fit = sa.sgdnet(X, y, family="binomial", alpha=1.0, lambda_=lam, thresh=1e-5, standardize=False, mode="auto",
+                        maxit=300, seed=3)
     ref = sa.sgdnet(X, y, family="binomial", alpha=1.0, lambda_=lam, thresh=1e-5, standardize=False, mode="batched",
                     batch=500, maxit=300, seed=3)
     assert np.all(fit.dev_ratio > 0.0) and np.all(np.isfinite(fit.beta))
@@ -270,7 +263,7 @@ def test_increasing_lambda_sequence_is_caught_by_the_null_model_net(sa, monkeypa
 @pytest.mark.parametrize("family,mode", [("binomial", "exact"), ("gaussian", "batched")])
 def test_large_dense_x_is_prepared_on_the_device(sa, monkeypatch, family, mode):
     """Dense matrices of >= 4M elements are standardised, multiplied for lambda_max, transposed and normed
-    on the device (dense_setup_*); the host loops (SGDNET_HOST_SETUP=1, the path small
+    on the device (dense_setup_*); the host loops (option host_setup = 1, the path small
     matrices keep because their sums run in the reference's order) must give the same fit."""
     rng = np.random.default_rng(5)
     n, p = 4100, 1000
@@ -282,8 +275,8 @@ def test_large_dense_x_is_prepared_on_the_device(sa, monkeypatch, family, mode):
     if mode == "exact":                       # one wavefront, p = 1000: keep the test short
         kw.update(nlambda=2, lambda_min_ratio=0.5, thresh=1e-4, maxit=25)
     dev = sa.sgdnet(x, y, **kw)
-    monkeypatch.setenv("SGDNET_HOST_SETUP", "1")
-    host = sa.sgdnet(x, y, **kw)
+    with sa.option("host_setup", 1):
+        host = sa.sgdnet(x, y, **kw)
     assert np.allclose(dev.lambda_, host.lambda_, rtol=1e-11) and dev.nulldev == pytest.approx(host.nulldev, rel=1e-12)
     assert np.array_equal(dev.return_codes, host.return_codes) and dev.npasses == host.npasses
     assert np.abs(dev.beta - host.beta).max() <= 1e-6 * np.abs(host.beta).max()

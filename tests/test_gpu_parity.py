@@ -1202,10 +1202,10 @@ def test_parallel_generators_reach_the_same_optimum(sa, oracle, monkeypatch):
     kw = dict(family="binomial", alpha=0.5, lambda_=[0.002], standardize=False, thresh=1e-10, maxit=3000,
               mode="batched", batch=500)
     one = sa.sgdnet(X, y, seed=4, **kw)
-    monkeypatch.setenv("SGDNET_RNG_GENERATORS", "8")
     st_a, st_b = sa.RRng(4), sa.RRng(4)
-    a = sa.sgdnet(X, y, rng=st_a, **kw)
-    b = sa.sgdnet(X, y, rng=st_b, **kw)
+    with sa.option("rng_generators", 8):
+        a = sa.sgdnet(X, y, rng=st_a, **kw)
+        b = sa.sgdnet(X, y, rng=st_b, **kw)
     assert a.return_codes[0] == 0 and abs(a.npasses - b.npasses) <= 1
     assert np.allclose(a.beta, b.beta, rtol=0, atol=1e-9)             # same streams, same fit (to summation order)
     assert np.abs(a.beta - one.beta).max() < 1e-6                     # another order, same optimum
