@@ -205,12 +205,14 @@ def main():
     shard_period = max(1, n // int(div)) if div else max(1, (n_local // max(1, V)) // 4 if V > 1 else n // 32)
     runs = merge_segments(n_local, n, V * min(batch, n_local // V), period=V * shard_period) \
         if merged_job else [n_local]
-    # One process: the sample order is R's single Mersenne-Twister stream of set.seed(config id),
-    # produced ON THE DEVICE INSIDE THE TIMED REGION, one epoch ahead on a side stream, by several
-    # generators kept on that one stream by jump-ahead (sgdnet_solver_rng_*, as sgdnet_fit_* does).
-    # N > 1: every rank's draws for all epochs are generated on the host before the timed region
-    # (the per-merge-segment layout of sharded ranks is not produced on the device yet).
-    pipe = (world == 1 and not force_merge and os.environ.get("SGDNET_BENCH_RESIDENT_STREAM") != "1")
+    # The sample order is R's single Mersenne-Twister stream of set.seed(config id + rank), produced ON THE
+    # DEVICE INSIDE THE TIMED REGION, one epoch ahead on a side stream, by several generators kept on that
+    # one stream by jump-ahead (sgdnet_solver_rng_*, as sgdnet_fit_* does) -- for every N: a sample-sharded
+    # rank gets its epoch laid out merge segment by merge segment (sgdnet_solver_rng_layout), so the
+    # N > 1 lines time the same configuration as the N = 1 line.  (The synchronous mode and
+    # SGDNET_BENCH_RESIDENT_STREAM=1 keep a host-generated resident stream.)
+    pipe = (not sync_mode and os.environ.get("SGDNET_BENCH_RESIDENT_STREAM") != "1"
+            and (not merged_job or len(set(runs[:-1])) <= 1))
     gens = int(os.environ.get("SGDNET_BENCH_RNG_GENERATORS", "0")) or (
         min(32, max(8, n_local // 300000)) if n_local >= 200000 else 1)
     if V > 1:
@@ -234,9 +236,9 @@ def main():
         stream = None if pipe else host_stream(epochs_total)
     else:
         stream = None if pipe else sa.RRng(seed + rank).stream(n_local, n_local * epochs_total)
-    bench_rng = sa.RRng(seed)
+    bench_rng = sa.RRng(seed + rank)
     if pipe:
-        S.rng_open(bench_rng, n_local, gens)
+        S.rng_open(bench_rng, n_local, gens, draws_per_run=runs[0] if (merged_job and V > 1) else 0)
     else:
         S.upload_stream(stream)
     # device-ordered merge (no host sync inside an epoch) unless SGDNET_BENCH_FUSED=0
@@ -267,7 +269,14 @@ def main():
         return sj.epoch, sh, desc, 0
 
     run_epoch, shard, merge_desc, sync_rounds = make_job("sync" if sync_mode else "avg")
-    if pipe:
+    if pipe and merged_job:
+        job_epoch = run_epoch
+
+        def run_epoch():                          # noqa: F811 -- this epoch's draws, its local runs and merges
+            shard.offset = S.rng_next()
+            job_epoch()
+            S.rng_done()
+    elif pipe:
         lb_pipe = min(batch, n_local)
 
         def run_epoch():                          # noqa: F811 -- draws of this epoch, epoch, hand the slot back
@@ -305,14 +314,17 @@ def main():
     # sync mode: this rank's share of a global batch, same (global-atomic) gather kernel as the
     # timed region; the profiled epoch runs without the exchange, the state is reset below
     local_batch = min(batch, n_local) if not sync_mode else max(1, -(-n_local // sync_rounds))
-    prof = S.profile_epoch(batch=local_batch, stream_offset=off, draws_per_epoch=n_local)
-    epoch_draws = S.get_stream(off, n_local) if pipe else stream[off:off + n_local]
+    # a sample-sharded rank profiles ONE local run (the draws between two merges are laid out per run)
+    prof_draws = runs[0] if merged_job else n_local
+    prof = S.profile_epoch(batch=min(local_batch, prof_draws), stream_offset=off, draws_per_epoch=prof_draws)
+    epoch_draws = S.get_stream(off, prof_draws) if pipe else stream[off:off + prof_draws]
     if pipe:
         S.rng_done()
     alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, epoch_draws, K)
     gather_s = prof["gather_ms"] * 1e-3
     achieved = alg_bytes_epoch / gather_s / 1e9
-    alg_all = torch.tensor([alg_bytes_epoch], dtype=torch.float64, device=red_dev)
+    alg_bytes_epoch_job = alg_bytes_epoch * (n_local / prof_draws)     # this rank's whole epoch
+    alg_all = torch.tensor([alg_bytes_epoch_job], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(alg_all, op=dist.ReduceOp.SUM)
     job_gbps = float(alg_all[0]) / (elapsed / args.steps) / 1e9
@@ -339,7 +351,8 @@ def main():
             "workload": f"{args.workload}: synthetic CSC {n}x{p}, {density:.4%} nnz, family={family}, "
                         f"alpha={mix}, lambda=1/n, intercept, standardize=FALSE",
             "mode": "batched", "batch": batch, "samples_per_gpu": n_local, "virtual_shards": V,
-            "sample_order": (f"R MT19937 set.seed({seed}), with replacement: one stream, {gens} generators kept on it by "
+            "sample_order": (f"R MT19937 set.seed({seed}{'+rank' if world > 1 else ''}), with replacement: one stream"
+                             f"{' per rank' if world > 1 else ''}, {gens} generators kept on it by "
                              "jump-ahead, generated on the device inside the timed region (one epoch ahead, side stream)"
                              if pipe else f"R MT19937 set.seed({seed}+rank [+100 shard]), with replacement, resident before the timed region"),
             "merge": merge_desc,
@@ -392,10 +405,14 @@ def main():
                 epoch_fn()
                 S.sync()
                 done = S.convergence(args.conv_thresh)
+                if world > 1:                      # one decision for all ranks (they hold the same w)
+                    flag = torch.tensor([1.0 if done else 0.0], dtype=torch.float64, device=red_dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    done = bool(flag[0] > 0.5)
                 conv_ep += 1
             tconv = time.perf_counter() - tconv
             return {"thresh": args.conv_thresh, "epochs": conv_ep, "converged": bool(done), "seconds": tconv,
-                    "deviance": S.deviance(),
+                    "deviance": S.deviance() if world == 1 else None,
                     "note": "cold start, ConvergenceCheck on the merged coefficients every epoch; "
                             "includes the per-epoch sample order and one host synchronisation per epoch"}
         crng = sa.RRng(seed + 1000 + rank)
@@ -491,6 +508,7 @@ def main():
         }
     if pipe:
         S.rng_close()
+    if pipe and not merged_job:
         # the same kernel WITHOUT the sample-order generators beside it (all 256 CUs, draws already resident):
         # `roofline.frac` above is what the timed epochs experience, this is the kernel's own figure
         try:

@@ -26,4 +26,8 @@ make -s -C oracle liboracle.so liboracle_det.so
 # mock of the R C API under tests/rmock (no R in this image): test infrastructure
 gcc -O2 -std=gnu11 -Wall -Wextra -Wno-cast-function-type -fPIC -shared -Itests/rmock/include -Iinclude -o tests/rmock/libsgdnet_shim_mock.so \
     shim/sgdnet_shim.c tests/rmock/rmock.c -L"$OUT" -lsgdnet_hip -Wl,-rpath,'$ORIGIN/../../sgdnet_amd/lib' 
+# ... and once more with the sanitizers on (CPU test of the shim's error paths: tests/test_shim_sanitizers.py)
+gcc -O1 -g -std=gnu11 -fsanitize=address,undefined -fno-omit-frame-pointer -fno-sanitize-recover=undefined -Wall -Wextra -Wno-cast-function-type \
+    -fPIC -shared -Itests/rmock/include -Iinclude -o tests/rmock/libsgdnet_shim_mock_asan.so \
+    shim/sgdnet_shim.c tests/rmock/rmock.c -L"$OUT" -lsgdnet_hip -Wl,-rpath,'$ORIGIN/../../sgdnet_amd/lib'
 echo "built $OUT/libsgdnet_hip.so"

@@ -270,7 +270,11 @@ int sgdnet_solver_sync(sgdnet_solver* s);
  *   rng_open(s, &rng, n, G); for every epoch { rng_next(s, &off); run / enqueue an epoch with
  *   stream_offset = off; rng_done(s); }  rng_close(s, &rng) -> rng = the state after exactly the
  *   epochs that were consumed (a speculative generation is discarded).
- * With virtual shards the draws come in the layout sgdnet_solver_set_virtual_shards describes. */
+ * With virtual shards the draws come in the layout sgdnet_solver_set_virtual_shards describes;
+ * sgdnet_solver_rng_layout (before rng_open) cuts an epoch into runs of draws_per_run draws -- what a
+ * sample-sharded rank does between two merges with the other ranks -- each laid out shard after
+ * shard, the last one shorter if the epoch does not divide (0: one run = the epoch). */
+int sgdnet_solver_rng_layout(sgdnet_solver* s, int64_t draws_per_run);
 int sgdnet_solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t draws_per_epoch, int generators);
 int sgdnet_solver_rng_next(sgdnet_solver* s, int64_t* stream_offset);
 int sgdnet_solver_rng_done(sgdnet_solver* s);

@@ -30,7 +30,7 @@ EXPORTS = [
     "sgdnet_solver_export_delta_weighted_async", "sgdnet_solver_set_virtual_shards", "sgdnet_solver_set_merge_period",
     "sgdnet_score_sparse", "sgdnet_score_dense", "sgdnet_predict_sparse", "sgdnet_predict_dense",
     "sgdnet_auc_sparse", "sgdnet_auc_dense",
-    "sgdnet_solver_rng_open", "sgdnet_solver_rng_next", "sgdnet_solver_rng_done", "sgdnet_solver_rng_close",
+    "sgdnet_solver_rng_layout", "sgdnet_solver_rng_open", "sgdnet_solver_rng_next", "sgdnet_solver_rng_done", "sgdnet_solver_rng_close",
 ]
 ABI_VERSION = 2   # include/sgdnet_hip.h: SGDNET_ABI_VERSION
 MEASURES = {"deviance": 0, "mse": 1, "mae": 2, "class": 3, "auc": 4}
@@ -173,6 +173,7 @@ def load():
                                    C.POINTER(Result)]
     L.sgdnet_rng_fill.argtypes = [C.POINTER(Rng), C.c_uint32, C.POINTER(C.c_uint32), C.c_int64]
     L.sgdnet_solver_rng_open.argtypes = [C.c_void_p, C.POINTER(Rng), C.c_int64, C.c_int]
+    L.sgdnet_solver_rng_layout.argtypes = [C.c_void_p, C.c_int64]
     L.sgdnet_solver_rng_next.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     L.sgdnet_solver_rng_done.argtypes = [C.c_void_p]
     L.sgdnet_solver_rng_close.argtypes = [C.c_void_p, C.POINTER(Rng)]

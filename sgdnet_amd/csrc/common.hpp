@@ -98,12 +98,11 @@ struct SagaDev {
   // compact two-plane records of the K == 1 LDS gather (saga_batched.hip) or nullptr
   char* cP;           // n x 128 B: first cE entries (16-bit feature ids), response, gradient memory
   const char* cQ;     // n x 128 B: entries cE .. cE + 11 of the rows that have them
-  const uint32_t* cmeta;  // 2 bits per sample: row longer than cE entries, response != 0
-  int cE;             // entries in plane P: 12 (binomial: the response rides in the tagged draw) or 11
+  const uint32_t* cmeta;  // 2 bits per sample: row longer than cE entries, response != 0 (binomial)
+  int cE;             // entries in plane P: 12 (binomial: the response is a bit of cmeta) or 11
   int m_rec;          // one-response sparse fits: the gradient memory is inside the records (cP + 120), not in M
   char* m_base;       // ... its address for sample s is m_base + s * m_stride: (M, 8) or (cP + 120, 128)
   int m_stride;
-  uint32_t* tstream;  // tagged draws of the current epoch: sample | long row | response | first occurrence in its batch
   // solver state (K fastest, like the reference's ArrayXXd K x p / K x n)
   double* w;
   double* G;      // g_sum
@@ -148,7 +147,6 @@ struct LamParams {
   int64_t m_full, m_tail;
   // epoch bookkeeping for graph replays
   int64_t stream_base;   // offset of the current epoch in the resident stream
-  int64_t tstream_base;  // ... and of its tagged draws in SagaDev::tstream (0 unless the sample-order pipeline tagged them ahead)
   int64_t draws_per_epoch;
   int batch_seq;         // running batch id (claims)
   // ConvergenceCheck scratch: bit patterns of max|dw| and max|w|
@@ -204,10 +202,7 @@ bool compact_eligible(const SagaDev& d);
 int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* meta, hipStream_t st);
 int compact_entries(const SagaDev& d);
 int launch_m_move(const SagaDev& d, int to_record, hipStream_t st);
-// lam != nullptr: the epoch's offsets are read on the device (captured epoch graphs); else the explicit ones
-int launch_stream_tag(const SagaDev& d, const LamParams* lam, int64_t m, int64_t draws, hipStream_t st,
-                      int64_t stream_off = 0, int64_t tstream_off = 0);
-bool tagged_gather(const SagaDev& d, int m);
+
 int launch_convergence(const SagaDev& d, LamParams* lam, hipStream_t st);
 int launch_loss(const SagaDev& d, LamParams* lam, bool sparse, hipStream_t st);
 int launch_delta_export(const SagaDev& d, const double* ref, double* out, double weight, hipStream_t st);
@@ -222,7 +217,7 @@ int launch_range_moment(const SagaDev& d, const uint16_t* feat_range, unsigned l
 size_t binned_max_range_features(int K);
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,
-                    int gens = 1);
+                    int gens = 1, int64_t run_len = 0);
 
 // jump-ahead of R's Mersenne-Twister (mt_jump.cpp, r_rng_device.hip)
 bool mt_jump_poly(uint64_t J, uint32_t* out624);

@@ -264,12 +264,14 @@ int launch_rng_jump(const uint32_t* state_in, uint32_t* state_out, const uint32_
 
 int rng_generators_per_workgroup() { return kGenPerWg; }
 
-// shards.V > 1 (virtual shards, common.hpp): the epoch's positions are split into V regions of
-// dps draws and region v draws from shard v's sample range -- lo_v + floor(size_v * u); positions
-// past V * dps (n not a multiple of V) keep the plain floor(n * u) and are not consumed
+// shards.V > 1 (virtual shards, common.hpp): the positions are laid out run by run (a run = what the shards do
+// between two merges across GPUs; one run = the whole epoch on a single GPU), and inside a run shard after
+// shard: V regions of run_len / V draws, region v drawing from shard v's sample range -- lo_v +
+// floor(size_v * u).  The last run of an epoch may be shorter.  Positions past V * (run_len / V) of a run keep
+// the plain floor(n * u) and are not consumed.
 struct RngShards {
   int V;
-  int64_t dps;
+  int64_t run;       // draws per run (the last one: what is left)
   double lo[8], size[8];
 };
 
@@ -277,22 +279,28 @@ __global__ __launch_bounds__(256) void r_mt_convert_kernel(uint32_t* out, int64_
                                                            RngShards sh) {
   const double n = (double)n_samples;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-    if (sh.V > 1 && i < sh.dps * sh.V) {
-      const int v = (int)(i / sh.dps);
-      out[i] = (uint32_t)sh.lo[v] + word_to_draw(out[i], sh.size[v]);
-    } else {
-      out[i] = word_to_draw(out[i], n);
+    if (sh.V > 1) {
+      const int64_t r = i / sh.run;
+      const int64_t j = i - r * sh.run;
+      const int64_t left = count - r * sh.run;
+      const int64_t dps = (left < sh.run ? left : sh.run) / sh.V;
+      if (dps > 0 && j < dps * sh.V) {
+        const int v = (int)(j / dps);
+        out[i] = (uint32_t)sh.lo[v] + word_to_draw(out[i], sh.size[v]);
+        continue;
+      }
     }
+    out[i] = word_to_draw(out[i], n);
   }
 }
 
 // state_in -> state_out (may alias); raw words then draws into out[0, count)
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
-                    int64_t count, hipStream_t st, int n_shards, const double* shard_size, int gens) {
+                    int64_t count, hipStream_t st, int n_shards, const double* shard_size, int gens, int64_t run_len) {
   RngShards sh{};
   sh.V = n_shards;
   if (n_shards > 1) {
-    sh.dps = count / n_shards;
+    sh.run = run_len > 0 && run_len < count ? run_len : count;
     double lo = 0.0;
     for (int v = 0; v < n_shards; ++v) {
       sh.lo[v] = lo;

@@ -509,37 +509,42 @@ __device__ __forceinline__ double k1_lanes8_draws(const SagaDev& d, const uint32
 }
 
 // --------------------------------------------------------------------------
-// Compact records (K == 1, p <= 65536) with the gradient memory inside, and a TAGGED sample order.
+// Compact records (K == 1, p <= 65536) with the gradient memory inside.
 //
-// Round 2's gather read a draw's record and then claimed / read / updated the sample's gradient memory
-// with one returning device-scope exchange on a separate 80 MB table: two random memory operations per
-// draw, the second one at the end of the dependent chain ids -> record -> x.w -> exp -> exchange.  What
-// the memory system charges for that was measured without any compute (scripts/microbench/
-// gather_patterns.hip, profiles/r03b_*): random 128-B lines 24 us per 2^20 draws, line + dependent
-// exchange 54 us, line + independent 8-byte load from a second table 45 us (ANY second random access costs
-// what the line costs: the fabric serves ~45 G requests/s whatever their size), line + an 8-byte store
-// INTO the line just read 43-49 us.  So the gradient memory of sample s now lives in the last 8 bytes of
-// the sample's own line (the read is free, the update is a plain fire-and-forget store), and what the
-// exchange also did -- give exactly one of a batch's repeated draws of a sample the change g - old, the
-// others 0 -- is decided before the gather runs: stream_tag_kernel marks the first occurrence of every
-// sample inside each batch (the sample order of an epoch exists before the epoch starts) and folds the
-// other per-sample bits the gather used to look up into the same 32-bit word.
+// Round 2's gather read a draw's record and then claimed / read / updated the sample's gradient memory with
+// one returning device-scope exchange on a separate 80 MB table.  What the memory system charges for the
+// candidates was measured without any compute (scripts/microbench/gather_patterns.hip, profiles/r03b_*,
+// r03j_*; a fresh stream segment per repetition): random 128-B lines 24 us per 2^20 draws; line + dependent
+// exchange on the separate table 54 us; line + an independent 8-byte load from a second table 45 us (ANY second
+// random access costs what the line costs: the fabric serves ~45 G requests/s whatever their size); line + the
+// same exchange aimed INTO the line just read 51.6 us; line + a plain 8-byte store into it 43-47 us.  So the
+// gradient memory of sample s lives in the last 8 bytes of the sample's own line, and the 0/1 response of a
+// binomial fit in a bit beside the long-row bit, which frees the room for a twelfth entry.
+//
+// The plain store needs to know beforehand which of a batch's repeated draws of a sample carries the change
+// (the exchange decides it on the fly: a repeat reads back the value just stored).  That was built and
+// measured -- stream_tag_kernel, a bitmap of the shard's samples in LDS, tagged draws `sample | first | long
+// | y`: the gather came down to 62-63.5 us per launch alone (from 66), but marking first occurrences is
+// 10M LDS atomics + 10M gathers per epoch on CUs that retire about one lane per clock of either: 185 us per
+// epoch as one workgroup per shard and batch, 117 + 51 us as eight sub-range workgroups per batch with dense
+// bit planes and a combine kernel, 139 us with three sub-ranges storing their words directly (partial-line
+// writes), and hidden on the sample-order side stream it took CUs from the gather (62 -> 68 us per launch).
+// The exchange INTO the record needs none of it and gives up ~2 us per launch: DESIGN.md 5 "Round 3".
 //
 //   plane P, 128 B per sample:  [ val[E] : 8 E | id[E] : 2 E (16-bit) | pad | y : 8 at 112 (E = 11) | M : 8 at 120 ]
-//       E = 12 for binomial fits (the 0/1 response rides in the tagged draw), 11 otherwise
+//       E = 12 for binomial fits (the 0/1 response is a bit of cmeta), 11 otherwise
 //   plane Q, 128 B per sample, touched only for rows with more than E entries (21 % / 30 % at 10 per row):
 //       [ nnz : 4 | - : 4 | id[12] : 24 | val[12] : 96 ]   entries E .. E + 11
 //   entries E + 12 .. of a row are read from the sample-major CSR arrays
-//   meta, 2 bits per sample: bit 0 = the row has more than E entries, bit 1 = y != 0 (binomial)
-//   tagged draw: [ 31 long row | 30 first occurrence in its batch | 29 y | 28..0 sample ]
+//   cmeta, 2 bits per sample: bit 0 = the row has more than E entries, bit 1 = y != 0 (binomial); looked up
+//       one pass ahead for sample ids requested two passes ahead, and carried in the id's spare high bits
 //
-// Lane mapping as before: lanes 0..5 of the 8-lane group hold P's entries 2 slot, 2 slot + 1, lanes 6..7
-// the first four of Q; entries E + 4 .. take the tail path.
+// Lane mapping as before: lanes 0..5 of the 8-lane group hold P's entries 2 slot, 2 slot + 1, lanes 6..7 the
+// first four of Q; entries E + 4 .. take the tail path.
 // --------------------------------------------------------------------------
 constexpr int kCQ = 12;               // entries in plane Q
 constexpr int kCYOff = 112;           // response inside plane P (E = 11)
 constexpr uint32_t kLongBit = 0x80000000u;
-constexpr uint32_t kFirstBit = 0x40000000u;
 constexpr uint32_t kYBit = 0x20000000u;
 constexpr uint32_t kIdMask = 0x1fffffffu;
 
@@ -569,7 +574,7 @@ __global__ __launch_bounds__(256) void pack_compact_kernel(const int64_t* ptr, c
       }
       bits |= 1u;
     }
-    if (y_in_tag && y[i] != 0.0) bits |= 2u;
+    if (y_in_tag && y[i] != 0.0) bits |= 2u;   // the response of a binomial fit rides in cmeta
     if (bits) atomicOr(meta + (i >> 4), bits << (2 * (i & 15)));
   }
 }
@@ -594,77 +599,6 @@ __device__ __forceinline__ void row_tail_compact(const SagaDev& d, uint32_t sid,
     } else {
       const int64_t q0 = d.ptr[sid];
       f((int64_t)d.idx[q0 + e], d.val[q0 + e]);
-    }
-  }
-}
-
-// --------------------------------------------------------------------------
-// Tagging the sample order of one epoch (or merge segment): tstream[i] = draw | long | y | first.
-// "First occurrence inside its batch" needs a set over the samples a batch can draw: a bitmap in LDS, one
-// bit per sample of a SUB-RANGE of at most kTagWords * 32 = 1 277 952 samples (a virtual shard of C4 is
-// 1 250 000).  Workgroup (sub, k, v) walks batch k of shard v and handles the draws that fall into its
-// sub-range: ds_or_rtn on the sample's bit -- whoever finds the bit clear is the first -- then writes the
-// tagged word.  Which of several equal draws wins is decided by the hardware's order, and does not matter:
-// they see the same snapshot, compute the same gradient, and exactly one of them carries the change.
-// 128 draws per thread at C4; ~80 workgroups per epoch.
-// --------------------------------------------------------------------------
-constexpr int kTagBlock = 1024;
-constexpr int kTagWords = 39936;      // 159 744 B of LDS
-
-__global__ __launch_bounds__(kTagBlock) void stream_tag_kernel(SagaDev d, const LamParams* lamp, int64_t m,
-                                                               int64_t dps, int64_t stream_off, int64_t tstream_off) {
-  extern __shared__ uint32_t bm[];
-  const int sub = blockIdx.x, k = blockIdx.y, v = blockIdx.z;
-  int64_t lo = 0, size = d.n;
-  if (d.V > 1) {
-    double lo_d = 0.0;
-    for (int q = 0; q < v; ++q) lo_d += d.v_size[q];
-    lo = (int64_t)lo_d;
-    size = (int64_t)d.v_size[v];
-  }
-  const int64_t cap = (int64_t)kTagWords * 32;
-  const int64_t r_lo = lo + (int64_t)sub * cap;
-  const int64_t r_hi = r_lo + cap < lo + size ? r_lo + cap : lo + size;
-  const int words = (int)((r_hi - r_lo + 31) >> 5);
-  for (int i = threadIdx.x; i < words; i += kTagBlock) bm[i] = 0u;
-  __syncthreads();
-  const int64_t b0 = (int64_t)k * m;
-  const int64_t cnt = dps - b0 < m ? dps - b0 : m;
-  const int64_t rel = (int64_t)v * dps + b0;
-  if (lamp) {
-    stream_off = lamp->stream_base;
-    tstream_off = lamp->tstream_base;
-  }
-  const uint32_t* __restrict__ src = d.stream + stream_off + rel;
-  uint32_t* __restrict__ dst = d.tstream + tstream_off + rel;
-  const uint32_t* __restrict__ meta = d.cmeta;
-  // kTagU draws per thread and round: their ids, then their meta words, are requested together (one draw
-  // at a time the loop is a chain of two round trips per draw: 213 us per epoch at C4 instead of ~30)
-  constexpr int kTagU = 16;
-  for (int64_t i0 = threadIdx.x; i0 < cnt; i0 += (int64_t)kTagBlock * kTagU) {
-    uint32_t sv[kTagU], mt[kTagU];
-    bool in[kTagU];
-#pragma unroll
-    for (int u = 0; u < kTagU; ++u) {
-      const int64_t i = i0 + (int64_t)u * kTagBlock;
-      sv[u] = i < cnt ? src[i] : 0xffffffffu;
-    }
-#pragma unroll
-    for (int u = 0; u < kTagU; ++u) {
-      in[u] = (int64_t)sv[u] >= r_lo && (int64_t)sv[u] < r_hi;
-      mt[u] = in[u] ? meta[sv[u] >> 4] : 0u;
-    }
-#pragma unroll
-    for (int u = 0; u < kTagU; ++u) {
-      if (in[u]) {
-        const uint32_t s = sv[u];
-        const uint32_t o = (uint32_t)((int64_t)s - r_lo);
-        const uint32_t bit = 1u << (o & 31);
-        const uint32_t old = __hip_atomic_fetch_or(bm + (o >> 5), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const uint32_t mb = (mt[u] >> (2 * (s & 15))) & 3u;
-        dst[i0 + (int64_t)u * kTagBlock] =
-            s | ((mb & 1u) ? kLongBit : 0u) | ((mb & 2u) ? kYBit : 0u) | ((old & bit) ? 0u : kFirstBit);
-      }
     }
   }
 }
@@ -706,141 +640,167 @@ struct TicketSource {
   }
 };
 
-// sp: the TAGGED draws of this workgroup's shard-batch (stream_tag_kernel)
-__device__ __forceinline__ double k1_lanes8_tagged(const SagaDev& d, const uint32_t* sp, int m, int blk, int nblk,
-                                                   int* ticket_counter, double b0, const double* wv, double* Dl) {
+// The K == 1 compact gather of one workgroup over the draws sp[0, m) of its shard-batch.  The kernel runs it in
+// three steps so that the first round trips of a workgroup overlap the staging of w into LDS instead of
+// following it: begin() (static tickets for every wavefront's first two passes, their sample ids requested)
+// before the staging, tag_first() (the first pass's cmeta bits) behind it, run() after the workgroup's barrier.
+// (Also requesting the first pass's records before the barrier, with the loop's record loads moved to its end,
+// carries one pass's registers across the back edge: 128 VGPRs and 112 bytes of scratch.)
+struct K1Compact {
   typedef double dpair_t __attribute__((ext_vector_type(2)));
-  constexpr int U = 4;
-  const int E = d.cE;                           // entries in plane P: 12 (response in the tag) or 11
-  const int in_reg = E + 4;                     // entries of a row held in registers
-  const bool y_in_tag = E == 12;
-  const int gl = threadIdx.x & (kLanes8 - 1);
-  const int g = (threadIdx.x & 63) >> 3;        // group inside the wavefront
-  const int q = gl >> 1;
-  const bool is_owner = (gl & 1) == 0;
-  const bool in_p = gl < 6;                     // this lane's two entries come from plane P
-  const int slot = in_p ? gl : gl - 6;
-  char* const P = d.cP;
-  const char* plane = in_p ? d.cP : d.cQ;
-  const int id_off = in_p ? 8 * E + 4 * slot : 8 + 4 * slot;
-  const int v_off = in_p ? 16 * slot : 32 + 16 * slot;
-  const bool half = in_p && slot == 5 && E == 11;   // entry 11 of plane P does not exist: the bytes are ids and pad
-  double gct = 0.0;
+  static constexpr int U = 4;
+  // lane geometry
+  int E, in_reg, gl, g, q, slot, id_off, v_off;
+  bool y_in_meta, is_owner, in_p, half;
+  const char* plane;
+  char* P;
+  const uint32_t* sp;
+  const uint32_t* meta;
+  int m;
   TicketSource tk;
-  {
+  int b_cur, b_nxt;
+  uint32_t s_cur, s_nxt;      // s_cur: tagged (long row, response); s_nxt: as read from the stream
+
+  __device__ __forceinline__ int own_pos(int base) const { return base + U * g + q < m ? base + U * g + q : base; }
+  __device__ __forceinline__ uint32_t tagged(uint32_t sid) const {
+    const uint32_t mb = (meta[sid >> 4] >> (2 * (sid & 15))) & 3u;
+    return sid | ((mb & 1u) ? kLongBit : 0u) | ((mb & 2u) ? kYBit : 0u);
+  }
+  // tickets handed out before the LDS counter exists: two per wavefront (the counter starts behind them)
+  static __device__ __forceinline__ int static_tickets() { return 2 * (kLdsBlock / 64) * kTicket; }
+
+  __device__ __forceinline__ void begin(const SagaDev& d, const uint32_t* sp_, int m_, int blk, int nblk,
+                                        int* ticket_counter) {
+    E = d.cE;                                     // entries in plane P: 12 (response in cmeta) or 11
+    in_reg = E + 4;                               // entries of a row held in registers
+    y_in_meta = E == 12;
+    gl = threadIdx.x & (kLanes8 - 1);
+    g = (threadIdx.x & 63) >> 3;                  // group inside the wavefront
+    q = gl >> 1;
+    is_owner = (gl & 1) == 0;
+    in_p = gl < 6;                                // this lane's two entries come from plane P
+    slot = in_p ? gl : gl - 6;
+    P = d.cP;
+    plane = in_p ? d.cP : d.cQ;
+    id_off = in_p ? 8 * E + 4 * slot : 8 + 4 * slot;
+    v_off = in_p ? 16 * slot : 32 + 16 * slot;
+    half = in_p && slot == 5 && E == 11;          // entry 11 of plane P does not exist: the bytes are ids and pad
+    sp = sp_;
+    meta = d.cmeta;
+    m = m_;
     const int share = ((m + nblk - 1) / nblk + kTicket - 1) / kTicket * kTicket;
     tk.counter = ticket_counter;
     tk.lo = blk * share;
     tk.hi = tk.lo + share < m ? tk.lo + share : m;
     tk.m = m;
     tk.dynamic = share >= 4 * (kLdsBlock / 64) * kTicket;
+    tk.t = 2;
+    const int wave = (int)(threadIdx.x >> 6);
+    b_cur = tk.lo + wave * kTicket;
+    b_nxt = tk.lo + ((kLdsBlock / 64) + wave) * kTicket;
+    if (b_cur >= tk.hi) b_cur = m;
+    if (b_nxt >= tk.hi) b_nxt = m;
+    s_cur = b_cur < m ? sp[own_pos(b_cur)] : 0u;
+    s_nxt = b_nxt < m ? sp[own_pos(b_nxt)] : 0u;
   }
-  // this lane's own draw of the pass whose ticket is `base` (positions past the end stand in with
-  // the ticket's first draw and are discarded)
-  auto own_pos = [&](int base) { return base + U * g + q < m ? base + U * g + q : base; };
-  int b_cur = tk.next();
-  if (b_cur >= m) return 0.0;
-  int b_nxt = tk.next();
-  uint32_t s_cur = sp[own_pos(b_cur)];
-  uint32_t s_nxt = b_nxt < m ? sp[own_pos(b_nxt)] : 0u;
-  while (b_cur < m) {
-    const bool v_own = b_cur + U * g + q < m;
-    uint32_t su[U];
+
+  __device__ __forceinline__ void tag_first() {
+    if (b_cur < m) s_cur = tagged(s_cur);
+  }
+
+  // all passes of this wavefront; returns the sum of the gradient changes of the draws this lane owns
+  __device__ __forceinline__ double run(const SagaDev& d, double b0, const double* wv, double* Dl) {
+    double gct = 0.0;
+    while (b_cur < m) {
+      const bool v_own = b_cur + U * g + q < m;
+      uint32_t su[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) su[u] = (uint32_t)__shfl((int)s_cur, 2 * u, kLanes8);
-    const uint32_t s_this = s_cur & kIdMask;
-    const bool long_own = (s_cur & kLongBit) != 0;
-    const bool first_own = (s_cur & kFirstBit) != 0;
-    // the owner's header: old gradient (and the response) from the line the group's entry loads fetch
-    char* const own_line = P + (size_t)s_this * kCStride;
-    double m_old = 0.0, y_own = (s_cur & kYBit) ? 1.0 : 0.0;
-    if (is_owner) {
-      if (y_in_tag) {
-        m_old = *reinterpret_cast<const double*>(own_line + kCMOff);
-      } else {
-        const dpair_t h = *reinterpret_cast<const dpair_t*>(own_line + kCYOff);
-        y_own = h.x;
-        m_old = h.y;
-      }
-    }
-    int nnz_own = 0;
-    if (long_own) nnz_own = *reinterpret_cast<const int*>(d.cQ + (size_t)s_this * kCStride);
-    uint32_t jf[U];
-    dpair_t vf[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const bool on = in_p || (su[u] & kLongBit) != 0;
-      const char* base = plane + (size_t)(su[u] & kIdMask) * kCStride;
-      jf[u] = 0u;
-      vf[u] = dpair_t{0.0, 0.0};
-      if (on) {
-        jf[u] = *reinterpret_cast<const uint32_t*>(base + id_off);
-        vf[u] = *reinterpret_cast<const dpair_t*>(base + v_off);
-      }
-    }
-    // tagged draws of the pass after the next one: requested before this pass's records are waited for
-    const int b_nn = b_nxt < m ? tk.next() : m;
-    uint32_t s_nn = 0u;
-    if (b_nn < m) s_nn = sp[own_pos(b_nn)];
-    if (half) {
+      for (int u = 0; u < U; ++u) su[u] = (uint32_t)__shfl((int)s_cur, 2 * u, kLanes8);
+      const uint32_t s_this = s_cur & kIdMask;
+      double y_own = (s_cur & kYBit) ? 1.0 : 0.0;
+      if (!y_in_meta) y_own = *reinterpret_cast<const double*>(P + (size_t)s_this * kCStride + kCYOff);
+      int nnz_own = 0;
+      if (s_cur & kLongBit) nnz_own = *reinterpret_cast<const int*>(d.cQ + (size_t)s_this * kCStride);
+      uint32_t jf[U];
+      dpair_t vf[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        vf[u].y = 0.0;
-        jf[u] &= 0xffffu;
-      }
-    }
-    double acc[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) acc[u] = vf[u].x * wv[jf[u] & 0xffffu] + vf[u].y * wv[jf[u] >> 16];
-    const bool own_tail = v_own && nnz_own > in_reg;
-    const bool any_tail = __ballot(own_tail) != 0;
-    if (any_tail) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int nz = __shfl(own_tail ? nnz_own : 0, 2 * u, kLanes8);
-        if (nz > in_reg) {
-          double a = 0.0;
-          row_tail_compact(d, su[u] & kIdMask, nz, gl, E, [&](int64_t j, double v) { a += v * wv[j]; });
-          acc[u] += a;
+        const bool on = in_p || (su[u] & kLongBit) != 0;
+        const char* base = plane + (size_t)(su[u] & kIdMask) * kCStride;
+        jf[u] = 0u;
+        vf[u] = dpair_t{0.0, 0.0};
+        if (on) {
+          jf[u] = *reinterpret_cast<const uint32_t*>(base + id_off);
+          vf[u] = *reinterpret_cast<const dpair_t*>(base + v_off);
         }
       }
-    }
-    const bool hi4 = (gl & 4) != 0, hi2 = (gl & 2) != 0;
-    const double r0 = (hi4 ? acc[2] : acc[0]) + __shfl_xor(hi4 ? acc[0] : acc[2], 4, kLanes8);
-    const double r1 = (hi4 ? acc[3] : acc[1]) + __shfl_xor(hi4 ? acc[1] : acc[3], 4, kLanes8);
-    double t = (hi2 ? r1 : r0) + __shfl_xor(hi2 ? r0 : r1, 2, kLanes8);
-    t += __shfl_xor(t, 1, kLanes8);
-    const double lp = t + b0;
-    const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y_own - 1.0 / (1.0 + exp(lp)) : lp - y_own;
-    double gcp = 0.0;
-    if (is_owner && v_own && first_own) {
-      // the batch's one carrier of this sample's change (src/saga-sparse.h:281-282); its repeats, marked
-      // by the tag, change nothing and write nothing (they would store the same g0)
-      gcp = g0 - m_old;
-      *reinterpret_cast<double*>(own_line + kCMOff) = g0;
-    }
+      // sample ids two passes ahead, their cmeta bits one pass ahead
+      const int b_nn = b_nxt < m ? tk.next() : m;
+      uint32_t s_nn = 0u;
+      if (b_nn < m) s_nn = sp[own_pos(b_nn)];
+      if (b_nxt < m) s_nxt = tagged(s_nxt);
+      if (half) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const double gc = __shfl(gcp, 2 * u, kLanes8);
-      if (gc != 0.0) {
-        if (vf[u].x != 0.0) scatter_add<true>(Dl + (jf[u] & 0xffffu), vf[u].x * gc);
-        if (vf[u].y != 0.0) scatter_add<true>(Dl + (jf[u] >> 16), vf[u].y * gc);
-        if (any_tail) {
+        for (int u = 0; u < U; ++u) {
+          vf[u].y = 0.0;
+          jf[u] &= 0xffffu;
+        }
+      }
+      double acc[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = vf[u].x * wv[jf[u] & 0xffffu] + vf[u].y * wv[jf[u] >> 16];
+      const bool own_tail = v_own && nnz_own > in_reg;
+      const bool any_tail = __ballot(own_tail) != 0;
+      if (any_tail) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
           const int nz = __shfl(own_tail ? nnz_own : 0, 2 * u, kLanes8);
-          if (nz > in_reg)
-            row_tail_compact(d, su[u] & kIdMask, nz, gl, E,
-                             [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
+          if (nz > in_reg) {
+            double a = 0.0;
+            row_tail_compact(d, su[u] & kIdMask, nz, gl, E, [&](int64_t j, double v) { a += v * wv[j]; });
+            acc[u] += a;
+          }
         }
       }
+      const bool hi4 = (gl & 4) != 0, hi2 = (gl & 2) != 0;
+      const double r0 = (hi4 ? acc[2] : acc[0]) + __shfl_xor(hi4 ? acc[0] : acc[2], 4, kLanes8);
+      const double r1 = (hi4 ? acc[3] : acc[1]) + __shfl_xor(hi4 ? acc[1] : acc[3], 4, kLanes8);
+      double t = (hi2 ? r1 : r0) + __shfl_xor(hi2 ? r0 : r1, 2, kLanes8);
+      t += __shfl_xor(t, 1, kLanes8);
+      const double lp = t + b0;
+      const double g0 = d.family == SGDNET_BINOMIAL ? 1.0 - y_own - 1.0 / (1.0 + exp(lp)) : lp - y_own;
+      double gcp = 0.0;
+      if (is_owner && v_own) {
+        // claim, read and update in ONE returning atomic on the line the records came from: a repeated draw of
+        // the batch reads back the value just stored (same snapshot, same g0), so its gc is exactly 0
+        // (src/saga-sparse.h:281-282)
+        const double old = __hip_atomic_exchange(reinterpret_cast<double*>(P + (size_t)s_this * kCStride + kCMOff), g0,
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        gcp = g0 - old;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const double gc = __shfl(gcp, 2 * u, kLanes8);
+        if (gc != 0.0) {
+          if (vf[u].x != 0.0) scatter_add<true>(Dl + (jf[u] & 0xffffu), vf[u].x * gc);
+          if (vf[u].y != 0.0) scatter_add<true>(Dl + (jf[u] >> 16), vf[u].y * gc);
+          if (any_tail) {
+            const int nz = __shfl(own_tail ? nnz_own : 0, 2 * u, kLanes8);
+            if (nz > in_reg)
+              row_tail_compact(d, su[u] & kIdMask, nz, gl, E,
+                               [&](int64_t j, double v) { scatter_add<true>(Dl + j, v * gc); });
+          }
+        }
+      }
+      gct += gcp;
+      s_cur = s_nxt;
+      s_nxt = s_nn;
+      b_cur = b_nxt;
+      b_nxt = b_nn;
     }
-    gct += gcp;
-    s_cur = s_nxt;
-    s_nxt = s_nn;
-    b_cur = b_nxt;
-    b_nxt = b_nn;
+    return gct;
   }
-  return gct;
-}
+};
 
 template <int U>
 struct K1IdsOnly {
@@ -1031,10 +991,17 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   const int K = KMAX == 1 ? 1 : d.K;
   const int64_t KP = (int64_t)K * d.p;
   __shared__ int ticket_counter;             // work tickets of the compact K == 1 form
-  if (threadIdx.x == 0) ticket_counter = 0;
   const int vsh = kVS ? (int)blockIdx.x / d.v_bps : 0;          // this workgroup's shard
   const int vblk = kVS ? (int)blockIdx.x - vsh * d.v_bps : (int)blockIdx.x;
   const double* w_src = kVS ? d.vw + (int64_t)vsh * KP : d.w;
+  // compact K == 1 form: the sample ids of every wavefront's first two passes are requested before anything else
+  constexpr bool kCompactForm = KMAX == 1 && kLanes == kLanes8;
+  const bool compact = kCompactForm && d.cP != nullptr;
+  K1Compact cg;
+  if (threadIdx.x == 0) ticket_counter = compact ? K1Compact::static_tickets() : 0;
+  if (compact)
+    cg.begin(d, d.stream + lamp->stream_base + t0_in_epoch + (kVS ? (int64_t)vsh * d.v_dps : 0), m, vblk,
+             kVS ? d.v_bps : (int)gridDim.x, &ticket_counter);
   PHASE(0);
   // the tables are moved as 16-byte pairs (half the instructions of a double-wise loop: the
   // kernel is bound by the instructions it issues as much as by memory); an odd last element
@@ -1049,7 +1016,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   if (kWLds) {
     // all loads of a thread in flight before its first LDS store (a plain copy loop waits for
     // every load in turn)
-    constexpr int kStage = 4;
+    constexpr int kStage = 8;                   // one round of loads for up to 16 384 coefficients
     double* Wl = Dl + KP + (KP & 1);            // 16-byte aligned
     const pair_t* w2 = reinterpret_cast<const pair_t*>(w_src);
     pair_t* W2 = reinterpret_cast<pair_t*>(Wl);
@@ -1068,6 +1035,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     }
     if ((KP & 1) && threadIdx.x == 0) Wl[KP - 1] = w_src[KP - 1];
   }
+  if (compact) cg.tag_first();                 // the ids have arrived behind the staging loads
   __syncthreads();
   PHASE(1);
 
@@ -1099,10 +1067,8 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     const double* wv = kWLds ? Dl + KP + (KP & 1) : d.w;
     const uint32_t* sp = d.stream + t0;
     if constexpr (kLanes == kLanes8) {
-      if (d.cP)    // tagged draws of this epoch (stream_tag_kernel), positions relative to the epoch's start
-        gct[0] = k1_lanes8_tagged(d, d.tstream + lamp->tstream_base + (t0 - lamp->stream_base), m, vblk,
-                                  kVS ? d.v_bps : (int)gridDim.x,
-                                  &ticket_counter, bk[0], wv, Dl);
+      if (compact)
+        gct[0] = cg.run(d, bk[0], wv, Dl);
       else
         gct[0] = k1_lanes8_draws<kLdsBlock>(d, sp, lo, hi, bk[0], wv, Dl);
     } else if (lo + group < hi) {
@@ -2635,14 +2601,6 @@ static bool lanes8_ok(const SagaDev& d) {
   return allow && (d.cP || d.rec_cap >= kInReg8) && !SGD_ABLATE(d, ~0);
 }
 
-// does the gather of an m-draw batch read the tagged sample order (k1_lanes8_tagged)?
-bool tagged_gather(const SagaDev& d, int m) {
-  if (!d.cP || d.K != 1 || d.xd || !lanes8_ok(d)) return false;
-  if (d.V > 1 && vs_eligible(d, m)) return true;
-  const GatherPlan g = plan_gather(d, m);
-  return g.lds && g.w_lds;
-}
-
 // Compact planes for a K == 1 sparse problem (d.ptr / d.idx / d.val / d.y resident).
 bool compact_eligible(const SagaDev& d) {
   static const int allow = exp_env_int("SGDNET_COMPACT", 1);
@@ -2668,41 +2626,6 @@ int launch_m_move(const SagaDev& d, int to_record, hipStream_t st) {
   int64_t grid = (d.n + 255) / 256;
   if (grid > 16384) grid = 16384;
   hipLaunchKernelGGL(m_move_kernel, dim3((unsigned)grid), dim3(256), 0, st, d, to_record);
-  SGD_HIP_TRY(hipGetLastError());
-  return SGDNET_OK;
-}
-
-// the tagged sample order of one epoch of `draws` draws in batches of m (dps: draws per virtual shard)
-int launch_stream_tag(const SagaDev& d, const LamParams* lam, int64_t m, int64_t draws, hipStream_t st,
-                      int64_t stream_off, int64_t tstream_off) {
-  static bool attr_done_dev[64] = {};
-  int cur = 0;
-  (void)hipGetDevice(&cur);
-  const size_t lds = sizeof(uint32_t) * (size_t)kTagWords;
-  if (!attr_done_dev[cur & 63]) {
-    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(stream_tag_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_done_dev[cur & 63] = true;
-  }
-  const int V = d.V > 1 ? d.V : 1;
-  const int64_t dps = d.V > 1 ? draws / V : draws;
-  if (m > dps) m = dps;
-  if (m < 1 || dps < 1) return SGDNET_OK;
-  double widest = (double)d.n;
-  if (d.V > 1) {
-    widest = 0.0;
-    for (int v = 0; v < V; ++v) widest = d.v_size[v] > widest ? d.v_size[v] : widest;
-  }
-  const int64_t cap = (int64_t)kTagWords * 32;
-  const int64_t n_sub = ((int64_t)widest + cap - 1) / cap;
-  const int64_t nb = (dps + m - 1) / m;
-  if (nb > 65535 || n_sub > 65535) {
-    set_error("internal: sample-order tagging of %lld batches", (long long)nb);
-    return SGDNET_EINVAL;
-  }
-  const int64_t words = ((int64_t)widest < cap ? (int64_t)widest : cap) / 32 + 2;
-  hipLaunchKernelGGL(stream_tag_kernel, dim3((unsigned)(n_sub < 1 ? 1 : n_sub), (unsigned)nb, (unsigned)V), dim3(kTagBlock),
-                     sizeof(uint32_t) * (size_t)words, st, d, lam, m, dps, stream_off, tstream_off);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

@@ -79,19 +79,14 @@ struct sgdnet_solver {
     // kernel leaves go to `ends` and are not used
     uint32_t* poly_n = nullptr;
     uint32_t* ends = nullptr;
-    // the shape (window, draws per epoch) each slot's draws were TAGGED for on the side stream (0: not tagged)
-    int64_t tag_m[2] = {0, 0}, tag_draws[2] = {0, 0};
+    int64_t run_len = 0;   // virtual shards: draws per run of the layout (0: one run = the epoch)
   } pipe;
-  // the epoch being consumed: where its draws are, and the shape they were tagged for ahead of time
-  int64_t acq_off = -1, acq_tag_m = 0, acq_tag_draws = 0;
-  bool pretagged = false;        // the epoch graph selected by ensure_graph skips the tagging launch
   int64_t nnz = 0;
   bool penalty_set = false;
   // cached epoch graph
   // captured epochs, one per (batch, draws) shape; gexec is the one selected by ensure_graph
   struct GraphEntry {
     int64_t batch, draws;
-    bool pretagged;
     hipGraph_t graph;
     hipGraphExec_t exec;
   };
@@ -116,7 +111,6 @@ struct sgdnet_solver {
   // one-response sparse fits with compact records: the batched kernels keep the gradient memory inside the
   // records (saga_batched.hip "Compact records"), everything else (exact mode, the host) sees the K x n array
   bool m_in_rec = false;
-  int64_t tstream_cap = 0;       // words of the tagged-draw buffer (one epoch)
 };
 
 namespace {
@@ -208,33 +202,6 @@ int m_to_array(sgdnet_solver* s) {
   s->d.m_stride = 8;
   drop_graph(s);
   return SGDNET_OK;
-}
-
-// the tagged-draw buffer covers one epoch of `draws` draws
-int ensure_tstream(sgdnet_solver* s, int64_t draws) {
-  if (!s->d.cP) return SGDNET_OK;
-  if (s->pipe.open && 2 * s->pipe.n > draws) draws = 2 * s->pipe.n;   // the pipeline tags both of its slots
-  if (draws + 64 <= s->tstream_cap) return SGDNET_OK;
-  SGD_HIP_TRY(hipStreamSynchronize(s->st));
-  if (s->pipe.st) SGD_HIP_TRY(hipStreamSynchronize(s->pipe.st));
-  if (s->d.tstream) SGD_HIP_TRY(hipFree(s->d.tstream));
-  s->d.tstream = nullptr;
-  SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d.tstream), sizeof(uint32_t) * (size_t)(draws + 64)));
-  SGD_HIP_TRY(hipMemsetAsync(s->d.tstream, 0, sizeof(uint32_t) * (size_t)(draws + 64), s->st));
-  SGD_HIP_TRY(hipStreamSynchronize(s->st));
-  s->tstream_cap = draws + 64;
-  s->pipe.tag_m[0] = s->pipe.tag_m[1] = 0;
-  s->acq_tag_m = 0;
-  drop_graph(s);
-  return SGDNET_OK;
-}
-
-// Was the epoch at `stream_offset` tagged ahead of time (sample-order pipeline) for the shape set_batch_shape
-// has just put into lam?  Sets lam.tstream_base and the graph variant.
-void select_tagging(sgdnet_solver* s, int64_t stream_offset, int64_t draws) {
-  s->pretagged = s->pipe.open && stream_offset == s->acq_off && s->acq_tag_m == s->lam.m_full && s->acq_tag_m > 0 &&
-                 s->acq_tag_draws == draws;
-  s->lam.tstream_base = s->pretagged ? stream_offset : 0;
 }
 
 // Binned form of the batched iteration for K x p tables that fit no LDS (saga_batched.hip
@@ -394,9 +361,8 @@ int ensure_dense_tiled(sgdnet_solver* s, int64_t batch) {
 int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   {
-    int rct = ensure_tstream(s, draws);
-    if (!rct) rct = m_to_record(s);          // batched kernels: the gradient memory rides in the records
-    if (rct) return rct;
+    const int rcm = m_to_record(s);          // batched kernels: the gradient memory rides in the records
+    if (rcm) return rcm;
   }
   if (s->d.V > 1 && vs_eligible(s->d, (int)batch)) {
     // per-shard batches; the scratch is sized for the launch that carries V of them
@@ -474,12 +440,7 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
   if (batch > dps) batch = dps;
   const int nb = n_batches(batch, dps);
   const int every = vs_merge_batches(s, batch);
-  int rc = SGDNET_OK;
-  if (tagged_gather(d, (int)batch) && !s->pretagged) {
-    rc = launch_stream_tag(d, s->lam_dev, batch, draws, s->st);
-    if (rc) return rc;
-  }
-  rc = launch_vs_broadcast(d, s->st);
+  int rc = launch_vs_broadcast(d, s->st);
   if (rc) return rc;
   rc = launch_vs_cw(d, s->st);
   if (rc) return rc;
@@ -524,13 +485,6 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
     const int rcw = launch_wpad_refresh(s->d, s->st);
     if (rcw) return rcw;
   }
-  {
-    const int64_t tail_m = draws - (draws / batch) * batch;
-    if (!s->pretagged && (tagged_gather(s->d, (int)batch) || (tail_m > 0 && tagged_gather(s->d, (int)tail_m)))) {
-      const int rct = launch_stream_tag(s->d, s->lam_dev, batch, draws, s->st);
-      if (rct) return rct;
-    }
-  }
   for (int k = 0; k < nb; ++k) {
     const int64_t t0 = (int64_t)k * batch;
     const int64_t m = (draws - t0 < batch) ? draws - t0 : batch;
@@ -562,11 +516,11 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
 
 int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
   for (auto& g : s->graphs)
-    if (g.batch == batch && g.draws == draws && g.pretagged == s->pretagged) {
+    if (g.batch == batch && g.draws == draws) {
       s->gexec = g.exec;
       return SGDNET_OK;
     }
-  if (s->graphs.size() >= 6) {   // a sharded epoch uses at most two shapes (segments + remainder), tagged ahead or not
+  if (s->graphs.size() >= 4) {   // a sharded epoch uses at most two shapes (segments + remainder)
     auto& old = s->graphs.front();
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     (void)hipGraphExecDestroy(old.exec);
@@ -592,7 +546,7 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return SGDNET_EHIP;
   }
-  s->graphs.push_back({batch, draws, s->pretagged, g, ex});
+  s->graphs.push_back({batch, draws, g, ex});
   s->gexec = ex;
   return SGDNET_OK;
 }
@@ -1034,7 +988,6 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
   if (s->d.slab) (void)hipFree(s->d.slab);
-  if (s->d.tstream) (void)hipFree(s->d.tstream);
   for (void* q : s->bin_bufs)
     if (q) (void)hipFree(q);
   for (void* q : s->vs_owned) (void)hipFree(q);
@@ -1163,6 +1116,16 @@ int sgdnet_solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t draws_per_
   int rc = solver_rng_open(s, rng, draws_per_epoch, generators);
   if (rc) return rc;
   return solver_rng_prefetch(s);
+}
+
+int sgdnet_solver_rng_layout(sgdnet_solver* s, int64_t draws_per_run) {
+  if (!s || draws_per_run < 0) return SGDNET_EINVAL;
+  if (s->pipe.open) {
+    set_error("sgdnet_solver_rng_layout: set the layout before sgdnet_solver_rng_open");
+    return SGDNET_EINVAL;
+  }
+  s->pipe.run_len = draws_per_run;
+  return SGDNET_OK;
 }
 
 int sgdnet_solver_rng_next(sgdnet_solver* s, int64_t* stream_offset) {
@@ -1301,11 +1264,8 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   P.G = generators;
   {
     // the generators' workgroups get CUs of their own: the LDS gather forms shrink their grids
-    // ... kGenPerWg generators share a workgroup; where the side stream also tags the draws for the LDS gather
-    // (one 160-KB-LDS workgroup per shard and batch) it gets 16 CUs: ~0.5 ms of side work per C4 epoch
     const int per_wg = rng_generators_per_workgroup();
-    int reserve = generators > 1 ? (generators + per_wg - 1) / per_wg : 0;
-    if (reserve > 0 && s->d.cP && reserve < 16) reserve = 16;
+    const int reserve = generators > 1 ? (generators + per_wg - 1) / per_wg : 0;
     if (reserve != s->d.cu_reserve) {
       SGD_HIP_TRY(hipStreamSynchronize(s->st));
       s->d.cu_reserve = reserve;
@@ -1331,11 +1291,8 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   for (int i = 0; i < 2; ++i) SGD_HIP_TRY(hipEventRecord(P.freed[i], s->st));
   P.n = n;
   P.gens = P.used = 0;
-  P.tag_m[0] = P.tag_m[1] = 0;
-  s->acq_off = -1;
-  s->acq_tag_m = 0;
   P.open = true;
-  return ensure_tstream(s, 2 * n);
+  return SGDNET_OK;
 }
 
 // enqueue the next generation (never more than one ahead of the epoch being consumed)
@@ -1348,27 +1305,16 @@ int solver_rng_prefetch(sgdnet_solver* s) {
   int rc;
   if (P.G > 1) {
     rc = launch_rng_fill(P.state[P.gens & 1], P.ends, (uint32_t)s->d.n, s->stream_dev + (int64_t)slot * P.n, P.n,
-                         P.st, s->d.V, s->d.v_size, P.G);
+                         P.st, s->d.V, s->d.v_size, P.G, P.run_len);
     // the jump's workgroups take their generators in turn: the side stream never holds more CUs than
     // the generators' own (a wider launch would push gather workgroups into a second round)
     if (!rc) rc = launch_rng_jump(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], P.poly_n, P.G, P.st,
                                   std::max(1, s->d.cu_reserve));
   } else {
     rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
-                         s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G);
+                         s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G, P.run_len);
   }
   if (rc) return rc;
-  // ... and, for the one-response LDS gather, the tags of those draws (first occurrence inside each batch, long
-  // row, response: saga_batched.hip) for the shape the last run used; an epoch that runs with another window
-  // is tagged again on the solver's stream
-  P.tag_m[slot] = P.tag_draws[slot] = 0;
-  if (s->d.cP && s->d.tstream && s->tstream_cap >= 2 * P.n && s->lam.m_full > 0 && s->lam.draws_per_epoch == P.n &&
-      tagged_gather(s->d, (int)s->lam.m_full)) {
-    rc = launch_stream_tag(s->d, nullptr, s->lam.m_full, P.n, P.st, (int64_t)slot * P.n, (int64_t)slot * P.n);
-    if (rc) return rc;
-    P.tag_m[slot] = s->lam.m_full;
-    P.tag_draws[slot] = P.n;
-  }
   SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
   ++P.gens;
   return SGDNET_OK;
@@ -1381,9 +1327,6 @@ int solver_rng_acquire(sgdnet_solver* s, int64_t* offset) {
   const int slot = (int)(P.used & 1);
   SGD_HIP_TRY(hipStreamWaitEvent(s->st, P.ready[slot], 0));
   *offset = (int64_t)slot * P.n;
-  s->acq_off = *offset;
-  s->acq_tag_m = P.tag_m[slot];
-  s->acq_tag_draws = P.tag_draws[slot];
   return SGDNET_OK;
 }
 
@@ -1513,7 +1456,6 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     rc = set_batch_shape(s, batch, draws_per_epoch);
     if (rc) return rc;
     s->lam.stream_base = stream_offset;
-    select_tagging(s, stream_offset, draws_per_epoch);
     rc = push_lam(s);
     if (rc) return rc;
     if (s->d.standardize) {
@@ -1586,7 +1528,6 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   rc = set_batch_shape(s, batch, draws_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
-  select_tagging(s, n_epochs == 1 ? stream_offset : -2, draws_per_epoch);
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1644,7 +1585,6 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   rc = set_batch_shape(s, batch, draws_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
-  select_tagging(s, stream_offset, draws_per_epoch);
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1874,8 +1814,6 @@ int sgdnet_solver_sync_begin(sgdnet_solver* s, int64_t stream_offset, int64_t dr
   int rc = check_stream(s, stream_offset, draws_local_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
-  s->lam.tstream_base = 0;
-  s->pretagged = false;
   s->lam.draws_per_epoch = draws_local_per_epoch;
   rc = push_lam(s);
   if (rc) return rc;

@@ -197,8 +197,11 @@ class SagaSolver:
         self.stream_len = count
 
     # ---- the device-side sample-order pipeline (sgdnet_solver_rng_*) ----
-    def rng_open(self, rrng, draws_per_epoch=None, generators=1):
+    def rng_open(self, rrng, draws_per_epoch=None, generators=1, draws_per_run=0):
+        """draws_per_run (virtual shards on a sample-sharded rank): the epoch is laid out run by run, every
+        run shard after shard (sgdnet_solver_rng_layout); 0: one run = the epoch."""
         self._rrng = rrng
+        check(self._L.sgdnet_solver_rng_layout(self._h, int(draws_per_run)))
         check(self._L.sgdnet_solver_rng_open(self._h, C.byref(rrng.state),
                                              self.n if draws_per_epoch is None else draws_per_epoch, generators))
 

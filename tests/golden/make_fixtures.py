@@ -113,6 +113,11 @@ def abalone():
     return x, y, names
 
 
+def abalone_libsvm_layout(x9):
+    """4177 x 9 in-repo frame -> the 4177 x 8 libsvm table it was made from."""
+    return np.column_stack([1.0 + x9[:, 0] + 2.0 * x9[:, 1], x9[:, 2:]])
+
+
 def main():
     from oracle import pyoracle as po
     from sklearn.datasets import load_iris
@@ -127,6 +132,20 @@ def main():
                         a0=fit["a0"], beta=fit["beta"], lambda_=fit["lambda"],
                         dev_ratio=fit["dev_ratio"], npasses=fit["npasses"], nulldev=fit["nulldev"],
                         args=np.array("family=gaussian alpha=1 nlambda=100 thresh=1e-3 maxit=1000 "
+                                      "standardize=TRUE intercept=TRUE seed=2 mode=exact"))
+
+    # ---- C2 as BASELINE.json words it, "abalone 4177 x 8": the libsvm layout the reference's benchmark
+    #      vignette reads (vignettes/benchmarks.Rmd:66).  The in-repo frame is that table with the 3-level sex
+    #      code V1 expanded into two dummies (data-raw/datasets.R:13-25: sex = [V1 == 2], infant = [V1 == 3]),
+    #      so V1 = 1 + sex + 2 infant and the other seven columns are unchanged. ----
+    x8 = abalone_libsvm_layout(x)
+    assert x8.shape == (4177, 8) and set(np.unique(x8[:, 0])) == {1.0, 2.0, 3.0}
+    fit = po.fit(x8, y, family="gaussian", alpha=1.0, nlambda=100, thresh=1e-3, maxit=1000, seed=2)
+    np.savez_compressed(os.path.join(HERE, "abalone8_gaussian_path.npz"),
+                        a0=fit["a0"], beta=fit["beta"], lambda_=fit["lambda"],
+                        dev_ratio=fit["dev_ratio"], npasses=fit["npasses"], nulldev=fit["nulldev"],
+                        args=np.array("x = [1 + sex + 2 infant, length ... weight_shell] of abalone.npz; "
+                                      "family=gaussian alpha=1 nlambda=100 thresh=1e-3 maxit=1000 "
                                       "standardize=TRUE intercept=TRUE seed=2 mode=exact"))
 
     # ---- C1: iris 150 x 4, multinomial, alpha = 0.8, default path ----

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO = os.path.join(HERE, "rmock", "libsgdnet_shim_mock.so")
+# SGDNET_SHIM_MOCK_SO: the sanitizer build of the same two sources (tests/test_shim_sanitizers.py)
+SO = os.environ.get("SGDNET_SHIM_MOCK_SO") or os.path.join(HERE, "rmock", "libsgdnet_shim_mock.so")
 REALSXP, INTSXP, LGLSXP, STRSXP, VECSXP = 14, 13, 10, 16, 19
 
 _L = None

@@ -341,6 +341,22 @@ def test_config2_abalone_gaussian_path(sa):
     assert relerr(fit.dev_ratio, gold["dev_ratio"]) < 1e-8
 
 
+def test_config2_abalone_libsvm_layout_path(sa):
+    # BASELINE config 2 as worded there, "abalone 4177 x 8": the libsvm table the reference's benchmark vignette
+    # reads -- the in-repo 9-column frame with its two sex dummies merged back into the 3-level code
+    # (tests/golden/make_fixtures.py: abalone_libsvm_layout; data-raw/datasets.R:13-25)
+    d = np.load(os.path.join(GOLD, "abalone.npz"))
+    x8 = np.column_stack([1.0 + d["x"][:, 0] + 2.0 * d["x"][:, 1], d["x"][:, 2:]])
+    assert x8.shape == (4177, 8)
+    gold = np.load(os.path.join(GOLD, "abalone8_gaussian_path.npz"))
+    fit = sa.sgdnet(x8, d["y"], family="gaussian", seed=2)
+    assert fit.npasses == float(gold["npasses"])
+    assert relerr(fit.lambda_, gold["lambda_"]) < 1e-12
+    assert relerr(fit.beta, gold["beta"][0]) < 1e-8
+    assert relerr(fit.a0, gold["a0"][0]) < 1e-8
+    assert relerr(fit.dev_ratio, gold["dev_ratio"]) < 1e-8
+
+
 @pytest.mark.parametrize("family", ["gaussian", "binomial", "multinomial", "mgaussian"])
 @pytest.mark.parametrize("sparse", [True, False])
 @pytest.mark.parametrize("standardize", [True, False])
@@ -1297,4 +1313,38 @@ def test_binned_form_matches_batched_oracle(sa, oracle, family, K, penalty, cent
     S.upload_stream(sa.RRng(1).stream(n, n))
     S.run(mode="batched", batch=batch, max_epochs=1, tol=0.0)
     assert S._L.sgdnet_solver_gather_form(S._h, batch) == 2        # the binned kernels are what ran
+    S.close()
+
+
+@pytest.mark.parametrize("family", ["binomial", "gaussian"])
+def test_gradient_memory_moves_between_records_and_array_with_the_mode(sa, oracle, family):
+    """One-response sparse fits keep the gradient memory inside the compact records while batched epochs run
+    and in the K x n array for the exact kernels and the host (solver.cpp: m_to_record / m_to_array).  A
+    solver that alternates batched epoch, exact epoch, host write, batched epoch must follow the oracle
+    doing the same, and the host must read what the kernels wrote."""
+    x, y = make_problem(family, 1, 6000, 300, 0.04, seed=12)
+    p, n = x.shape
+    kw = dict(family=family, penalty="elasticnet", gamma=0.004, alpha=1e-3, beta=2e-3)
+    stream = oracle.Rng(8).stream(n, 4 * n)
+    st = oracle.new_state(1, p, n)
+    S = sa.SagaSolver(x, y, family=family, n_classes=1)
+    S.set_penalty("elasticnet", kw["gamma"], kw["alpha"], kw["beta"])
+    S.upload_stream(stream)
+    plan = [("batched", 700), ("exact", 0), ("batched", 2500), ("batched", 2500)]
+    for e, (mode, batch) in enumerate(plan):
+        seg = stream[e * n:(e + 1) * n]
+        oracle.saga(x, y, st, max_iter=1, tol=0.0, stream=seg, batch=batch, **kw)
+        S.run(mode=mode, batch=batch, stream_offset=e * n, max_epochs=1, tol=0.0)
+        for k in STATE:
+            assert relerr(S.get(k), st[k]) < TOL_BATCHED, (e, k)
+        if e == 2:                                   # the host rewrites the gradient memory between two batched epochs
+            M = S.get("g_memory") * 0.5
+            S.set("g_memory", M)
+            st["g_memory"][:] = M
+            G = (x @ M.T).T / n                      # keep the invariant g_sum = (1/n) sum_i x_i M_i
+            S.set("g_sum", G)
+            st["g_sum"][:] = np.asfortranarray(G)
+            gb = M.sum(axis=1) / n
+            S.set("g_sum_intercept", gb)
+            st["g_sum_intercept"][:] = gb
     S.close()

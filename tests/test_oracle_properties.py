@@ -341,3 +341,22 @@ def test_batched_intercept_step_sparse_and_dense_rule(oracle):
         assert np.allclose(st["intercept"], b0 - gamma * (gb * c * m + d0 / n), rtol=1e-14)
         out[dense] = (st["w"].copy(), st["g_sum"].copy())
     assert np.array_equal(out[False][0], out[True][0]) and np.array_equal(out[False][1], out[True][1])
+
+
+def test_golden_paths_of_configs_1_and_2_are_the_oracles(oracle):
+    """The committed golden lambda paths (tests/golden/*_path.npz: BASELINE configs 1 and 2, the latter in the
+    in-repo 9-column frame and in the 4177 x 8 libsvm layout BASELINE.json names) are what the oracle computes
+    today -- the GPU tests compare the HIP exact path with these files."""
+    import os
+    gold_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ab = np.load(os.path.join(gold_dir, "abalone.npz"))
+    x8 = np.column_stack([1.0 + ab["x"][:, 0] + 2.0 * ab["x"][:, 1], ab["x"][:, 2:]])
+    ir = np.load(os.path.join(gold_dir, "iris.npz"))
+    for name, x, y, kw in (("abalone_gaussian_path", ab["x"], ab["y"], dict(family="gaussian", alpha=1.0, seed=2)),
+                           ("abalone8_gaussian_path", x8, ab["y"], dict(family="gaussian", alpha=1.0, seed=2)),
+                           ("iris_multinomial_path", ir["x"], ir["y"], dict(family="multinomial", alpha=0.8, seed=1))):
+        gold = np.load(os.path.join(gold_dir, name + ".npz"))
+        fit = oracle.fit(x, y, nlambda=100, thresh=1e-3, maxit=1000, **kw)
+        assert fit["npasses"] == float(gold["npasses"]), name
+        assert np.array_equal(fit["lambda"], gold["lambda_"]) and np.array_equal(fit["beta"], gold["beta"]), name
+        assert np.array_equal(fit["a0"], gold["a0"]) and np.array_equal(fit["dev_ratio"], gold["dev_ratio"]), name
