@@ -147,6 +147,7 @@ struct LamParams {
   int64_t m_full, m_tail;
   // epoch bookkeeping for graph replays
   int64_t stream_base;   // offset of the current epoch in the resident stream
+  int64_t stream_wrap;   // > 0: the epoch's end wraps stream_base at this length (the two-epoch buffer of the sample-order pipeline)
   int64_t draws_per_epoch;
   int batch_seq;         // running batch id (claims)
   // ConvergenceCheck scratch: bit patterns of max|dw| and max|w|
@@ -195,7 +196,7 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
                      hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);
-int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st);
+int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st, LamParams* epoch_end = nullptr, int batches = 0);
 int launch_vs_cw(const SagaDev& d, hipStream_t st);
 bool vs_eligible(const SagaDev& d, int m);
 bool compact_eligible(const SagaDev& d);

@@ -92,6 +92,15 @@ __device__ __forceinline__ void d0_publish(const SagaDev& d, int batch_id, int k
                            __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The epoch's bookkeeping on the device (captured epoch graphs replay without the host touching LamParams):
+// the next epoch's draws follow this one's -- in the two-epoch buffer of the sample-order pipeline, in the other half.
+__device__ __forceinline__ void end_epoch(LamParams* lamp, int batches) {
+  int64_t sb = lamp->stream_base + lamp->draws_per_epoch;
+  if (lamp->stream_wrap > 0 && sb >= lamp->stream_wrap) sb -= lamp->stream_wrap;
+  lamp->stream_base = sb;
+  lamp->batch_seq += batches;
+}
+
 __device__ __forceinline__ double cw_sum(const SagaDev& d, int batch_id, int k) {
   const double* set = d.cw + (size_t)(batch_id & 1) * kCwSlots * d.K;
   double t = 0.0;
@@ -1763,6 +1772,15 @@ __global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamPar
   const double n_d = d.v_size[v];
   const int e = threadIdx.x % kSlabElems, g = threadIdx.x / kSlabElems;
   const int64_t j = (int64_t)fb * kSlabElems + e;
+  // the updating threads' own coefficient and gradient average: requested with the slabs, not behind them
+  const int64_t jj_own = (int64_t)fb * kSlabElems + threadIdx.x;
+  const bool updates = (int)threadIdx.x < kSlabElems && jj_own < KP;
+  double w_old = 0.0, g_old = 0.0, c_own = 0.0;
+  if (updates) {
+    w_old = d.vw[(int64_t)v * KP + jj_own];
+    g_old = d.vG[(int64_t)v * KP + jj_own];
+    if (d.standardize) c_own = d.c[jj_own];
+  }
   double acc = 0.0;
   if (j < KP) {
     const double* sp = d.slab + (int64_t)v * d.v_bps * KP + j;
@@ -1788,20 +1806,15 @@ __global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamPar
   if (need_d0)
     for (int wv = 0; wv < kBlock / 64; ++wv) d0_all += red[wv];
   if (fb == 0 && threadIdx.x == 0) d0_s = d0_all;
-  if ((int)threadIdx.x < kSlabElems) {
-    const int64_t jj = (int64_t)fb * kSlabElems + threadIdx.x;
-    if (jj < KP) {
-      double dj = 0.0;
-      for (int gg = 0; gg < kSlabGroups; ++gg) dj += part[gg][threadIdx.x];
-      if (d.standardize) dj -= d.c[jj] * d0_all;   // implicit centring: D_j -= c_j * sum(gc)
-      double* wj = d.vw + (int64_t)v * KP + jj;
-      double* gj = d.vG + (int64_t)v * KP + jj;
-      const double gls = q.gamma * q.ls_m;
-      double val = q.r_m * *wj - gls * *gj - q.gamma * dj;
-      if (q.penalty == SGDNET_ELASTICNET) val = soft_threshold(val, q.beta * q.gamma * q.ls_m);
-      *wj = val;
-      if (dj != 0.0) *gj += dj / n_d;
-    }
+  if (updates) {
+    double dj = 0.0;
+    for (int gg = 0; gg < kSlabGroups; ++gg) dj += part[gg][threadIdx.x];
+    if (d.standardize) dj -= c_own * d0_all;   // implicit centring: D_j -= c_j * sum(gc)
+    const double gls = q.gamma * q.ls_m;
+    double val = q.r_m * w_old - gls * g_old - q.gamma * dj;
+    if (q.penalty == SGDNET_ELASTICNET) val = soft_threshold(val, q.beta * q.gamma * q.ls_m);
+    d.vw[(int64_t)v * KP + jj_own] = val;
+    if (dj != 0.0) d.vG[(int64_t)v * KP + jj_own] = g_old + dj / n_d;
   }
   __syncthreads();
   if (fb == 0 && threadIdx.x == 0 && d.fit_intercept) {   // saga-sparse.h:300-304, batched form
@@ -1851,7 +1864,10 @@ __global__ __launch_bounds__(kBlock) void saga_vs_broadcast_kernel(SagaDev d) {
 
 // periodic average: every replica (and the snapshot) <- snapshot + sum_v (size_v / n) (replica_v - snapshot);
 // final_merge also stores the result as the solver's state
-__global__ __launch_bounds__(kBlock) void saga_vs_merge_kernel(SagaDev d, int final_merge) {
+// epoch_end != nullptr (the epoch's last merge): also the epoch's bookkeeping (saga_epoch_end_kernel), one launch less
+__global__ __launch_bounds__(kBlock) void saga_vs_merge_kernel(SagaDev d, int final_merge, LamParams* epoch_end,
+                                                               int batches) {
+  if (epoch_end && blockIdx.x == 0 && threadIdx.x == 0) end_epoch(epoch_end, batches);
   const int64_t KP = d.p, len = 2 * KP + 2;
   double tot_size = 0.0;
   for (int v = 0; v < d.V; ++v) tot_size += d.v_size[v];
@@ -1883,10 +1899,7 @@ __global__ __launch_bounds__(kBlock) void saga_vs_merge_kernel(SagaDev d, int fi
 }
 
 __global__ void saga_epoch_end_kernel(LamParams* lamp, int batches) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    lamp->stream_base += lamp->draws_per_epoch;
-    lamp->batch_seq += batches;
-  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) end_epoch(lamp, batches);
 }
 
 // ConvergenceCheck (src/utils.h:240-262): max |w - w_prev| and max |w|, then w_prev = w.
@@ -2848,10 +2861,10 @@ int launch_vs_cw(const SagaDev& d, hipStream_t st) {
   return SGDNET_OK;
 }
 
-int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st) {
+int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st, LamParams* epoch_end, int batches) {
   int grid = (int)((2 * d.p + 2 + kBlock - 1) / kBlock);
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(saga_vs_merge_kernel, dim3(grid), dim3(kBlock), 0, st, d, final_merge);
+  hipLaunchKernelGGL(saga_vs_merge_kernel, dim3(grid), dim3(kBlock), 0, st, d, final_merge, epoch_end, batches);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

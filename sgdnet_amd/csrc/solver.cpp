@@ -18,6 +18,8 @@
 #include <atomic>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 #include "setup_device.hpp"
 
@@ -45,6 +47,8 @@ struct sgdnet_solver {
   hipStream_t st = nullptr;
   LamParams lam{};
   LamParams* lam_dev = nullptr;
+  LamParams lam_dev_mirror{};   // what lam_dev holds (push_lam skips an upload that would change nothing)
+  bool lam_dev_valid = false;
   // pinned staging ring for the asynchronous upload of `lam`: the host copy keeps changing
   // (stream_base, batch_seq) while earlier uploads may still be in flight
   static constexpr int kLamSlots = 8;
@@ -142,7 +146,32 @@ int dev_upload(sgdnet_solver* s, T** out, const T* host, size_t count) {
   return SGDNET_OK;
 }
 
+// what the device copy of `lam` holds, as far as the host can know it (the kernels advance stream_base and
+// batch_seq themselves: lam_advance mirrors that; the ConvergenceCheck / loss scratch fields are the device's own)
+bool lam_on_device(const sgdnet_solver* s) {
+  if (!s->lam_dev_valid) return false;
+  const LamParams &a = s->lam, &b = s->lam_dev_mirror;
+  return a.penalty == b.penalty && a.gamma == b.gamma && a.alpha == b.alpha && a.beta == b.beta && a.r_full == b.r_full &&
+         a.ls_full == b.ls_full && a.r_tail == b.r_tail && a.ls_tail == b.ls_tail && a.m_full == b.m_full &&
+         a.m_tail == b.m_tail && a.stream_base == b.stream_base && a.stream_wrap == b.stream_wrap &&
+         a.draws_per_epoch == b.draws_per_epoch && a.batch_seq == b.batch_seq;
+}
+
+// host mirror of end_epoch (saga_batched.hip)
+void lam_advance(sgdnet_solver* s, int64_t draws, int batches) {
+  for (LamParams* q : {&s->lam, &s->lam_dev_mirror}) {
+    int64_t sb = q->stream_base + draws;
+    if (q->stream_wrap > 0 && sb >= q->stream_wrap) sb -= q->stream_wrap;
+    q->stream_base = sb;
+    q->batch_seq += batches;
+  }
+}
+
+// Uploads `lam` unless the device already holds exactly these values: back-to-back epochs of one lambda then
+// run graph after graph with no copy in between (the 120-byte upload is a blit kernel of ~20 us on the solver's
+// stream: 2 % of a C4 epoch).
 int push_lam(sgdnet_solver* s) {
+  if (lam_on_device(s)) return SGDNET_OK;
   const int slot = s->lam_slot;
   s->lam_slot = (slot + 1) % sgdnet_solver::kLamSlots;
   SGD_HIP_TRY(hipEventSynchronize(s->lam_ev[slot]));   // the slot's previous upload has completed
@@ -150,7 +179,16 @@ int push_lam(sgdnet_solver* s) {
   SGD_HIP_TRY(hipMemcpyAsync(s->lam_dev, &s->lam_stage[slot], sizeof(LamParams), hipMemcpyHostToDevice,
                              s->st));
   SGD_HIP_TRY(hipEventRecord(s->lam_ev[slot], s->st));
+  s->lam_dev_mirror = s->lam;
+  s->lam_dev_valid = true;
   return SGDNET_OK;
+}
+
+// Epochs that consume the sample-order pipeline's two-epoch buffer alternate between its halves: the device
+// wraps stream_base there itself, so consecutive epochs need no upload.
+int64_t stream_wrap_for(const sgdnet_solver* s, int64_t stream_offset, int64_t draws) {
+  const auto& P = s->pipe;
+  return (P.open && draws == P.n && (stream_offset == 0 || stream_offset == P.n)) ? 2 * P.n : 0;
 }
 
 // r^m and LS_m = sum_{k<m} r^k for r = 1 - alpha*gamma: closed form of the
@@ -464,7 +502,7 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
     }
     const bool last = k + 1 == nb;
     if (last || (k + 1) % every == 0) {
-      rc = launch_vs_merge(d, last ? 1 : 0, s->st);
+      rc = launch_vs_merge(d, last ? 1 : 0, s->st, last ? s->lam_dev : nullptr, nb);   // the last one also ends the epoch
       if (rc) return rc;
     }
     if (!last) {
@@ -472,7 +510,7 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
       if (rc) return rc;
     }
   }
-  return launch_epoch_end(s->lam_dev, nb, s->st);
+  return SGDNET_OK;
 }
 
 // Enqueue the kernels of one batched epoch (eager or under stream capture).
@@ -1266,6 +1304,12 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
     // the generators' workgroups get CUs of their own: the LDS gather forms shrink their grids
     const int per_wg = rng_generators_per_workgroup();
     const int reserve = generators > 1 ? (generators + per_wg - 1) / per_wg : 0;
+    // (Tried: confining the side stream to exactly those CUs with hipExtStreamCreateWithCUMask -- mask bit i is a
+    // CU of XCC i % 8, scripts/microbench/cu_mask.hip -- so that the conversion kernel's 2048 small workgroups
+    // cannot spread over CUs a gather launch is about to need: on 8 CUs that kernel takes 0.8 ms instead of 0.05,
+    // the side stream becomes the epoch's critical path (1.32 ms per epoch) and the gather beside it is slower,
+    // not faster (90 us per launch).  A masked stream for the solver itself places N whole-LDS workgroups on
+    // N - 1 of its N CUs, i.e. runs two rounds.  profiles/r03p_cu_mask_microbench.txt, r03q_*.)
     if (reserve != s->d.cu_reserve) {
       SGD_HIP_TRY(hipStreamSynchronize(s->st));
       s->d.cu_reserve = reserve;
@@ -1456,6 +1500,7 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     rc = set_batch_shape(s, batch, draws_per_epoch);
     if (rc) return rc;
     s->lam.stream_base = stream_offset;
+    s->lam.stream_wrap = stream_wrap_for(s, stream_offset, draws_per_epoch);
     rc = push_lam(s);
     if (rc) return rc;
     if (s->d.standardize) {
@@ -1481,8 +1526,7 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
       if (tr) (void)hipEventRecord(tev1, s->st);
       g_trace_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
-      s->lam.stream_base += draws_per_epoch;  // mirrors saga_epoch_end_kernel
-      s->lam.batch_seq += nb;
+      lam_advance(s, draws_per_epoch, nb);     // mirrors end_epoch on the device
       if (losses) {
         double sum = 0.0;
         rc = device_loss_sum(s, &sum);
@@ -1528,6 +1572,7 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   rc = set_batch_shape(s, batch, draws_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
+  s->lam.stream_wrap = stream_wrap_for(s, stream_offset, draws_per_epoch);
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1539,8 +1584,7 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   const int nb = n_batches(batch, draws_per_epoch);
   for (int e = 0; e < n_epochs; ++e) {
     SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
-    s->lam.stream_base += draws_per_epoch;
-    s->lam.batch_seq += nb;
+    lam_advance(s, draws_per_epoch, nb);
   }
   return SGDNET_OK;
 }
@@ -1585,6 +1629,7 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   rc = set_batch_shape(s, batch, draws_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
+  s->lam.stream_wrap = stream_wrap_for(s, stream_offset, draws_per_epoch);
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1595,8 +1640,7 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   rc = enqueue_epoch_kernels(s, batch, draws_per_epoch, &ev);
   if (rc) return rc;
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
-  s->lam.stream_base += draws_per_epoch;
-  s->lam.batch_seq += n_batches(batch, draws_per_epoch);
+  lam_advance(s, draws_per_epoch, n_batches(batch, draws_per_epoch));
   double g = 0.0, w = 0.0;
   int ng = 0;
   for (size_t i = 0; i + 3 < ev.size(); i += 4) {
@@ -1814,6 +1858,7 @@ int sgdnet_solver_sync_begin(sgdnet_solver* s, int64_t stream_offset, int64_t dr
   int rc = check_stream(s, stream_offset, draws_local_per_epoch);
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
+  s->lam.stream_wrap = 0;
   s->lam.draws_per_epoch = draws_local_per_epoch;
   rc = push_lam(s);
   if (rc) return rc;
@@ -1842,8 +1887,7 @@ int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds) {
   SGD_HIP_TRY(hipSetDevice(s->device));
   int rc = launch_epoch_end(s->lam_dev, rounds, s->st);
   if (rc) return rc;
-  s->lam.stream_base += s->lam.draws_per_epoch;   // mirrors saga_epoch_end_kernel
-  s->lam.batch_seq += rounds;
+  lam_advance(s, s->lam.draws_per_epoch, rounds);   // mirrors end_epoch on the device
   return SGDNET_OK;
 }
 
