@@ -272,20 +272,37 @@ int rng_generators_per_workgroup() { return kGenPerWg; }
 struct RngShards {
   int V;
   int64_t run;       // draws per run (the last one: what is left)
+  int64_t dps;       // draws per shard in a full run = run / V
+  double inv_run;    // 1 / run: the run of a position without a 64-bit division
   double lo[8], size[8];
 };
 
+// (64-bit integer divisions are software routines of ~100 instructions on this part, and this kernel runs on
+// whatever CUs are free between two gather launches, i.e. in front of the next one: position -> (run, shard) is a
+// multiplication with one correction step and a handful of compares.)
 __global__ __launch_bounds__(256) void r_mt_convert_kernel(uint32_t* out, int64_t count, uint32_t n_samples,
                                                            RngShards sh) {
   const double n = (double)n_samples;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
     if (sh.V > 1) {
-      const int64_t r = i / sh.run;
-      const int64_t j = i - r * sh.run;
+      int64_t r = 0, j = i;
+      if (sh.run < count) {
+        r = (int64_t)((double)i * sh.inv_run);
+        j = i - r * sh.run;
+        if (j < 0) {
+          --r;
+          j += sh.run;
+        } else if (j >= sh.run) {
+          ++r;
+          j -= sh.run;
+        }
+      }
       const int64_t left = count - r * sh.run;
-      const int64_t dps = (left < sh.run ? left : sh.run) / sh.V;
+      const int64_t dps = left >= sh.run ? sh.dps : left / sh.V;      // the division: in the last, shorter run only
       if (dps > 0 && j < dps * sh.V) {
-        const int v = (int)(j / dps);
+        int v = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v += (q < sh.V && j >= (int64_t)q * dps) ? 1 : 0;
         out[i] = (uint32_t)sh.lo[v] + word_to_draw(out[i], sh.size[v]);
         continue;
       }
@@ -301,6 +318,8 @@ int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_sa
   sh.V = n_shards;
   if (n_shards > 1) {
     sh.run = run_len > 0 && run_len < count ? run_len : count;
+    sh.dps = sh.run / n_shards;
+    sh.inv_run = 1.0 / (double)sh.run;
     double lo = 0.0;
     for (int v = 0; v < n_shards; ++v) {
       sh.lo[v] = lo;
