@@ -193,7 +193,7 @@ int launch_epoch_end(LamParams* lam, int batches, hipStream_t st);
 // virtual shards: one launch covers the same batch of all V shards
 int launch_vs_broadcast(const SagaDev& d, hipStream_t st);
 int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, hipStream_t st,
-                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+                     hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr, int batch_index = 0);
 int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);
 int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st, LamParams* epoch_end = nullptr, int batches = 0);

@@ -183,10 +183,11 @@ __device__ __forceinline__ void scatter_add(double* p, double v) {
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// wsrc: the coefficients the draw is evaluated against (d.w, or a virtual shard's replica)
 template <int KMAX, bool kLds>
 __device__ __forceinline__ void saga_draw(const SagaDev& d, const uint32_t s, const int gl,
                                           const int batch_id, const double (&bk)[KMAX], double* Dt,
-                                          double (&gc)[KMAX]) {
+                                          double (&gc)[KMAX], const double* wsrc) {
   const int K = KMAX == 1 ? 1 : d.K;
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) gc[k] = 0.0;
@@ -218,14 +219,14 @@ __device__ __forceinline__ void saga_draw(const SagaDev& d, const uint32_t s, co
   if (gl < cnt0) {
     jf = reinterpret_cast<const int*>(base + 16)[gl];
     vf = reinterpret_cast<const double*>(base + d.rec_val_off)[gl];
-    const double* wj = d.w + jf * K;
+    const double* wj = wsrc + jf * K;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
       if (k < K) acc[k] += vf * wj[k];
   }
   if (has_tail) {
     row_tail_for_each(d, base, nnz, ovf, gl, [&](int64_t j, double v) {
-      const double* wj = d.w + j * K;
+      const double* wj = wsrc + j * K;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k)
         if (k < K) acc[k] += v * wj[k];
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void saga_batch_gather_kernel(SagaDev d, co
     bk[k] = k < K ? d.b[k] - (d.standardize ? cw_sum(d, batch_id, k) : 0.0) : 0.0;
   }
   if (d.standardize) cw_clear_next(d, batch_id);
-  if (i < m) saga_draw<KMAX, false>(d, d.stream[t0 + i], gl, batch_id, bk, d.D, gc);
+  if (i < m) saga_draw<KMAX, false>(d, d.stream[t0 + i], gl, batch_id, bk, d.D, gc, d.w);
   if (d.fit_intercept || d.standardize) store_d0_partial<KMAX, kBlock>(d, K, batch_id, gc);
 }
 
@@ -1059,7 +1060,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     gct[k] = 0.0;
-    bk[k] = k < K ? (kVS ? d.vb[vsh] - (d.standardize ? d.vcw[vsh] : 0.0)
+    bk[k] = k < K ? (kVS ? d.vb[vsh * K + k] - (d.standardize ? d.vcw[vsh * K + k] : 0.0)
                          : d.b[k] - (d.standardize ? cw_sum(d, batch_id, k) : 0.0))
                   : 0.0;
   }
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
   } else {
     for (int i = lo + group; i < hi; i += kGroups) {
       double gc[KMAX];
-      saga_draw<KMAX, true>(d, d.stream[t0 + i], gl, batch_id, bk, Dl, gc);
+      saga_draw<KMAX, true>(d, d.stream[t0 + i], gl, batch_id, bk, Dl, gc, w_src);
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) gct[k] += gc[k];
     }
@@ -1119,15 +1120,20 @@ __global__ __launch_bounds__(kLdsBlock) void saga_batch_gather_lds_kernel(SagaDe
     }
   }
   PHASE(4);
-  if (kVS) {                                    // one partial per workgroup, summed per shard by the sweep
-    __shared__ double vpart[kLdsBlock / 64];
-    const double t = wave_sum(gct[0]);
-    if ((threadIdx.x & 63) == 0) vpart[threadIdx.x >> 6] = t;
+  if (kVS) {                                    // one partial per workgroup and class, summed per shard by the sweep
+    __shared__ double vpart[kLdsBlock / 64][KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        const double t = wave_sum(gct[k]);
+        if ((threadIdx.x & 63) == 0) vpart[threadIdx.x >> 6][k] = t;
+      }
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < K) {
       double tot = 0.0;
-      for (int wv = 0; wv < kLdsBlock / 64; ++wv) tot += vpart[wv];
-      d.vd0[blockIdx.x] = tot;
+      for (int wv = 0; wv < kLdsBlock / 64; ++wv) tot += vpart[wv][threadIdx.x];
+      d.vd0[(int64_t)blockIdx.x * K + threadIdx.x] = tot;
     }
   } else if (d.fit_intercept || d.standardize) {
     store_d0_partial<KMAX, kLdsBlock>(d, K, batch_id, gct);
@@ -1762,28 +1768,36 @@ __global__ __launch_bounds__(kBlock) void saga_cw_init_kernel(SagaDev d, const L
 // order, updates the shard's replica of (w, g_sum) with the shard's own normalisation, and the
 // first block of every shard updates the shard's intercept pair.
 // --------------------------------------------------------------------------
+template <int KMAX>
 __global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamParams* lamp, int tail, int nfb) {
   __shared__ double part[kSlabGroups][kSlabElems];
   __shared__ double red[kBlock / 64];
-  __shared__ double d0_s;
+  __shared__ double sh_d0[KMAX];
   const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
+  const int K = KMAX == 1 ? 1 : d.K;
+  const int F = kSlabElems / K;              // features per block (K <= 16)
+  const int E = F * K;
   const int v = (int)blockIdx.x / nfb, fb = (int)blockIdx.x - v * nfb;
-  const int64_t KP = d.p;
+  const int64_t KP = (int64_t)K * d.p;
   const double n_d = d.v_size[v];
   const int e = threadIdx.x % kSlabElems, g = threadIdx.x / kSlabElems;
-  const int64_t j = (int64_t)fb * kSlabElems + e;
-  // the updating threads' own coefficient and gradient average: requested with the slabs, not behind them
-  const int64_t jj_own = (int64_t)fb * kSlabElems + threadIdx.x;
-  const bool updates = (int)threadIdx.x < kSlabElems && jj_own < KP;
-  double w_old = 0.0, g_old = 0.0, c_own = 0.0;
-  if (updates) {
-    w_old = d.vw[(int64_t)v * KP + jj_own];
-    g_old = d.vG[(int64_t)v * KP + jj_own];
-    if (d.standardize) c_own = d.c[jj_own];
+  const int64_t elem = (int64_t)fb * E + e;
+  // the updating threads' own coefficients and gradient averages: requested with the slabs, not behind them
+  const int64_t j_own = (int64_t)fb * F + threadIdx.x;
+  const bool updates = (int)threadIdx.x < F && j_own < d.p;
+  double w_old[KMAX], g_old[KMAX], c_own = 0.0;
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    w_old[k] = g_old[k] = 0.0;
+    if (updates && k < K) {
+      w_old[k] = d.vw[(int64_t)v * KP + j_own * K + k];
+      g_old[k] = d.vG[(int64_t)v * KP + j_own * K + k];
+    }
   }
+  if (updates && d.standardize) c_own = d.c[j_own];
   double acc = 0.0;
-  if (j < KP) {
-    const double* sp = d.slab + (int64_t)v * d.v_bps * KP + j;
+  if (e < E && elem < KP) {
+    const double* sp = d.slab + (int64_t)v * d.v_bps * KP + elem;
     int bidx = g;
     for (; bidx + 3 * kSlabGroups < d.v_bps; bidx += 4 * kSlabGroups) {   // 4 loads in flight
       const double a0 = sp[(int64_t)bidx * KP], a1 = sp[(int64_t)(bidx + kSlabGroups) * KP];
@@ -1794,71 +1808,106 @@ __global__ __launch_bounds__(kBlock) void saga_vs_sweep_kernel(SagaDev d, LamPar
     for (; bidx < d.v_bps; bidx += kSlabGroups) acc += sp[(int64_t)bidx * KP];
   }
   part[g][e] = acc;
-  const bool need_d0 = fb == 0 || d.standardize;  // the shard's intercept accumulator = sum of gc
+  const bool need_d0 = fb == 0 || d.standardize;  // the shard's intercept accumulator = sum of gc, per class
   if (need_d0) {
-    double a = 0.0;
-    for (int i = threadIdx.x; i < d.v_bps; i += kBlock) a += d.vd0[v * d.v_bps + i];
-    a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    for (int k = 0; k < K; ++k) {
+      double a = 0.0;
+      for (int i = threadIdx.x; i < d.v_bps; i += kBlock) a += d.vd0[(int64_t)(v * d.v_bps + i) * K + k];
+      a = wave_sum(a);
+      if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int wv = 0; wv < kBlock / 64; ++wv) t += red[wv];
+        sh_d0[k] = t;
+      }
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
   }
-  __syncthreads();
-  double d0_all = 0.0;
-  if (need_d0)
-    for (int wv = 0; wv < kBlock / 64; ++wv) d0_all += red[wv];
-  if (fb == 0 && threadIdx.x == 0) d0_s = d0_all;
   if (updates) {
-    double dj = 0.0;
-    for (int gg = 0; gg < kSlabGroups; ++gg) dj += part[gg][threadIdx.x];
-    if (d.standardize) dj -= c_own * d0_all;   // implicit centring: D_j -= c_j * sum(gc)
+    double dj[KMAX], val[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      dj[k] = 0.0;
+      if (k < K) {
+        const int ee = (int)threadIdx.x * K + k;
+        double t = 0.0;
+        for (int gg = 0; gg < kSlabGroups; ++gg) t += part[gg][ee];
+        dj[k] = t - (d.standardize ? c_own * sh_d0[k] : 0.0);   // implicit centring: D_j -= c_j * sum(gc)
+      }
+    }
     const double gls = q.gamma * q.ls_m;
-    double val = q.r_m * w_old - gls * g_old - q.gamma * dj;
-    if (q.penalty == SGDNET_ELASTICNET) val = soft_threshold(val, q.beta * q.gamma * q.ls_m);
-    d.vw[(int64_t)v * KP + jj_own] = val;
-    if (dj != 0.0) d.vG[(int64_t)v * KP + jj_own] = g_old + dj / n_d;
+    double nrm = 0.0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      val[k] = k < K ? q.r_m * w_old[k] - gls * g_old[k] - q.gamma * dj[k] : 0.0;
+      nrm += val[k] * val[k];
+    }
+    const double tau = q.beta * q.gamma * q.ls_m;
+    const double factor = q.penalty == SGDNET_GROUPLASSO ? tau / sqrt(nrm) : 0.0;   // penalties.h:61-79
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (k < K) {
+        double out = val[k];
+        if (q.penalty == SGDNET_ELASTICNET) out = soft_threshold(out, tau);
+        else if (q.penalty == SGDNET_GROUPLASSO) out = factor < 1.0 ? out * (1.0 - factor) : 0.0;
+        d.vw[(int64_t)v * KP + j_own * K + k] = out;
+        if (dj[k] != 0.0 || q.penalty == SGDNET_GROUPLASSO)
+          d.vG[(int64_t)v * KP + j_own * K + k] = g_old[k] + dj[k] / n_d;
+      }
+    }
   }
-  __syncthreads();
-  if (fb == 0 && threadIdx.x == 0 && d.fit_intercept) {   // saga-sparse.h:300-304, batched form
-    const double dk = d0_s / n_d;
-    const double gbk = d.vgb[v] + dk;
-    d.vgb[v] = gbk;
-    d.vb[v] -= q.gamma * (gbk * (d.xd ? 1.0 : 0.01) * q.m_d + dk);
+  if (fb == 0 && (int)threadIdx.x < K && d.fit_intercept) {   // saga-sparse.h:300-304, batched form
+    const int k = threadIdx.x;
+    const double dk = sh_d0[k] / n_d;
+    const double gbk = d.vgb[v * K + k] + dk;
+    d.vgb[v * K + k] = gbk;
+    d.vb[v * K + k] -= q.gamma * (gbk * (d.xd ? 1.0 : 0.01) * q.m_d + dk);
   }
 }
 
-// implicit centring with virtual shards: c . w of every replica, recomputed after each sweep and
-// merge (one block per shard; the single-replica path keeps this sum incrementally in slots)
+// c . w of every replica and class (implicit centring)
 __global__ __launch_bounds__(kBlock) void saga_vs_cw_kernel(SagaDev d) {
   __shared__ double red[kBlock / 64];
-  const int v = blockIdx.x;
-  const double* wv = d.vw + (int64_t)v * d.p;
+  const int K = d.K;
+  const int v = (int)blockIdx.x / K, k = (int)blockIdx.x - v * K;
+  const double* wv = d.vw + (int64_t)v * K * d.p + k;
   double a = 0.0;
-  for (int64_t j = threadIdx.x; j < d.p; j += kBlock) a += d.c[j] * wv[j];
+  for (int64_t j = threadIdx.x; j < d.p; j += kBlock) a += d.c[j] * wv[j * K];
   a = wave_sum(a);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int wvi = 0; wvi < kBlock / 64; ++wvi) t += red[wvi];
-    d.vcw[v] = t;
+    d.vcw[blockIdx.x] = t;
   }
+}
+
+// replicated state, flattened: [g_sum (K p) | w (K p) | g_sum_intercept (K) | intercept (K)]
+__device__ __forceinline__ double* vs_slot(const SagaDev& d, int v, int64_t i, int64_t KP, int K) {
+  if (i < KP) return d.vG + (int64_t)v * KP + i;
+  if (i < 2 * KP) return d.vw + (int64_t)v * KP + (i - KP);
+  if (i < 2 * KP + K) return d.vgb + (int64_t)v * K + (i - 2 * KP);
+  return d.vb + (int64_t)v * K + (i - 2 * KP - K);
+}
+__device__ __forceinline__ double* vs_own_slot(const SagaDev& d, int64_t i, int64_t KP, int K) {
+  if (i < KP) return d.G + i;
+  if (i < 2 * KP) return d.w + (i - KP);
+  if (i < 2 * KP + K) return d.gb + (i - 2 * KP);
+  return d.b + (i - 2 * KP - K);
 }
 
 // every replica (and the snapshot) <- the solver's current (w, g_sum, b, g_sum_b)
 __global__ __launch_bounds__(kBlock) void saga_vs_broadcast_kernel(SagaDev d) {
-  const int64_t KP = d.p, len = 2 * KP + 2;
+  const int K = d.K;
+  const int64_t KP = (int64_t)K * d.p, len = 2 * KP + 2 * K;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
-    double val;
-    if (i < KP) val = d.G[i];
-    else if (i < 2 * KP) val = d.w[i - KP];
-    else if (i == 2 * KP) val = d.gb[0];
-    else val = d.b[0];
+    const double val = *vs_own_slot(d, i, KP, K);
     d.vref[i] = val;
-    for (int v = 0; v < d.V; ++v) {
-      if (i < KP) d.vG[(int64_t)v * KP + i] = val;
-      else if (i < 2 * KP) d.vw[(int64_t)v * KP + i - KP] = val;
-      else if (i == 2 * KP) d.vgb[v] = val;
-      else d.vb[v] = val;
-    }
+    for (int v = 0; v < d.V; ++v) *vs_slot(d, v, i, KP, K) = val;
   }
 }
 
@@ -1868,33 +1917,17 @@ __global__ __launch_bounds__(kBlock) void saga_vs_broadcast_kernel(SagaDev d) {
 __global__ __launch_bounds__(kBlock) void saga_vs_merge_kernel(SagaDev d, int final_merge, LamParams* epoch_end,
                                                                int batches) {
   if (epoch_end && blockIdx.x == 0 && threadIdx.x == 0) end_epoch(epoch_end, batches);
-  const int64_t KP = d.p, len = 2 * KP + 2;
+  const int K = d.K;
+  const int64_t KP = (int64_t)K * d.p, len = 2 * KP + 2 * K;
   double tot_size = 0.0;
   for (int v = 0; v < d.V; ++v) tot_size += d.v_size[v];
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += (int64_t)gridDim.x * kBlock) {
     const double ref = d.vref[i];
     double val = ref;
-    for (int v = 0; v < d.V; ++v) {
-      double cur;
-      if (i < KP) cur = d.vG[(int64_t)v * KP + i];
-      else if (i < 2 * KP) cur = d.vw[(int64_t)v * KP + i - KP];
-      else if (i == 2 * KP) cur = d.vgb[v];
-      else cur = d.vb[v];
-      val += (d.v_size[v] / tot_size) * (cur - ref);
-    }
+    for (int v = 0; v < d.V; ++v) val += (d.v_size[v] / tot_size) * (*vs_slot(d, v, i, KP, K) - ref);
     d.vref[i] = val;
-    for (int v = 0; v < d.V; ++v) {
-      if (i < KP) d.vG[(int64_t)v * KP + i] = val;
-      else if (i < 2 * KP) d.vw[(int64_t)v * KP + i - KP] = val;
-      else if (i == 2 * KP) d.vgb[v] = val;
-      else d.vb[v] = val;
-    }
-    if (final_merge) {
-      if (i < KP) d.G[i] = val;
-      else if (i < 2 * KP) d.w[i - KP] = val;
-      else if (i == 2 * KP) d.gb[0] = val;
-      else d.b[0] = val;
-    }
+    for (int v = 0; v < d.V; ++v) *vs_slot(d, v, i, KP, K) = val;
+    if (final_merge) *vs_own_slot(d, i, KP, K) = val;
   }
 }
 
@@ -2836,10 +2869,13 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
 }
 
 // Virtual shards need the K == 1 LDS gather with w staged in LDS and a grid that splits evenly.
+// Virtual shards need an LDS gather form and a grid that splits evenly: K == 1 with w staged in LDS (sparse or
+// dense x), or 2..4 classes of sparse x whose K x p accumulator fits (round 3; the replica of w is read through L2).
 bool vs_eligible(const SagaDev& d, int m) {
   (void)m;
-  if (d.V < 2 || d.K != 1 || (d.standardize && !(d.vcw && d.c)) || d.force_global || !d.vw) return false;
-  const size_t table = sizeof(double) * (size_t)d.p;
+  if (d.V < 2 || d.K < 1 || d.K > 4 || (d.standardize && !(d.vcw && d.c)) || d.force_global || !d.vw) return false;
+  const size_t table = sizeof(double) * (size_t)d.K * (size_t)d.p;
+  if (d.K > 1) return !d.xd && d.rec && table <= 80 * 1024;
   if (d.xd) return table <= 80 * 1024;                           // dense x: only the accumulator is staged
   return 2 * table + 16 + kLdsStaticReserve <= kLdsPerCu;     // accumulator + coefficient snapshot in LDS
 }
@@ -2847,7 +2883,7 @@ bool vs_eligible(const SagaDev& d, int m) {
 static int vs_grid(const SagaDev& d) { return d.v_bps * d.V; }
 
 int launch_vs_broadcast(const SagaDev& d, hipStream_t st) {
-  int grid = (int)((2 * d.p + 2 + kBlock - 1) / kBlock);
+  int grid = (int)((2 * (int64_t)d.K * d.p + 2 * d.K + kBlock - 1) / kBlock);
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(saga_vs_broadcast_kernel, dim3(grid), dim3(kBlock), 0, st, d);
   SGD_HIP_TRY(hipGetLastError());
@@ -2856,13 +2892,13 @@ int launch_vs_broadcast(const SagaDev& d, hipStream_t st) {
 
 int launch_vs_cw(const SagaDev& d, hipStream_t st) {
   if (!d.standardize) return SGDNET_OK;
-  hipLaunchKernelGGL(saga_vs_cw_kernel, dim3(d.V), dim3(kBlock), 0, st, d);
+  hipLaunchKernelGGL(saga_vs_cw_kernel, dim3(d.V * d.K), dim3(kBlock), 0, st, d);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }
 
 int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st, LamParams* epoch_end, int batches) {
-  int grid = (int)((2 * d.p + 2 + kBlock - 1) / kBlock);
+  int grid = (int)((2 * (int64_t)d.K * d.p + 2 * d.K + kBlock - 1) / kBlock);
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(saga_vs_merge_kernel, dim3(grid), dim3(kBlock), 0, st, d, final_merge, epoch_end, batches);
   SGD_HIP_TRY(hipGetLastError());
@@ -2870,7 +2906,7 @@ int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st, LamParams
 }
 
 int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int m, hipStream_t st, hipEvent_t ev0,
-                     hipEvent_t ev1) {
+                     hipEvent_t ev1, int batch_index) {
   const int grid = vs_grid(d);
   if (grid / d.V != d.v_bps || grid > kD0Slots) {
     set_error("internal: virtual-shard geometry (%d workgroups, %d per shard)", grid, d.v_bps);
@@ -2898,6 +2934,23 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
   int dpb = (m + d.v_bps - 1) / d.v_bps;
   const int per_round = kLdsBlock / kGroup;
   if (dpb < per_round) dpb = per_round;
+  if (d.K > 1) {
+    // 2..4 classes: the 16-lane draw of the LDS form against the shard's replica (batch_id_offset = the batch's
+    // index in the epoch: the first-occurrence claims of a sample are per batch)
+    static bool k4_attr_done[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!k4_attr_done[dev & 63]) {
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<4, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      k4_attr_done[dev & 63] = true;
+    }
+    hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<4, false, true>), dim3(grid), dim3(kLdsBlock),
+                          sizeof(double) * (size_t)d.K * (size_t)d.p, st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_index,
+                          dpb);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
+  }
   const size_t lds = 2 * sizeof(double) * (size_t)d.p + 16;
   static bool attr_done_dev[64] = {};
   int cur_dev = 0;
@@ -2924,8 +2977,12 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
 int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream_t st, hipEvent_t ev0,
                     hipEvent_t ev1) {
   (void)m;
-  const int nfb = (int)((d.p + kSlabElems - 1) / kSlabElems);
-  hipExtLaunchKernelGGL(saga_vs_sweep_kernel, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
+  const int F = kSlabElems / d.K;            // features per block
+  const int nfb = (int)((d.p + F - 1) / F);
+  if (d.K == 1)
+    hipExtLaunchKernelGGL(saga_vs_sweep_kernel<1>, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
+  else
+    hipExtLaunchKernelGGL(saga_vs_sweep_kernel<4>, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

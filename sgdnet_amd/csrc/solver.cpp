@@ -489,13 +489,13 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
     if (ev) {
       hipEvent_t e[4];
       for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
-      rc = launch_vs_gather(d, s->lam_dev, t0, (int)m, s->st, e[0], e[1]);
+      rc = launch_vs_gather(d, s->lam_dev, t0, (int)m, s->st, e[0], e[1], k);
       if (rc) return rc;
       rc = launch_vs_sweep(d, s->lam_dev, tail, (int)m, s->st, e[2], e[3]);
       if (rc) return rc;
       for (auto x : e) ev->push_back(x);
     } else {
-      rc = launch_vs_gather(d, s->lam_dev, t0, (int)m, s->st);
+      rc = launch_vs_gather(d, s->lam_dev, t0, (int)m, s->st, nullptr, nullptr, k);
       if (rc) return rc;
       rc = launch_vs_sweep(d, s->lam_dev, tail, (int)m, s->st);
       if (rc) return rc;
@@ -1905,11 +1905,11 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   d.V = 0;
   d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = nullptr;
   if (n_shards < 2) return SGDNET_OK;
-  if (d.K != 1) {
-    set_error("virtual shards: one class");
+  if (d.K > 4 || (d.K > 1 && !s->sparse)) {
+    set_error("virtual shards: one response, or up to 4 classes of sparse x");
     return SGDNET_EUNSUPPORTED;
   }
-  const int64_t KP = d.p;
+  const int64_t KP = (int64_t)d.K * d.p;
   auto alloc = [&](double** out, size_t count) -> int {
     void* q = nullptr;
     if (hipMalloc(&q, sizeof(double) * count) != hipSuccess) return SGDNET_ENOMEM;
@@ -1920,11 +1920,11 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   };
   int rc = alloc(&d.vw, (size_t)n_shards * KP);
   if (!rc) rc = alloc(&d.vG, (size_t)n_shards * KP);
-  if (!rc) rc = alloc(&d.vb, 8);
-  if (!rc) rc = alloc(&d.vgb, 8);
-  if (!rc) rc = alloc(&d.vcw, 8);
-  if (!rc) rc = alloc(&d.vd0, 256);
-  if (!rc) rc = alloc(&d.vref, (size_t)(2 * KP + 2));
+  if (!rc) rc = alloc(&d.vb, 8 * (size_t)d.K);
+  if (!rc) rc = alloc(&d.vgb, 8 * (size_t)d.K);
+  if (!rc) rc = alloc(&d.vcw, 8 * (size_t)d.K);
+  if (!rc) rc = alloc(&d.vd0, 256 * (size_t)d.K);
+  if (!rc) rc = alloc(&d.vref, (size_t)(2 * KP + 2 * d.K));
   if (rc) {
     set_error("virtual shards: out of device memory");
     return rc;

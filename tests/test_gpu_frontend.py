@@ -281,3 +281,23 @@ def test_large_dense_x_is_prepared_on_the_device(sa, monkeypatch, family, mode):
     assert np.array_equal(dev.return_codes, host.return_codes) and dev.npasses == host.npasses
     assert np.abs(dev.beta - host.beta).max() <= 1e-6 * np.abs(host.beta).max()
     assert np.allclose(dev.dev_ratio, host.dev_ratio, atol=1e-7)
+
+
+def test_multinomial_fit_on_virtual_shards_reaches_the_unsharded_optimum(sa):
+    """Round 3: the fit driver runs 2..4-class fits of sparse x on virtual shards too (250 000 x 300, K = 3: four
+    replicas).  Same path, same optimum as the unsharded batched fit at a tight thresh."""
+    from sgdnet_amd import data as D
+    n, p, K = 250_000, 300, 3
+    pr = D.make_sparse_glm(n, p, 0.03, family="multinomial", n_classes=K, seed=17)
+    X = D.as_scipy(pr).T.tocsc()
+    y = pr["y"].ravel()
+    kw = dict(family="multinomial", alpha=0.5, nlambda=5, lambda_min_ratio=0.01, standardize=False, thresh=1e-8,
+              maxit=400, seed=3, mode="batched")
+    with sa.option("virtual_shards", 0):
+        ref = sa.sgdnet(X, y, **kw)
+    fit = sa.sgdnet(X, y, **kw)                                   # the driver's rule: 4 shards
+    assert np.all(np.asarray(fit.return_codes) == 0) and np.all(np.asarray(ref.return_codes) == 0)
+    assert np.allclose(fit.lambda_, ref.lambda_, rtol=1e-12)
+    fb, rb = np.stack(fit.beta), np.stack(ref.beta)
+    assert np.abs(fb - rb).max() <= 2e-6 * np.abs(rb).max()
+    assert np.allclose(fit.dev_ratio, ref.dev_ratio, atol=1e-7)

@@ -1090,10 +1090,11 @@ def _oracle_virtual_shards(oracle, x, y, V, batch, stream, epochs, kw):
     p, n = x.shape
     dps = n // V
     bounds = [shard_bounds(n, V, v) for v in range(V)]
+    K = kw.pop("K", 1)
     sub = [(x[:, lo:hi], np.asfortranarray(y[:, lo:hi])) for lo, hi in bounds]
-    mem = [np.zeros((1, hi - lo), order="F") for lo, hi in bounds]
-    state = dict(w=np.zeros((1, p), order="F"), g_sum=np.zeros((1, p), order="F"), intercept=np.zeros(1),
-                 g_sum_intercept=np.zeros(1))
+    mem = [np.zeros((K, hi - lo), order="F") for lo, hi in bounds]
+    state = dict(w=np.zeros((K, p), order="F"), g_sum=np.zeros((K, p), order="F"), intercept=np.zeros(K),
+                 g_sum_intercept=np.zeros(K))
     every = max(1, (n // 32) // batch)
     wts = [(hi - lo) / n for lo, hi in bounds]
     for e in range(epochs):
@@ -1107,7 +1108,7 @@ def _oracle_virtual_shards(oracle, x, y, V, batch, stream, epochs, kw):
                 lo, hi = bounds[v]
                 seg = stream[(e * V + v) * dps + k * batch:(e * V + v) * dps + min(dps, (k + 1) * batch)]
                 local = (seg.astype(np.int64) - lo).astype(np.uint32)
-                Dm, d0 = np.zeros((1, p), order="F"), np.zeros(1)
+                Dm, d0 = np.zeros((K, p), order="F"), np.zeros(K)
                 oracle.batch_gather(sub[v][0], sub[v][1], reps[v], local, Dm, d0, n_total=hi - lo, **kw)
                 oracle.batch_sweep((p, hi - lo), reps[v], local.size, Dm, d0, n_total=hi - lo, **kw)
             if k + 1 == nb or (k + 1) % every == 0:
@@ -1347,4 +1348,33 @@ def test_gradient_memory_moves_between_records_and_array_with_the_mode(sa, oracl
             gb = M.sum(axis=1) / n
             S.set("g_sum_intercept", gb)
             st["g_sum_intercept"][:] = gb
+    S.close()
+
+
+@pytest.mark.parametrize("V,n,p,batch,family,K,penalty,centre", [
+    (2, 4000, 60, 64, "multinomial", 3, "elasticnet", False), (4, 6002, 90, 100, "mgaussian", 2, "grouplasso", False),
+    (8, 8005, 50, 120, "multinomial", 4, "ridge", True), (2, 3001, 40, 3001, "multinomial", 3, "elasticnet", True)])
+def test_virtual_shards_with_several_classes(sa, oracle, V, n, p, batch, family, K, penalty, centre):
+    """Round 3: virtual shards for 2..4 classes of sparse x (the LDS gather of the 16-lane draw against the shard's
+    replica, a sweep that owns K-vectors, per-class intercept partials): the oracle's batch halves driven through the
+    same shards, streams and merge points, including a group penalty, implicit centring, n not divisible by V and a
+    window as long as a shard's epoch."""
+    x, y = make_problem(family, K, n, p, 0.1, seed=31)
+    c = np.asarray(x.mean(axis=1)).ravel() * 2.0 if centre else None
+    kw = dict(family=family, penalty=penalty, gamma=0.004, alpha=1e-4, beta=0.0 if penalty == "ridge" else 1e-4)
+    if c is not None:
+        kw["x_center_scaled"] = c
+    epochs = 3
+    S = sa.SagaSolver(x, y, family=family, n_classes=K, x_center_scaled=c)
+    S.set_penalty(penalty, kw["gamma"], kw["alpha"], kw["beta"])
+    S.set_virtual_shards(V)
+    stream = S.sharded_stream([sa.RRng(70 + v) for v in range(V)], epochs)
+    S.upload_stream(stream)
+    draws = V * (n // V)
+    ep, _ = S.run(mode="batched", batch=batch, draws_per_epoch=draws, max_epochs=epochs, tol=0.0)
+    assert ep == epochs
+    st = _oracle_virtual_shards(oracle, x, y, V, min(batch, n // V), stream, epochs, dict(kw, K=K))
+    for k in STATE:
+        assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
+    S.set_virtual_shards(0)
     S.close()
