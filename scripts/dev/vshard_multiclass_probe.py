@@ -1,4 +1,5 @@
-"""Virtual shards for 2..4 classes (round 3): epochs/s of a mid-size multinomial fit with and without them."""
+"""Virtual shards for 2..16 classes (round 3): epochs/s of a mid-size multinomial fit with and without them.
+Usage: vshard_multiclass_probe.py [n_classes=3] [n_features=1000]"""
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
@@ -6,7 +7,9 @@ import torch  # noqa: F401
 import sgdnet_amd as sa
 from sgdnet_amd import data as D
 
-n, p, K, dens = 1_000_000, 1000, 3, 0.01
+n, dens = 1_000_000, 0.01
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+p = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 pr = D.make_sparse_glm(n, p, dens, family="multinomial", n_classes=K, seed=3)
 X = D.as_scipy(pr)
 row_sq = np.add.reduceat(pr["val"] ** 2, pr["ptr"][:-1])
@@ -33,7 +36,7 @@ for V in (0, 2, 4, 8):
         done = S.convergence(1e-6)
         ep += 1
     dt = time.perf_counter() - t0
-    print(f"V={V}: window {batch}, {ep} epochs to 1e-6 in {dt:.3f} s = {1e3 * dt / ep:.3f} ms/epoch (incl. host sync + stream), deviance {S.deviance():.6f}", flush=True)
+    print(f"K={K} p={p} V={V}: window {batch}, {ep} epochs to 1e-6 in {dt:.3f} s = {1e3 * dt / ep:.3f} ms/epoch (incl. host sync + stream), deviance {S.deviance():.6f}", flush=True)
     if V:
         S.set_virtual_shards(0)
     S.close()

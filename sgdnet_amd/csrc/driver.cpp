@@ -695,12 +695,12 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   DrawSource draws(ctl);
   int vshards = 0;
   // Virtual shards (include/sgdnet_hip.h): with enough samples per feature the batched fit of
-  // one response (round 3: or of 2..4 classes of sparse x) runs as up to 8 locally normalised replicas over sample ranges, averaged on the
+  // one response (round 3: or of 2..16 classes of sparse x) runs as up to 8 locally normalised replicas over sample ranges, averaged on the
   // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
   // at the benchmark shapes.  sgdnet_set_option("virtual_shards", 0) switches it off, V forces V.
   // The shard kernels read a per-shard layout of the sample order: the built-in generator and
   // the unif callback produce it (DrawSource::fill), an explicit sample_stream cannot.
-  if (mode == SGDNET_MODE_BATCHED && (K == 1 || (K <= 4 && X.sparse)) && draws.shardable()) {
+  if (mode == SGDNET_MODE_BATCHED && (K == 1 || (K <= 16 && X.sparse)) && draws.shardable()) {
     int V = 1;
     // at least 100 samples per feature in every shard, and a problem large enough for the
     // per-launch cost to matter (small correlated data, e.g. abalone 4177 x 9, converges slower

@@ -1430,7 +1430,8 @@ __device__ __forceinline__ void row_for_each_uniform(const SagaDev& d, const cha
 // returns the gradient change of this lane's class (0 on lanes >= K and on repeated draws)
 template <bool kLds>
 __device__ __forceinline__ double saga_draw_classlane(const SagaDev& d, const uint32_t s, const int gl,
-                                                      const int batch_id, const double bl, double* Dt) {
+                                                      const int batch_id, const double bl, double* Dt,
+                                                      const double* wsrc) {
   const int K = d.K;
   const bool lane_on = gl < K;
   const char* base = d.rec + (size_t)s * d.rec_stride;
@@ -1444,7 +1445,7 @@ __device__ __forceinline__ double saga_draw_classlane(const SagaDev& d, const ui
 
   double acc = 0.0;
   row_for_each_uniform(d, base, nnz, ovf, [&](int64_t j, double v) {
-    if (lane_on) acc += v * d.w[j * K + gl];
+    if (lane_on) acc += v * wsrc[j * K + gl];
   });
   const double lp = acc + bl;
 
@@ -1472,7 +1473,9 @@ __device__ __forceinline__ double saga_draw_classlane(const SagaDev& d, const ui
   return gc;
 }
 
-template <bool kLds>
+// kVS (kLds only; round 3): virtual shards as in saga_batch_gather_lds_kernel -- workgroup b works for shard
+// b / d.v_bps on that shard's replica of (w, b), its region of the sample stream and its own intercept partials.
+template <bool kLds, bool kVS = false>
 __global__ __launch_bounds__(kLds ? kLdsBlock : kBlock) void saga_batch_gather_cl_kernel(
     SagaDev d, const LamParams* lamp, int64_t t0_in_epoch, int m, int batch_id_offset, int draws_per_block) {
   extern __shared__ __attribute__((aligned(16))) double Dl[];
@@ -1482,24 +1485,30 @@ __global__ __launch_bounds__(kLds ? kLdsBlock : kBlock) void saga_batch_gather_c
   const int64_t KP = (int64_t)K * d.p;
   const int gl = threadIdx.x & (kGroup - 1);
   const int group = threadIdx.x / kGroup;
-  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int vsh = kVS ? (int)blockIdx.x / d.v_bps : 0;
+  const int vblk = kVS ? (int)blockIdx.x - vsh * d.v_bps : (int)blockIdx.x;
+  const double* w_src = kVS ? d.vw + (int64_t)vsh * KP : d.w;
+  const int64_t t0 = lamp->stream_base + t0_in_epoch + (kVS ? (int64_t)vsh * d.v_dps : 0);
   const int batch_id = lamp->batch_seq + batch_id_offset;
   if (kLds)
     for (int64_t i = threadIdx.x; i < KP; i += kThreads) Dl[i] = 0.0;
   if (threadIdx.x < 16) d0s[threadIdx.x] = 0.0;
   __syncthreads();
-  const double bl = gl < K ? d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0) : 0.0;
-  if (d.standardize) cw_clear_next(d, batch_id);
+  double bl = 0.0;
+  if (gl < K)
+    bl = kVS ? d.vb[vsh * K + gl] - (d.standardize ? d.vcw[vsh * K + gl] : 0.0)
+             : d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0);
+  if (d.standardize && !kVS) cw_clear_next(d, batch_id);
 
   double gct = 0.0;
   if (kLds) {
-    const int lo = blockIdx.x * draws_per_block;
+    const int lo = vblk * draws_per_block;
     const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
     for (int i = lo + group; i < hi; i += kThreads / kGroup)
-      gct += saga_draw_classlane<true>(d, d.stream[t0 + i], gl, batch_id, bl, Dl);
+      gct += saga_draw_classlane<true>(d, d.stream[t0 + i], gl, batch_id, bl, Dl, w_src);
   } else {
     const int i = blockIdx.x * (kThreads / kGroup) + group;
-    if (i < m) gct = saga_draw_classlane<false>(d, d.stream[t0 + i], gl, batch_id, bl, d.D);
+    if (i < m) gct = saga_draw_classlane<false>(d, d.stream[t0 + i], gl, batch_id, bl, d.D, w_src);
   }
   if (gct != 0.0) __hip_atomic_fetch_add(&d0s[gl], gct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   __syncthreads();
@@ -1507,8 +1516,11 @@ __global__ __launch_bounds__(kLds ? kLdsBlock : kBlock) void saga_batch_gather_c
     double* slab = d.slab + (int64_t)blockIdx.x * KP;
     for (int64_t i = threadIdx.x; i < KP; i += kThreads) slab[i] = Dl[i];
   }
-  if ((d.fit_intercept || d.standardize) && (int)threadIdx.x < K)
+  if (kVS) {
+    if ((int)threadIdx.x < K) d.vd0[(int64_t)blockIdx.x * K + threadIdx.x] = d0s[threadIdx.x];
+  } else if ((d.fit_intercept || d.standardize) && (int)threadIdx.x < K) {
     d0_publish(d, batch_id, threadIdx.x, d0s[threadIdx.x]);
+  }
 }
 
 // --------------------------------------------------------------------------
@@ -2870,10 +2882,10 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
 
 // Virtual shards need the K == 1 LDS gather with w staged in LDS and a grid that splits evenly.
 // Virtual shards need an LDS gather form and a grid that splits evenly: K == 1 with w staged in LDS (sparse or
-// dense x), or 2..4 classes of sparse x whose K x p accumulator fits (round 3; the replica of w is read through L2).
+// dense x), or 2..16 classes of sparse x whose K x p accumulator fits (round 3; the replica of w is read through L2).
 bool vs_eligible(const SagaDev& d, int m) {
   (void)m;
-  if (d.V < 2 || d.K < 1 || d.K > 4 || (d.standardize && !(d.vcw && d.c)) || d.force_global || !d.vw) return false;
+  if (d.V < 2 || d.K < 1 || d.K > 16 || (d.standardize && !(d.vcw && d.c)) || d.force_global || !d.vw) return false;
   const size_t table = sizeof(double) * (size_t)d.K * (size_t)d.p;
   if (d.K > 1) return !d.xd && d.rec && table <= 80 * 1024;
   if (d.xd) return table <= 80 * 1024;                           // dense x: only the accumulator is staged
@@ -2943,11 +2955,18 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
     if (!k4_attr_done[dev & 63]) {
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_lds_kernel<4, false, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_cl_kernel<true, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       k4_attr_done[dev & 63] = true;
     }
-    hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<4, false, true>), dim3(grid), dim3(kLdsBlock),
-                          sizeof(double) * (size_t)d.K * (size_t)d.p, st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_index,
-                          dpb);
+    if (d.K <= 4)
+      hipExtLaunchKernelGGL((saga_batch_gather_lds_kernel<4, false, true>), dim3(grid), dim3(kLdsBlock),
+                            sizeof(double) * (size_t)d.K * (size_t)d.p, st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_index,
+                            dpb);
+    else        // 5..16 classes: the class-lane form
+      hipExtLaunchKernelGGL((saga_batch_gather_cl_kernel<true, true>), dim3(grid), dim3(kLdsBlock),
+                            sizeof(double) * (size_t)d.K * (size_t)d.p, st, ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_index,
+                            dpb);
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;
   }
@@ -2981,8 +3000,10 @@ int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream
   const int nfb = (int)((d.p + F - 1) / F);
   if (d.K == 1)
     hipExtLaunchKernelGGL(saga_vs_sweep_kernel<1>, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
-  else
+  else if (d.K <= 4)
     hipExtLaunchKernelGGL(saga_vs_sweep_kernel<4>, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
+  else
+    hipExtLaunchKernelGGL(saga_vs_sweep_kernel<16>, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

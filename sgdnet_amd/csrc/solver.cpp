@@ -1905,8 +1905,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   d.V = 0;
   d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = nullptr;
   if (n_shards < 2) return SGDNET_OK;
-  if (d.K > 4 || (d.K > 1 && !s->sparse)) {
-    set_error("virtual shards: one response, or up to 4 classes of sparse x");
+  if (d.K > 16 || (d.K > 1 && !s->sparse)) {
+    set_error("virtual shards: one response, or up to 16 classes of sparse x");
     return SGDNET_EUNSUPPORTED;
   }
   const int64_t KP = (int64_t)d.K * d.p;

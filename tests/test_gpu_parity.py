@@ -1353,10 +1353,12 @@ def test_gradient_memory_moves_between_records_and_array_with_the_mode(sa, oracl
 
 @pytest.mark.parametrize("V,n,p,batch,family,K,penalty,centre", [
     (2, 4000, 60, 64, "multinomial", 3, "elasticnet", False), (4, 6002, 90, 100, "mgaussian", 2, "grouplasso", False),
-    (8, 8005, 50, 120, "multinomial", 4, "ridge", True), (2, 3001, 40, 3001, "multinomial", 3, "elasticnet", True)])
+    (8, 8005, 50, 120, "multinomial", 4, "ridge", True), (2, 3001, 40, 3001, "multinomial", 3, "elasticnet", True),
+    (4, 6003, 70, 90, "multinomial", 10, "elasticnet", False), (2, 4001, 30, 77, "mgaussian", 6, "grouplasso", True),
+    (8, 8008, 40, 100, "multinomial", 16, "elasticnet", True)])
 def test_virtual_shards_with_several_classes(sa, oracle, V, n, p, batch, family, K, penalty, centre):
-    """Round 3: virtual shards for 2..4 classes of sparse x (the LDS gather of the 16-lane draw against the shard's
-    replica, a sweep that owns K-vectors, per-class intercept partials): the oracle's batch halves driven through the
+    """Round 3: virtual shards for 2..16 classes of sparse x (the LDS gather of the 16-lane draw, or of the class-lane
+    draw from 5 classes on, against the shard's replica; a sweep that owns K-vectors; per-class intercept partials): the oracle's batch halves driven through the
     same shards, streams and merge points, including a group penalty, implicit centring, n not divisible by V and a
     window as long as a shard's epoch."""
     x, y = make_problem(family, K, n, p, 0.1, seed=31)
