@@ -35,14 +35,14 @@
 #include "sgdnet_detmath_tables.h"
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define SGD_EXP_TAB(j, c) sgd_exp_tab[j][c]
+#define SGD_EXP_TABPTR (&sgd_exp_tab[0][0])
 #define SGD_LOG_TAB(j, c) sgd_log_tab[j][c]
 #elif defined(__HIPCC__)
 /* host pass of a HIP translation unit: the tables are device symbols; the host copies are not needed there */
-#define SGD_EXP_TAB(j, c) 0.0
+#define SGD_EXP_TABPTR ((const double*)0)
 #define SGD_LOG_TAB(j, c) 0.0
 #else
-#define SGD_EXP_TAB(j, c) sgd_exp_tab[j][c]
+#define SGD_EXP_TABPTR (&sgd_exp_tab[0][0])
 #define SGD_LOG_TAB(j, c) sgd_log_tab[j][c]
 #endif
 
@@ -57,7 +57,8 @@ SGD_DM_FN double sgd_u2d(uint64_t u) {
   return x;
 }
 
-SGD_DM_FN double sgd_exp(double x) {
+/* `tab`: sgd_exp_tab as 128 consecutive doubles, or a copy of it (a kernel may keep one in on-chip memory) */
+SGD_DM_FN double sgd_exp_from(double x, const double* tab) {
   if (x != x) return x;
   if (x > 709.782712893384) return sgd_u2d(0x7ff0000000000000ull);      /* +inf */
   if (x < -745.2) return 0.0;
@@ -76,12 +77,14 @@ SGD_DM_FN double sgd_exp(double x) {
   const double p = r1 - (r2 - q);
   const int j = (int)((uint32_t)N & 63u);
   const int m = (N - j) / 64;
-  const double hi = SGD_EXP_TAB(j, 0), lo = SGD_EXP_TAB(j, 1);
+  const double hi = tab[2 * j], lo = tab[2 * j + 1];
   const double res = hi + (lo + (hi + lo) * p);
   if (m >= -1021 && m <= 1023) return res * sgd_u2d((uint64_t)(m + 1023) << 52);
   if (m > 1023) return res * sgd_u2d((uint64_t)(m - 1 + 1023) << 52) * 2.0;
   return res * sgd_u2d((uint64_t)(m + 1000 + 1023) << 52) * sgd_u2d((uint64_t)(1023 - 1000) << 52);   /* subnormal range */
 }
+
+SGD_DM_FN double sgd_exp(double x) { return sgd_exp_from(x, SGD_EXP_TABPTR); }
 
 SGD_DM_FN double sgd_log(double x) {
   if (x != x) return x;

@@ -166,6 +166,12 @@ int sgdnet_device_count(void);
 /*                        dense x of >= 4e6 elements; 1: host loops          */
 /*   "exact_epoch_blocks" 1 (default): exact mode with the built-in generator*/
 /*                        runs several epochs per launch; 0: one per launch  */
+/*   "exact_row_registers" 1 (default): exact mode on sparse x with one      */
+/*                        response and explicit x keeps the drawn row's      */
+/*                        coefficients in registers for the whole draw and   */
+/*                        requests the next draw's a draw ahead (same bits,  */
+/*                        DESIGN.md 4.1); 0: the general kernel; 2: as 1 but */
+/*                        the state stays in memory where the LDS would fit it*/
 /* Unknown names and out-of-range values return SGDNET_EINVAL.  Options are  */
 /* read when a fit starts; changing them during a fit on another thread      */
 /* affects later fits only.                                                  */

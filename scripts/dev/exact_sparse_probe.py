@@ -7,8 +7,10 @@ import torch
 import sgdnet_amd as sa
 from test_gpu_parity import make_problem
 
-for family, K, n, p, dens, epochs in (("binomial", 1, 20000, 200, 0.05, 3), ("gaussian", 1, 20000, 1000, 0.03, 3),
-                                      ("multinomial", 3, 20000, 200, 0.05, 3)):
+for family, K, n, p, dens, epochs, reg in [(f, K, n, p, dn, e, r) for (f, K, n, p, dn, e) in (
+        ("binomial", 1, 20000, 200, 0.05, 3), ("gaussian", 1, 20000, 1000, 0.03, 3), ("binomial", 1, 200000, 10000, 0.001, 2),
+        ("binomial", 1, 100000, 50000, 0.0002, 2), ("multinomial", 3, 20000, 200, 0.05, 3)) for r in ((0, 1, 2) if K == 1 else (0,))]:
+    sa.set_option("exact_row_registers", reg)
     x, y = make_problem(family, K, n, p, dens, seed=2)
     S = sa.SagaSolver(x, y, family=family, n_classes=K)
     S.set_penalty("elasticnet", 0.02, 1e-3, 1e-3)
@@ -18,6 +20,6 @@ for family, K, n, p, dens, epochs in (("binomial", 1, 20000, 200, 0.05, 3), ("ga
     t = time.time()
     S.run(mode="exact", max_epochs=epochs, tol=0.0, stream_offset=n)
     S.sync()
-    print(f"sparse {family} K={K} n={n} p={p} ({dens * p:.0f} nnz/row): {(time.time() - t) / (epochs * n) * 1e6:.2f} us per iteration",
+    print(f"registers={reg} sparse {family} K={K} n={n} p={p} ({dens * p:.0f} nnz/row): {(time.time() - t) / (epochs * n) * 1e6:.2f} us per iteration",
           flush=True)
     S.close()

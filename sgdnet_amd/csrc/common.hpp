@@ -38,7 +38,8 @@ inline const char* exp_env_str(const char*) { return nullptr; }
 #endif
 
 // sgdnet_set_option values (solver.cpp)
-enum Option { kOptVirtualShards = 0, kOptRngGenerators, kOptWindowEigenvalue, kOptHostSetup, kOptExactEpochBlocks, kOptCount };
+enum Option { kOptVirtualShards = 0, kOptRngGenerators, kOptWindowEigenvalue, kOptHostSetup, kOptExactEpochBlocks,
+              kOptExactRowRegisters, kOptCount };
 int option(Option o);
 
 #define SGD_HIP_TRY(expr)                                                              \
@@ -163,6 +164,7 @@ struct ExactCtl {
   double tol;
   const double* LS;     // lag_scaling table, nit + 1 entries (sparse)
   int use_lds;          // w, g_sum (and lag) staged in LDS
+  int ls_cache;         // register-resident sparse kernel: lag_scaling entries kept in LDS
   int* out;             // [0] epochs run, [1] converged
 };
 
@@ -172,6 +174,9 @@ int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& 
 int launch_dense_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
                        hipStream_t st);
 size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state);
+bool sparse_exact_k1_eligible(const SagaDev& d);
+size_t sparse_exact_k1_lds_bytes(const SagaDev& d, int64_t nit, bool allow_stage, int* ls_cache, int* stage_state);
+int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st);
 size_t dense_exact_small_lds_bytes(const SagaDev& d, int64_t nit);
 int dense_exact_wide_threads(const SagaDev& d);
 size_t dense_exact_wide_lds_bytes(const SagaDev& d, bool stage_state);

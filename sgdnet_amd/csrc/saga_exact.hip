@@ -37,6 +37,11 @@ __device__ __forceinline__ void wave_sync(bool lds_only) {
   }
 }
 
+// Lanes of ONE wavefront exchanging data through the LDS: the hardware runs the wavefront's LDS operations in
+// program order, the compiler only has to emit them in that order (it reasons per thread and would otherwise
+// forward a lane's own store to its next load, or drop a store that the same lane overwrites later).
+__device__ __forceinline__ void lanes_publish() { asm volatile("" ::: "memory"); }
+
 __device__ __forceinline__ double readlane_d(double v, int src) {
   const long long b = __double_as_longlong(v);
   const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
@@ -390,6 +395,416 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
     d.gb[k] = sgb[k];
   }
   if (lane == 0) {
+    ctl.out[0] = (int)it_outer;
+    ctl.out[1] = converged;
+  }
+}
+
+// --------------------------------------------------------------------------
+// One response, explicit x (no implicit centring): the register-resident iteration (round 3).
+//
+// The general kernel above pays a memory round trip per phase of a draw -- lag, then w and g_sum, the
+// store, w again for the dot product, w for AddWeighted, lag / w / g_sum for the SAGA step: ~7 dependent
+// trips of 300-400 ns through L2 when the state does not fit the LDS.  Here lane e owns entry e of the drawn
+// row for the WHOLE draw: it is handed w[j], g_sum[j], lag[j] and the lag scaling of its feature at the top
+// of the iteration, runs catch-up (:263-272), its product of the ascending sum (:274), AddWeighted
+// (:306-313), the SAGA step (:316-325) and the g_sum update (:328-335) on registers -- the same operations
+// on the same doubles in the same order per feature, so the state stays bit for bit -- and stores once.
+// Nothing the next draws need from memory depends on the solver state except through features two draws
+// share, so the stream runs four draws ahead, the row pointers three, the row two, and w / g_sum / lag /
+// y / gradient memory one; a feature the current draw also holds is forwarded from its lane's registers
+// (the stores of earlier draws are older memory operations of this wavefront and are seen in order).
+// Rows longer than the wavefront, the `wscale < SMALL` reset and the epoch end work on memory, after which
+// the one-ahead state is fetched again.
+// --------------------------------------------------------------------------
+constexpr int kOwnSlots = 8192;                                   // bytes: feature (hashed) -> lane of the draw in hand
+constexpr int kK1Sum = kWave + 8;                                 // products of the draw in hand, padded to whole blocks
+constexpr size_t kK1FixedLds = sizeof(double) * (kK1Sum + 128) + kOwnSlots;
+
+template <bool kLds>
+__global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, const LamParams* lamp,
+                                                                     ExactCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int64_t p = d.p;
+  const unsigned L = (unsigned)ctl.ls_cache;      // lag_scaling entries kept in LDS
+  double* sx = reinterpret_cast<double*>(smem);                       // [kK1Sum]
+  double* sexp = sx + kK1Sum;                                         // [128]: sgd_exp_tab (a global table would queue
+                                                                      // behind the row requests: the counter retires in order)
+  unsigned char* owner = reinterpret_cast<unsigned char*>(sexp + 128);
+  double* sls = reinterpret_cast<double*>(owner + kOwnSlots);
+  double* w;
+  double* G;
+  unsigned* lag;
+  if constexpr (kLds) {
+    w = sls + L;
+    G = w + p;
+    lag = reinterpret_cast<unsigned*>(G + p);
+    for (int64_t i = lane; i < p; i += kWave) {
+      w[i] = d.w[i];
+      G[i] = d.G[i];
+    }
+  } else {
+    w = d.w;
+    G = d.G;
+    lag = d.lag;
+  }
+  const unsigned nit = (unsigned)ctl.nit;
+  const double* LS = ctl.LS;
+  for (unsigned i = lane; i < L; i += kWave) sls[i] = LS[i];
+  for (int i = lane; i < 128; i += kWave) sexp[i] = SGD_EXP_TABPTR[i];
+  for (int i = lane; i < kOwnSlots / 4; i += kWave) reinterpret_cast<unsigned*>(owner)[i] = 0u;
+  for (int i = lane; i < kK1Sum; i += kWave) sx[i] = 0.0;
+  for (int64_t j = lane; j < p; j += kWave) lag[j] = 0u;            // saga-sparse.h:225
+  for (int64_t i = lane; i < p; i += kWave) d.w_prev[i] = w[i];      // :251
+  __syncthreads();
+
+  auto ls_at = [&](unsigned m) -> double { return m < L ? sls[m] : LS[m]; };
+
+  const int penalty = lamp->penalty;
+  const bool group = penalty == SGDNET_GROUPLASSO;                    // one response: a group of one (generic functor)
+  const bool l1 = penalty == SGDNET_ELASTICNET;
+  const int family = d.family;
+  const bool fit_intercept = d.fit_intercept != 0;
+  const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
+  const double wscale_update = 1.0 - alpha * gamma;                  // :234
+  const double n_d = d.n_total, rn_d = 1.0 / n_d;
+  const double g_scale = 1.0 / n_d;                                  // AddWeighted(g_sum, ..., 1/n)
+  const double ls_one = ls_at(1u);                                    // the SAGA step always lags by one
+  const double bg = beta * gamma;                                    // penalties.h:49: beta * gamma * scaling / w_scale
+  const double bg_ls1 = bg * ls_one;
+  double b = d.b[0], gb = d.gb[0];                                   // intercept, g_sum_intercept: every lane the same
+  double W = 1.0;                                                    // w_scale  :227
+  double q_prev = gamma / W;                                         // gamma / w_scale as the catch-up sees it
+  double q_t = 0.0, tau1_t = 0.0, tauc = 0.0, Wp_t = 0.0;            // see `prepare`
+
+  unsigned it_outer = 0;
+  int converged = 0;
+  int64_t t = ctl.stream_off;
+  const int64_t t_last = ctl.stream_off + (int64_t)ctl.max_epochs * nit - 1;
+  auto clampt = [&](int64_t x) { return x < t_last ? x : t_last; };
+
+  // ---- fill the pipeline: stream (t .. t+3), row pointers (t .. t+2), row (t, t+1), state (t) ----
+  uint32_t s0 = d.stream[clampt(t)], s1 = d.stream[clampt(t + 1)], s2 = d.stream[clampt(t + 2)],
+           s3 = d.stream[clampt(t + 3)];
+  int64_t a0 = d.ptr[s0], e0 = d.ptr[s0 + 1];
+  int64_t a1 = d.ptr[s1], e1 = d.ptr[s1 + 1];
+  int64_t a2 = d.ptr[s2], e2 = d.ptr[s2 + 1];
+  int idx0 = 0, idx1 = 0;
+  double val0 = 0.0, val1 = 0.0;
+  if (a0 + lane < e0) {
+    idx0 = d.idx[a0 + lane];
+    val0 = d.val[a0 + lane];
+  }
+  if (a1 + lane < e1) {
+    idx1 = d.idx[a1 + lane];
+    val1 = d.val[a1 + lane];
+  }
+  double y0 = d.y[s0], m0 = d.M[s0];
+  double w0 = 0.0, G0 = 0.0, lsc0 = 0.0;
+  unsigned lag0 = 0u;
+  // state of the draw in hand, from memory (first draw of a launch or an epoch, after a long row, after a
+  // scale reset): everything older has been stored and waited for
+  auto fetch_state = [&](unsigned it_of_draw) {
+    w0 = 0.0;
+    G0 = 0.0;
+    lag0 = it_of_draw;
+    if (a0 + lane < e0 && e0 - a0 <= kWave) {
+      w0 = w[idx0];
+      G0 = G[idx0];
+      lag0 = lag[idx0];
+    }
+    lsc0 = ls_at(it_of_draw - lag0);
+  };
+  // Everything the coming draw divides by w_scale, in ONE division: W is w_scale as its catch-up sees it, Wp what
+  // the draw leaves behind ((W < SMALL ? 1 : W) * update, :285-297).  Lanes 0..61 take the soft threshold of their
+  // catch-up, beta*gamma*lag_scaling / W; lane 62 the SAGA step's, beta*gamma*lag_scaling[1] / Wp; lane 63
+  // gamma / Wp -- the quotients the reference forms, formed once (a division costs a lone wavefront ~300 cycles).
+  auto prepare = [&]() {
+    const double Wp = (W < kSmall ? 1.0 : W) * wscale_update;
+    const double bgl = bg * lsc0;
+    const double num = lane == 63 ? gamma : (lane == 62 ? bg_ls1 : bgl);
+    const double den = lane >= 62 ? Wp : W;
+    const double r = num / den;
+    q_t = readlane_d(r, 63);
+    tau1_t = readlane_d(r, 62);
+    tauc = r;
+    if (e0 - a0 > 62) tauc = bgl / W;       // a row that needs lanes 62 and 63 for itself
+    Wp_t = Wp;
+#ifdef K1_DBG_PREP
+    q_t = gamma / Wp;
+    tau1_t = bg_ls1 / Wp;
+    tauc = bgl / W;
+#endif
+  };
+  fetch_state(0u);
+  prepare();
+#ifdef SGDNET_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define K1_STAMP(i) do { const unsigned long long now_ = clock64(); ph[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define K1_STAMP(i) ((void)0)
+#endif
+
+  do {
+    for (unsigned it = 0; it < nit; ++it, ++t) {
+#ifdef SGDNET_PHASE_TIMING
+      unsigned long long last_ = clock64();
+#endif
+      // ---- the draw in hand, and the requests of the draws behind it -------------------------------
+      const uint32_t s = s0;                                         // :261
+      const int64_t q0 = a0, q1 = e0;
+      const int idx_c = idx0;
+      const double val_c = val0;
+      const double y_c = y0, m_c = m0;
+      const int len = (int)((q1 - q0) < (int64_t)(kWave + 1) ? (q1 - q0) : (int64_t)(kWave + 1));
+      const bool shortrow = len <= kWave;
+      const bool mine = lane < len && shortrow;
+      s0 = s1;
+      s1 = s2;
+      s2 = s3;
+      a0 = a1;
+      e0 = e1;
+      a1 = a2;
+      e1 = e2;
+      idx0 = idx1;
+      val0 = val1;
+      // w / g_sum / lag of the next draw, requested before this draw's stores (forwarded below) and before the
+      // requests that go to HBM
+      const bool mine_n = a0 + lane < e0 && e0 - a0 <= kWave;
+      double w_n = 0.0, G_n = 0.0;
+      unsigned lag_n = it + 1u;
+      if (mine_n) {
+        w_n = w[idx0];
+        G_n = G[idx0];
+        lag_n = lag[idx0];
+      }
+      y0 = d.y[s0];
+      m0 = d.M[s0];
+      idx1 = 0;
+      val1 = 0.0;
+      if (a1 + lane < e1) {
+        idx1 = d.idx[a1 + lane];
+        val1 = d.val[a1 + lane];
+      }
+      a2 = d.ptr[s2];
+      e2 = d.ptr[s2 + 1];
+      s3 = d.stream[clampt(t + 4)];
+      // which lane of this draw, if any, holds the feature a lane of the next draw asked for
+      unsigned cand = 0u;
+      bool collide = false;
+      if (shortrow) {
+        const int h_c = idx_c & (kOwnSlots - 1), h_n = idx0 & (kOwnSlots - 1);
+        // (lanes talk through the LDS here: the compiler must neither forward a lane's own store to its load
+        // nor drop the first store as dead -- the LDS itself runs a wavefront's operations in order)
+        if (mine) owner[h_c] = (unsigned char)(lane + 1);
+        lanes_publish();
+        const unsigned chk = mine ? owner[h_c] : (unsigned)(lane + 1);
+        cand = mine_n ? owner[h_n] : 0u;
+        lanes_publish();
+        if (mine) owner[h_c] = 0;
+        collide = __ballot(chk != (unsigned)(lane + 1)) != 0ull;   // two features of this row share a slot: compare instead
+#ifdef K1_DBG_MATCH
+        collide = true;
+#endif
+      }
+
+      K1_STAMP(0);
+      double wj = w0, Gj = G0;
+      double acc = 0.0;
+      if (shortrow) {
+        // LaggedUpdate(it_inner): catch-up of the sample's features  :263-272
+        const unsigned lagged = it - lag0;
+        if (mine && lagged != 0u) {
+          if (group) {
+            penalty_apply_q(penalty, 1, &wj, &Gj, W, lsc0, q_prev, gamma, beta);
+          } else {
+            const double f = q_prev * lsc0;
+            const double v = wj - f * Gj;
+            wj = l1 ? soft_threshold(v, tauc) : v;
+          }
+        }
+        // linear predictor, ascending feature order  :274 (products past the row are +0.0: adding them changes nothing)
+        sx[lane] = mine ? val_c * wj : 0.0;
+        lanes_publish();
+        K1_STAMP(1);
+#ifdef K1_DBG_SUM
+        { const double wx_ = mine ? val_c * wj : 0.0; for (int e = 0; e < len; ++e) acc += readlane_d(wx_, e); }
+#else
+        for (int eb = 0; eb < len; eb += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc += sx[eb + u];
+        }
+#endif
+      } else {
+        __syncthreads();                     // the stores of the draws before it
+        for (int64_t q = q0 + lane; q < q1; q += kWave) {
+          const int64_t j = d.idx[q];
+          const unsigned lagged = it - lag[j];
+          if (lagged != 0u) {
+            penalty_apply_q(penalty, 1, w + j, G + j, W, ls_at(lagged), q_prev, gamma, beta);
+            lag[j] = it;
+          }
+        }
+        __syncthreads();
+        for (int64_t base = q0; base < q1; base += kWave) {
+          const int64_t q = base + lane;
+          const double wx = q < q1 ? d.val[q] * w[d.idx[q]] : 0.0;
+          const int cnt = (q1 - base) < (int64_t)kWave ? (int)(q1 - base) : kWave;
+          for (int e = 0; e < cnt; ++e) acc += readlane_d(wx, e);
+        }
+      }
+      const double lp = acc * W + b;
+      K1_STAMP(2);
+
+      // gradient, gradient memory  :279-282
+      double g;
+      if (family == SGDNET_BINOMIAL)
+        g = 1.0 - y_c - 1.0 / (1.0 + sgd_exp_from(lp, sexp));
+      else
+        g = lp - y_c;
+      const double gc = g - m_c;
+      K1_STAMP(3);
+      if (lane == 0) d.M[s] = g;
+      if (s0 == s) m0 = g;                  // the next draw repeats this sample: forward its memory
+
+      // rescale + unlag whenever wscale becomes too small  :285-295
+      bool refetch = !shortrow;
+      if (W < kSmall) {
+        if (mine) {                          // the caught-up features go to memory first
+          w[idx_c] = wj;
+          lag[idx_c] = it;
+        }
+        __syncthreads();
+        for (int64_t j = lane; j < p; j += kWave) {
+          const unsigned lagged = it - lag[j];
+          if (lagged != 0u) penalty_apply(penalty, 1, w + j, G + j, W, ls_at(lagged), gamma, beta);
+          w[j] *= W;
+          lag[j] = it;
+        }
+        __syncthreads();
+        if (mine) wj = w[idx_c];
+        refetch = true;
+      }
+      W = Wp_t;                                                      // :297 (after the reset, if any)
+
+      if (fit_intercept) {                                           // :300-304
+        const double gck = div_by_n_exact(gc, n_d, rn_d);
+        gb = gb + gck;
+        b -= gamma * (gb * 0.01 + gck);
+      }
+      K1_STAMP(4);
+
+      if (shortrow) {
+        if (mine) {
+          wj += val_c * gc * (-q_t);                                 // AddWeighted(w, ..., -gamma/wscale)  :306-313
+          // LaggedUpdate(it_inner + 1): the SAGA step (the feature was caught up to `it`, so it lags by one) :316-325
+          if (group) {
+            penalty_apply_q(penalty, 1, &wj, &Gj, W, ls_one, q_t, gamma, beta);
+          } else {
+            const double f = q_t * ls_one;
+            const double v = wj - f * Gj;
+            wj = l1 ? soft_threshold(v, tau1_t) : v;
+          }
+          Gj += val_c * gc * g_scale;                                // AddWeighted(g_sum, ..., 1/n)  :328-335
+          w[idx_c] = wj;
+          G[idx_c] = Gj;
+          lag[idx_c] = it + 1u;
+        }
+      } else {
+        const double scaling = -q_t;
+        for (int64_t q = q0 + lane; q < q1; q += kWave) w[d.idx[q]] += d.val[q] * gc * scaling;
+        for (int64_t q = q0 + lane; q < q1; q += kWave) {
+          const int64_t j = d.idx[q];
+          const unsigned lagged = (it + 1u) - lag[j];
+          if (lagged != 0u) {
+            penalty_apply_q(penalty, 1, w + j, G + j, W, ls_at(lagged), q_t, gamma, beta);
+            lag[j] = it + 1u;
+          }
+          G[j] += d.val[q] * gc * g_scale;
+        }
+      }
+      q_prev = q_t;
+
+      K1_STAMP(5);
+      // ---- hand the next draw its state ------------------------------------------------------------
+      if (refetch || it + 1u == nit) {
+        // memory was rewritten behind the request (or is about to be, by Reset): ask again once the stores are in
+        if (it + 1u < nit) {
+          __syncthreads();
+          fetch_state(it + 1u);
+          prepare();
+        }
+      } else {
+        bool hit = false;
+        int src = 0;
+        if (!collide) {
+          src = (int)cand - 1;
+          hit = cand != 0u;
+          if (__ballot(hit) != 0ull) {
+            const int je = __shfl(idx_c, src & (kWave - 1), kWave);     // every lane takes part: the source lanes must be live
+            hit = hit && je == idx0;
+          }
+        } else {
+          for (int e = 0; e < len; ++e) {
+            const int je = __builtin_amdgcn_readlane(idx_c, e);
+            if (mine_n && idx0 == je) {
+              src = e;
+              hit = true;
+            }
+          }
+        }
+        if (__ballot(hit) != 0ull) {
+          const double wf = __shfl(wj, src & (kWave - 1), kWave);
+          const double Gf = __shfl(Gj, src & (kWave - 1), kWave);
+          if (hit) {
+            w_n = wf;
+            G_n = Gf;
+            lag_n = it + 1u;
+          }
+        }
+        w0 = w_n;
+        G0 = G_n;
+        lag0 = lag_n;
+        lsc0 = ls_at((it + 1u) - lag_n);
+        prepare();
+      }
+      K1_STAMP(6);
+    }
+
+    // Reset(n_samples): unlag and rescale  :340-348
+    __syncthreads();
+    for (int64_t j = lane; j < p; j += kWave) {
+      const unsigned lagged = nit - lag[j];
+      if (lagged != 0u) penalty_apply(penalty, 1, w + j, G + j, W, ls_at(lagged), gamma, beta);
+      w[j] *= W;
+      lag[j] = 0u;
+    }
+    W = 1.0;
+    q_prev = gamma / W;
+    __syncthreads();
+
+    converged = convergence_check(w, d.w_prev, p, ctl.tol, lane);    // :367
+    ++it_outer;
+    __syncthreads();
+    fetch_state(0u);
+    prepare();
+  } while (!converged && it_outer < ctl.max_epochs);                 // :371
+
+  if constexpr (kLds) {
+    for (int64_t i = lane; i < p; i += kWave) {
+      d.w[i] = w[i];
+      d.G[i] = G[i];
+    }
+  }
+#ifdef SGDNET_PHASE_TIMING
+  if (d.dbg && lane == 0)
+    for (int i = 0; i < 8; ++i) d.dbg[i] += ph[i];
+#endif
+#undef K1_STAMP
+  if (lane == 0) {
+    d.b[0] = b;
+    d.gb[0] = gb;
     ctl.out[0] = (int)it_outer;
     ctl.out[1] = converged;
   }
@@ -1246,6 +1661,40 @@ size_t dense_exact_lds_bytes(const SagaDev& d, bool stage_state) {
   size_t b = sizeof(double) * (4 * (size_t)d.K + (size_t)d.Ky + (size_t)d.p);
   if (stage_state) b += sizeof(double) * 2 * (size_t)d.K * (size_t)d.p;
   return (b + 15) & ~size_t(15);
+}
+
+// The register-resident kernel: one response, explicit x.  LDS = the lag_scaling cache, plus w, g_sum and lag
+// when they fit beside at least 2048 entries of it; `*ls_cache` / `*stage_state` tell the launch what was chosen.
+bool sparse_exact_k1_eligible(const SagaDev& d) {
+  return d.K == 1 && d.Ky == 1 && !d.standardize && d.family != SGDNET_MULTINOMIAL && d.ptr && d.idx && d.val;
+}
+
+size_t sparse_exact_k1_lds_bytes(const SagaDev& d, int64_t nit, bool allow_stage, int* ls_cache, int* stage_state) {
+  const size_t cap = 160 * 1024 - 256 - kK1FixedLds;
+  const size_t state = (sizeof(double) * 2 + sizeof(unsigned)) * (size_t)d.p;
+  const size_t want = (size_t)nit + 1;
+  const size_t floor_entries = want < 2048 ? want : 2048;
+  const bool stage = allow_stage && state + sizeof(double) * floor_entries <= cap;
+  size_t entries = (cap - (stage ? state : 0)) / sizeof(double);
+  if (entries > want) entries = want;
+  *ls_cache = (int)entries;
+  *stage_state = stage ? 1 : 0;
+  return (kK1FixedLds + sizeof(double) * entries + (stage ? state : 0) + 15) & ~size_t(15);
+}
+
+int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                           hipStream_t st) {
+  if (ctl.use_lds) {
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_sparse_exact_k1_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(saga_sparse_exact_k1_kernel<true>, dim3(1), dim3(kWave), lds_bytes, st, d, lam, ctl);
+  } else {
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_sparse_exact_k1_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(saga_sparse_exact_k1_kernel<false>, dim3(1), dim3(kWave), lds_bytes, st, d, lam, ctl);
+  }
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
 }
 
 int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,

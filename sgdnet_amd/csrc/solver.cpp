@@ -778,9 +778,9 @@ struct OptionDef {
 };
 const OptionDef kOptionDefs[sgdnet::kOptCount] = {
     {"virtual_shards", -1, -1, 8}, {"rng_generators", 0, 0, 64},     {"window_eigenvalue", 1, 0, 1},
-    {"host_setup", 0, 0, 1},       {"exact_epoch_blocks", 1, 0, 1},
+    {"host_setup", 0, 0, 1},       {"exact_epoch_blocks", 1, 0, 1}, {"exact_row_registers", 1, 0, 2},
 };
-std::atomic<int> g_options[sgdnet::kOptCount] = {{-1}, {0}, {1}, {0}, {1}};
+std::atomic<int> g_options[sgdnet::kOptCount] = {{-1}, {0}, {1}, {0}, {1}, {1}};
 int find_option(const char* name) {
   if (name)
     for (int i = 0; i < sgdnet::kOptCount; ++i)
@@ -1435,6 +1435,12 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     // wider dense rows (up to 16 classes): the workgroup-per-iteration kernel; SGDNET_EXACT_WIDE=0 keeps the one-wavefront one
     static const int wide_ok = exp_env_int("SGDNET_EXACT_WIDE", 1);
     const bool wide = !s->sparse && !lds_small && wide_ok && dense_exact_wide_threads(s->d) > 0;
+    // sparse x, one response, no implicit centring: the register-resident iteration (option exact_row_registers:
+    // 0 keeps the general kernel, 2 keeps the state out of the LDS even where it fits)
+    const int k1_opt = option(kOptExactRowRegisters);
+    const bool k1 = s->sparse && k1_opt != 0 && sparse_exact_k1_eligible(s->d);
+    int k1_cache = 0, k1_stage = 0;
+    const size_t k1_lds = k1 ? sparse_exact_k1_lds_bytes(s->d, draws_per_epoch, k1_opt != 2, &k1_cache, &k1_stage) : 0;
     const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true)
                                       : (wide ? dense_exact_wide_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true));
     const bool stage = lds_full <= lds_cap;
@@ -1462,7 +1468,12 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       ctl.LS = s->LS_dev;
       ctl.use_lds = stage ? 1 : 0;
       ctl.out = s->out_dev;
-      rc = s->sparse ? launch_sparse_exact(s->d, s->lam_dev, ctl, lds, s->st)
+      if (k1) {
+        ctl.use_lds = k1_stage;
+        ctl.ls_cache = k1_cache;
+      }
+      rc = k1 ? launch_sparse_exact_k1(s->d, s->lam_dev, ctl, k1_lds, s->st)
+         : s->sparse ? launch_sparse_exact(s->d, s->lam_dev, ctl, lds, s->st)
                      : (lds_small ? launch_dense_exact_small(s->d, s->lam.penalty, s->lam_dev, ctl, lds_small, s->st)
                         : wide    ? launch_dense_exact_wide(s->d, s->lam_dev, ctl, lds, s->st)
                                   : launch_dense_exact(s->d, s->lam_dev, ctl, lds, s->st));
@@ -1477,6 +1488,16 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         losses[done] = sum / (double)s->d.n;
       }
 #ifdef SGDNET_PHASE_TIMING
+      if (k1 && s->d.dbg && out[0] > 0) {
+        unsigned long long ph[8];
+        SGD_HIP_TRY(hipMemcpy(ph, s->d.dbg, sizeof(ph), hipMemcpyDeviceToHost));
+        (void)hipMemset(s->d.dbg, 0, sizeof(ph));
+        const double its = (double)out[0] * (double)draws_per_epoch;
+        fprintf(stderr, "[sgdnet] register-resident sparse kernel, cycles per draw: requests %.0f, catch-up %.0f, sum %.0f, gradient %.0f, "
+                        "scale+intercept %.0f, step+stores %.0f, forward %.0f\n",
+                (double)ph[0] / its, (double)ph[1] / its, (double)ph[2] / its, (double)ph[3] / its, (double)ph[4] / its, (double)ph[5] / its,
+                (double)ph[6] / its);
+      }
       if (wide && s->d.dbg && out[0] > 0) {   // development aid: shader-clock cycles of thread 0 per phase of the wide kernel
         unsigned long long ph[6];
         SGD_HIP_TRY(hipMemcpy(ph, s->d.dbg, sizeof(ph), hipMemcpyDeviceToHost));

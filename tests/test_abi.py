@@ -83,7 +83,7 @@ def test_backend_options_are_the_documented_ones():
     variable (they exist in -DSGDNET_EXPERIMENTS builds only)."""
     import sgdnet_amd as sa
     defaults = {"virtual_shards": -1, "rng_generators": 0, "window_eigenvalue": 1, "host_setup": 0,
-                "exact_epoch_blocks": 1}
+                "exact_epoch_blocks": 1, "exact_row_registers": 1}
     for name, dflt in defaults.items():
         assert sa.get_option(name) == dflt
         assert name in open(os.path.join(ROOT, "include", "sgdnet_hip.h")).read()

@@ -61,3 +61,75 @@ def test_wide_dense_kernel_and_convergence_epochs(sa, det):
     assert ref[0] == got[0] and ref[0] < 300                                           # same stopping epoch
     for name in STATE:
         assert relerr(got[2][name], ref[2][name]) < 1e-10, name
+
+
+def _ragged_problem(family, n, p, lengths, seed):
+    """Sparse x (features x samples, as make_problem gives it) whose sample i holds lengths[i % len(lengths)]
+    non-zeros: empty rows, rows of exactly one wavefront, rows past it."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    indptr, indices, data = [0], [], []
+    for i in range(n):
+        k = min(int(lengths[i % len(lengths)]), p)
+        indices.append(np.sort(rng.choice(p, size=k, replace=False)))
+        data.append(rng.standard_normal(k) / np.sqrt(max(k, 1)))
+        indptr.append(indptr[-1] + k)
+    x = sp.csc_matrix((np.concatenate(data), np.concatenate(indices).astype(np.int32), np.asarray(indptr, dtype=np.int64)),
+                      shape=(p, n))
+    lp = np.asarray(x.T @ rng.standard_normal(p)).ravel()
+    if family == "binomial":
+        y = (rng.random(n) < 1 / (1 + np.exp(-lp))).astype(float)
+    else:
+        y = lp + 0.1 * rng.standard_normal(n)
+    return x, np.asfortranarray(y.reshape(1, n))
+
+
+ROW_REGISTER_CASES = {
+    # name: (family, penalty, n, p, density or row lengths, gamma, alpha, beta, epochs, fit_intercept)
+    "crowded": ("binomial", "elasticnet", 800, 12, 0.5, 0.05, 5e-4, 5e-4, 4, True),       # neighbours share features
+    "gaussian_ridge": ("gaussian", "ridge", 1500, 80, 0.06, 0.05, 1e-3, 0.0, 3, True),
+    "group_of_one": ("gaussian", "grouplasso", 1200, 50, 0.1, 0.03, 1e-3, 2e-3, 3, False),
+    "ragged": ("binomial", "elasticnet", 900, 200, (0, 3, 64, 65, 1, 130, 17, 64, 0, 200), 0.04, 5e-4, 1e-3, 3, True),
+    "all_long": ("gaussian", "elasticnet", 400, 300, (120, 90, 70), 0.02, 1e-3, 1e-3, 2, True),
+    "scale_reset": ("gaussian", "elasticnet", 1500, 60, 0.1, 0.3, 1.0, 1e-3, 2, True),    # wscale < SMALL every ~90 draws
+    "scale_reset_ragged": ("gaussian", "elasticnet", 600, 150, (5, 80, 2, 64), 0.3, 1.0, 1e-3, 2, True),
+    "state_in_memory": ("binomial", "elasticnet", 25000, 9000, 0.001, 0.05, 2e-5, 2e-5, 2, True),  # lags past the LDS cache
+}
+
+
+@pytest.mark.parametrize("case", sorted(ROW_REGISTER_CASES))
+@pytest.mark.parametrize("registers", [0, 1, 2])
+def test_register_resident_sparse_kernel_is_bit_identical(sa, det, case, registers):
+    """Round 3: `saga_sparse_exact_k1_kernel` (one response: the row's lanes keep w, g_sum and lag of their features
+    in registers for the whole draw, the state of the next draw is requested a draw ahead and forwarded where two
+    draws share a feature) against the det-math restatement -- equal, like the general kernel (option
+    exact_row_registers = 0) it replaces; 2 keeps the state in memory even where the LDS would hold it."""
+    from test_gpu_parity import make_problem
+    family, penalty, n, p, shape, gamma, alpha, beta, epochs, fit_intercept = ROW_REGISTER_CASES[case]
+    if isinstance(shape, tuple):
+        x, y = _ragged_problem(family, n, p, shape, seed=11)
+    else:
+        x, y = make_problem(family, 1, n, p, shape, seed=7)
+    with sa.option("exact_row_registers", registers):
+        ref, got = run(sa, det, x, y, family=family, K=1, penalty=penalty, gamma=gamma, alpha=alpha, beta=beta,
+                       epochs=epochs, fit_intercept=fit_intercept)
+    assert ref[0] == got[0]
+    for name in STATE:
+        assert np.array_equal(got[2][name], ref[2][name]), name
+
+
+@pytest.mark.parametrize("registers", [0, 1, 2])
+def test_register_resident_kernel_with_repeated_draws_and_early_stop(sa, det, registers):
+    # the same sample drawn several times in a row (its gradient memory and every feature are forwarded), and a
+    # tolerance that stops the launch inside its block of epochs
+    from test_gpu_parity import make_problem, run_both
+    x, y = make_problem("binomial", 1, 700, 40, 0.15, seed=4)
+    n = 700
+    rng = np.random.default_rng(1)
+    stream = np.repeat(rng.integers(0, n, size=n * 40 // 3 + 3), 3)[: n * 40].astype(np.uint32)
+    with sa.option("exact_row_registers", registers):
+        ref, got = run_both(sa, det, x, y, family="binomial", K=1, penalty="elasticnet", gamma=0.05, alpha=1e-3,
+                            beta=1e-3, epochs=40, mode="exact", tol=1e-2, stream=stream)
+    assert ref[0] == got[0] and ref[0] < 40
+    for name in STATE:
+        assert np.array_equal(got[2][name], ref[2][name]), name
