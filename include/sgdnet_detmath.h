@@ -57,32 +57,35 @@ SGD_DM_FN double sgd_u2d(uint64_t u) {
   return x;
 }
 
-/* `tab`: sgd_exp_tab as 128 consecutive doubles, or a copy of it (a kernel may keep one in on-chip memory) */
-SGD_DM_FN double sgd_exp_from(double x, const double* tab) {
-  if (x != x) return x;
-  if (x > 709.782712893384) return sgd_u2d(0x7ff0000000000000ull);      /* +inf */
-  if (x < -745.2) return 0.0;
-  const double ax = x < 0.0 ? -x : x;
-  if (ax < 5.551115123125783e-17) return 1.0 + x;                          /* 2^-54 */
-  /* x = (64 m + j) ln2/64 + r */
-  const double magic = 6755399441055744.0;                                 /* 1.5 * 2^52: round to nearest integer */
-  const double t = x * SGD_EXP_INVL + magic;
-  const int32_t N = (int32_t)(uint32_t)(sgd_d2u(t) & 0xffffffffull);
-  const double kd = t - magic;
-  const double r1 = x - kd * SGD_EXP_L1;                                   /* exact: L1 has 32 bits */
-  const double r2 = kd * SGD_EXP_L2;
-  const double r = r1 - r2;
-  const double q = r * r * (0.5 + r * (0.16666666666666666 + r * (0.041666666666666664 +
-                   r * (0.008333333333333333 + r * 0.001388888888888889))));
-  const double p = r1 - (r2 - q);
-  const int j = (int)((uint32_t)N & 63u);
-  const int m = (N - j) / 64;
-  const double hi = tab[2 * j], lo = tab[2 * j + 1];
-  const double res = hi + (lo + (hi + lo) * p);
-  if (m >= -1021 && m <= 1023) return res * sgd_u2d((uint64_t)(m + 1023) << 52);
-  if (m > 1023) return res * sgd_u2d((uint64_t)(m - 1 + 1023) << 52) * 2.0;
-  return res * sgd_u2d((uint64_t)(m + 1000 + 1023) << 52) * sgd_u2d((uint64_t)(1023 - 1000) << 52);   /* subnormal range */
+/* `tab`: sgd_exp_tab as 128 consecutive doubles, or a copy of it (a kernel may keep one in on-chip memory, under
+ * its own pointer type: SGD_DEFINE_EXP(name, pointer type) writes the same function for it) */
+#define SGD_DEFINE_EXP(NAME, TABPTR_T) \
+SGD_DM_FN double NAME(double x, TABPTR_T tab) { \
+  if (x != x) return x; \
+  if (x > 709.782712893384) return sgd_u2d(0x7ff0000000000000ull);      /* +inf */ \
+  if (x < -745.2) return 0.0; \
+  const double ax = x < 0.0 ? -x : x; \
+  if (ax < 5.551115123125783e-17) return 1.0 + x;                          /* 2^-54 */ \
+  /* x = (64 m + j) ln2/64 + r */ \
+  const double magic = 6755399441055744.0;                                 /* 1.5 * 2^52: round to nearest integer */ \
+  const double t = x * SGD_EXP_INVL + magic; \
+  const int32_t N = (int32_t)(uint32_t)(sgd_d2u(t) & 0xffffffffull); \
+  const double kd = t - magic; \
+  const double r1 = x - kd * SGD_EXP_L1;                                   /* exact: L1 has 32 bits */ \
+  const double r2 = kd * SGD_EXP_L2; \
+  const double r = r1 - r2; \
+  const double q = r * r * (0.5 + r * (0.16666666666666666 + r * (0.041666666666666664 + \
+                   r * (0.008333333333333333 + r * 0.001388888888888889)))); \
+  const double p = r1 - (r2 - q); \
+  const int j = (int)((uint32_t)N & 63u); \
+  const int m = (N - j) / 64; \
+  const double hi = tab[2 * j], lo = tab[2 * j + 1]; \
+  const double res = hi + (lo + (hi + lo) * p); \
+  if (m >= -1021 && m <= 1023) return res * sgd_u2d((uint64_t)(m + 1023) << 52); \
+  if (m > 1023) return res * sgd_u2d((uint64_t)(m - 1 + 1023) << 52) * 2.0; \
+  return res * sgd_u2d((uint64_t)(m + 1000 + 1023) << 52) * sgd_u2d((uint64_t)(1023 - 1000) << 52);   /* subnormal range */ \
 }
+SGD_DEFINE_EXP(sgd_exp_from, const double*)
 
 SGD_DM_FN double sgd_exp(double x) { return sgd_exp_from(x, SGD_EXP_TABPTR); }
 

@@ -53,6 +53,12 @@ __device__ __forceinline__ double readlane_d(double v, int src) {
 // remainder, one correction (Markstein) -- three instructions instead of the ~30 of an IEEE division
 // sequence.  Correctly rounded whenever the remainder does not underflow; the wide kernel's parity
 // is to rounding, not bit for bit.
+__device__ __forceinline__ int64_t readlane_ll(int64_t v, int src) {
+  const int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(v >> 32), src);
+  return ((int64_t)hi << 32) | (unsigned int)lo;
+}
+
 __device__ __forceinline__ double div_by_n(double a, double n, double rn) {
   const double q0 = a * rn;
   const double rem = __builtin_fma(-q0, n, a);
@@ -410,37 +416,88 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
 // of the iteration, runs catch-up (:263-272), its product of the ascending sum (:274), AddWeighted
 // (:306-313), the SAGA step (:316-325) and the g_sum update (:328-335) on registers -- the same operations
 // on the same doubles in the same order per feature, so the state stays bit for bit -- and stores once.
-// Nothing the next draws need from memory depends on the solver state except through features two draws
-// share, so the stream runs four draws ahead, the row pointers three, the row two, and w / g_sum / lag /
-// y / gradient memory one; a feature the current draw also holds is forwarded from its lane's registers
-// (the stores of earlier draws are older memory operations of this wavefront and are seen in order).
-// Rows longer than the wavefront, the `wscale < SMALL` reset and the epoch end work on memory, after which
-// the one-ahead state is fetched again.
+// w / g_sum / lag of the next draw are requested a draw ahead, before this draw's stores; a feature the two
+// draws share is forwarded from its lane's registers (an LDS byte table, feature -> lane, finds it; the stores
+// of earlier draws are older memory operations of this wavefront and are seen in order).  Rows longer than
+// the wavefront, the `wscale < SMALL` reset and the epoch end work on memory, after which the one-ahead state
+// is fetched again.
+//
+// The requests that do not depend on the solver are taken off the wavefront that iterates: a workgroup of TWO
+// wavefronts.  Wavefront 1 (the producer) walks the sample stream ahead of the solver: stream entries, row
+// pointers, responses and gradient memory are gathered sixteen draws at a time (one lane per draw), rows four
+// draws at a time, and every draw's data-independent numbers -- w_scale before and after the draw and the two
+// quotients by it, gamma / w_scale and the SAGA step's soft threshold (:234, :285-297; the sequence restarts
+// every epoch) -- are formed there; each draw becomes one slot of an LDS ring.  Wavefront 0 (the consumer) runs
+// the iteration of the kernel above from those slots: its only memory traffic is w / g_sum / lag of the next
+// draw (requested a draw ahead, forwarded where two draws share a feature) and the stores, so its counter never
+// queues behind a request to HBM.  (Measured, DESIGN.md 4.1: one wavefront doing everything issued 436 instructions
+// and took 3900 cycles per draw, half of them instruction issue -- a lone wavefront retires one every ~4.5 cycles,
+// an f64 one every 8 -- and half waits; with the producer the consumer never waits for a slot, 22 polls in 400 000
+// draws, and the ring alone runs at 0.38 us per draw.)
+// Gradient memory: the producer's copy of M[s] may predate the consumer's store for a draw of the same sample
+// at most kRing + 32 draws back; the consumer keeps the last 64 (sample, gradient) pairs in registers, one per
+// lane, and takes the latest match instead.
 // --------------------------------------------------------------------------
 constexpr int kOwnSlots = 8192;                                   // bytes: feature (hashed) -> lane of the draw in hand
 constexpr int kK1Sum = kWave + 8;                                 // products of the draw in hand, padded to whole blocks
 constexpr size_t kK1FixedLds = sizeof(double) * (kK1Sum + 128) + kOwnSlots;
 
+constexpr int kRing = 16;                                          // slots (a power of two)
+constexpr int kSlotHdr = 10;                                       // doubles per slot header
+constexpr unsigned kK1xSpinLimit = 1u << 24;                       // polls of ~100 cycles: a second
+constexpr size_t kK1xFixedLds = kK1FixedLds + kRing * (sizeof(int) * kWave + sizeof(double) * (kWave + kSlotHdr)) + 32;
+
+// SoftThreshold (prox.h:32-39) of the register-resident kernels.  For s >= 0 (and for NaN operands)
+// max(x - s, 0) - max(-x - s, 0) is |x| - s carrying x's sign where that is positive, +0 otherwise: the same double
+// from one f64 operation instead of five (a lone wavefront pays 8 cycles for each); `plain` keeps the reference form.
+__device__ __forceinline__ double k1_soft(double x, double s, bool plain) {
+  if (plain) return soft_threshold(x, s);
+  const double t = fabs(x) - s;
+  return t > 0.0 ? copysign(t, x) : 0.0;
+}
+
+#define SGD_LDS(T) __attribute__((address_space(3))) T
+template <bool kLds> struct K1State { using D = double*; using U = unsigned*; };
+template <> struct K1State<true> { using D = SGD_LDS(double)*; using U = SGD_LDS(unsigned)*; };
+SGD_DEFINE_EXP(sgd_exp_lds, const SGD_LDS(double)*)
+
+// one counter of the ring, the same value in every lane and known to be so
+__device__ __forceinline__ unsigned long long ctrl_load(const volatile SGD_LDS(unsigned long long)* c) {
+  const unsigned long long v = *c;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(v & 0xffffffffull));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ void wave_mem_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
 template <bool kLds>
-__global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, const LamParams* lamp,
-                                                                     ExactCtl ctl) {
+__global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDev d, const LamParams* lamp,
+                                                                          ExactCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t p = d.p;
-  const unsigned L = (unsigned)ctl.ls_cache;      // lag_scaling entries kept in LDS
-  double* sx = reinterpret_cast<double*>(smem);                       // [kK1Sum]
-  double* sexp = sx + kK1Sum;                                         // [128]: sgd_exp_tab (a global table would queue
-                                                                      // behind the row requests: the counter retires in order)
-  unsigned char* owner = reinterpret_cast<unsigned char*>(sexp + 128);
-  double* sls = reinterpret_cast<double*>(owner + kOwnSlots);
-  double* w;
-  double* G;
-  unsigned* lag;
+  const unsigned L = (unsigned)ctl.ls_cache;
+  // (LDS pointers carry their address space in the type: a pointer the compiler cannot place becomes a FLAT access,
+  // which waits for the vector-memory AND the LDS counter to drain -- i.e. for every store in flight)
+  SGD_LDS(double)* sx = (SGD_LDS(double)*)smem;                       // [kK1Sum]
+  SGD_LDS(double)* sexp = sx + kK1Sum;                                // [128]
+  SGD_LDS(unsigned char)* owner = (SGD_LDS(unsigned char)*)(sexp + 128);
+  SGD_LDS(double)* rval = (SGD_LDS(double)*)(owner + kOwnSlots);      // [kRing][kWave]
+  SGD_LDS(double)* rhdr = rval + kRing * kWave;                       // [kRing][kSlotHdr]
+  SGD_LDS(int)* ridx = (SGD_LDS(int)*)(rhdr + kRing * kSlotHdr);      // [kRing][kWave]
+  volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(ridx + kRing * kWave);  // produced, consumed, stop
+  SGD_LDS(double)* sls = (SGD_LDS(double)*)(ridx + kRing * kWave) + 4;
+  typename K1State<kLds>::D w;
+  typename K1State<kLds>::D G;
+  typename K1State<kLds>::U lag;
   if constexpr (kLds) {
     w = sls + L;
     G = w + p;
-    lag = reinterpret_cast<unsigned*>(G + p);
-    for (int64_t i = lane; i < p; i += kWave) {
+    lag = (typename K1State<kLds>::U)(G + p);
+    for (int64_t i = tid; i < p; i += 2 * kWave) {
       w[i] = d.w[i];
       G[i] = d.G[i];
     }
@@ -451,167 +508,252 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
   }
   const unsigned nit = (unsigned)ctl.nit;
   const double* LS = ctl.LS;
-  for (unsigned i = lane; i < L; i += kWave) sls[i] = LS[i];
-  for (int i = lane; i < 128; i += kWave) sexp[i] = SGD_EXP_TABPTR[i];
-  for (int i = lane; i < kOwnSlots / 4; i += kWave) reinterpret_cast<unsigned*>(owner)[i] = 0u;
-  for (int i = lane; i < kK1Sum; i += kWave) sx[i] = 0.0;
-  for (int64_t j = lane; j < p; j += kWave) lag[j] = 0u;            // saga-sparse.h:225
-  for (int64_t i = lane; i < p; i += kWave) d.w_prev[i] = w[i];      // :251
-  __syncthreads();
+  for (unsigned i = tid; i < L; i += 2 * kWave) sls[i] = LS[i];
+  for (int i = tid; i < 128; i += 2 * kWave) sexp[i] = SGD_EXP_TABPTR[i];
+  for (int i = tid; i < kOwnSlots / 4; i += 2 * kWave) ((SGD_LDS(unsigned)*)owner)[i] = 0u;
+  for (int i = tid; i < kK1Sum; i += 2 * kWave) sx[i] = 0.0;
+  if (tid < 4) ctrl[tid] = 0ull;
+  for (int64_t j = tid; j < p; j += 2 * kWave) lag[j] = 0u;          // saga-sparse.h:225
+  for (int64_t i = tid; i < p; i += 2 * kWave) d.w_prev[i] = w[i];    // :251
+  __syncthreads();                                                    // the last barrier both wavefronts meet
 
-  auto ls_at = [&](unsigned m) -> double { return m < L ? sls[m] : LS[m]; };
+  const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
+  const double wscale_update = 1.0 - alpha * gamma;                  // :234
+  const double bg = beta * gamma;                                    // penalties.h:49: beta * gamma * scaling / w_scale
+  const double ls_one = 1u < L ? sls[1] : LS[1];                     // the SAGA step always lags by one
+  const double bg_ls1 = bg * ls_one;
+  const int64_t total = (int64_t)ctl.max_epochs * nit;               // draws of this launch, unless it converges first
+  const int64_t t_last = ctl.stream_off + total - 1;
 
+  if (wave == 1) {
+    // ================================ producer ================================
+    auto stream_at = [&](int64_t u) -> uint32_t {
+      const int64_t x = ctl.stream_off + u;
+      return d.stream[x < t_last ? x : t_last];
+    };
+    const bool gl = lane < 16;
+    uint32_t sv = gl ? stream_at(lane) : 0u, sv_n = gl ? stream_at(16 + lane) : 0u;
+    int64_t pa = 0, pe = 0;
+    double yv = 0.0, mv = 0.0;
+    if (gl) {
+      pa = d.ptr[sv];
+      pe = d.ptr[sv + 1];
+      yv = d.y[sv];
+      mv = d.M[sv];
+    }
+    double W = 1.0, q_prev = gamma / W;
+    unsigned itp = 0;
+    bool stop = false;
+    int64_t freed = 0;                 // slots the consumer is known to have taken
+#ifdef SGDNET_PHASE_TIMING
+    unsigned long long prod_spins = 0, prod_waits = 0;
+#endif
+    for (int64_t ub = 0; ub <= total && !stop; ub += 16) {
+      // the gathers of the next sixteen draws and the stream entries of the sixteen after them
+      const uint32_t sv_nn = gl ? stream_at(ub + 32 + lane) : 0u;
+      int64_t pa_n = 0, pe_n = 0;
+      double yv_n = 0.0, mv_n = 0.0;
+      if (gl) {
+        pa_n = d.ptr[sv_n];
+        pe_n = d.ptr[sv_n + 1];
+        yv_n = d.y[sv_n];
+        // (the consumer's stores of draws more than 64 back are long in L2; read past this CU's L1)
+        mv_n = __hip_atomic_load(d.M + sv_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      for (int i0 = 0; i0 < 16 && !stop; i0 += 4) {
+        int idx4[4];
+        double val4[4];
+        int64_t a4[4], e4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a4[j] = readlane_ll(pa, i0 + j);
+          e4[j] = readlane_ll(pe, i0 + j);
+          idx4[j] = 0;
+          val4[j] = 0.0;
+          if (a4[j] + lane < e4[j]) {
+            idx4[j] = d.idx[a4[j] + lane];
+            val4[j] = d.val[a4[j] + lane];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t u = ub + i0 + j;
+          if (u > total || stop) break;
+          if (u - freed >= kRing) {                                  // ring full: the consumer frees a slot per draw
+            unsigned spins = 0;
+            for (;;) {
+              freed = (int64_t)ctrl_load(ctrl + 1);
+              if (u - freed < kRing) break;
+              if (ctrl_load(ctrl + 2) != 0ull || ++spins > kK1xSpinLimit) {   // (the limit: an exit every wavefront reaches)
+                stop = true;
+                break;
+              }
+              __builtin_amdgcn_s_sleep(2);
+            }
+#ifdef SGDNET_PHASE_TIMING
+            prod_spins += spins;
+            ++prod_waits;
+#endif
+          }
+          if (stop) break;
+          const int slot = (int)(u & (kRing - 1));
+          const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)sv, i0 + j);
+          const double y_u = readlane_d(yv, i0 + j), m_u = readlane_d(mv, i0 + j);
+          const int64_t rlen = e4[j] - a4[j];
+          const int len_u = (int)(rlen < (int64_t)(kWave + 1) ? rlen : (int64_t)(kWave + 1));
+          // w_scale as the draw's catch-up sees it, what the draw leaves behind, and the quotients by the latter
+          const double Wp = (W < kSmall ? 1.0 : W) * wscale_update;
+          const double r = (lane == 0 ? gamma : bg_ls1) / Wp;
+          const double q_t = readlane_d(r, 0), tau1 = readlane_d(r, 1);
+          ridx[slot * kWave + lane] = idx4[j];
+          rval[slot * kWave + lane] = val4[j];
+          double hv = __longlong_as_double(((long long)len_u << 32) | (long long)s_u);
+          hv = lane == 1 ? __longlong_as_double(a4[j]) : hv;
+          hv = lane == 2 ? y_u : hv;
+          hv = lane == 3 ? m_u : hv;
+          hv = lane == 4 ? W : hv;
+          hv = lane == 5 ? Wp : hv;
+          hv = lane == 6 ? q_prev : hv;
+          hv = lane == 7 ? q_t : hv;
+          hv = lane == 8 ? tau1 : hv;
+          hv = lane == 9 ? __longlong_as_double(e4[j]) : hv;
+          if (lane < kSlotHdr) rhdr[slot * kSlotHdr + lane] = hv;
+          lanes_publish();
+          if (lane == 0) ctrl[0] = (unsigned long long)(u + 1);
+          q_prev = q_t;
+          W = Wp;
+          if (++itp == nit) {                                      // Reset(n_samples) :340-348 leaves w_scale = 1
+            itp = 0;
+            W = 1.0;
+            q_prev = gamma / W;
+          }
+        }
+      }
+      sv = sv_n;
+      sv_n = sv_nn;
+      pa = pa_n;
+      pe = pe_n;
+      yv = yv_n;
+      mv = mv_n;
+    }
+#ifdef SGDNET_PHASE_TIMING
+    if (d.dbg && lane == 0) {
+      d.dbg[8] += prod_spins;
+      d.dbg[9] += prod_waits;
+    }
+#endif
+    return;
+  }
+
+  // ================================ consumer ================================
+  auto ls_at = [&](unsigned m) -> double {   // (never a select between an LDS and a global address: that is a FLAT load)
+    double v = sls[m < L ? m : 0u];
+    if (m >= L) v = LS[m];
+    return v;
+  };
   const int penalty = lamp->penalty;
   const bool group = penalty == SGDNET_GROUPLASSO;                    // one response: a group of one (generic functor)
   const bool l1 = penalty == SGDNET_ELASTICNET;
+  // the one-operation soft threshold needs a threshold that is never negative: true while w_scale stays positive
+  const bool plain_soft = !(wscale_update > 0.0 && bg >= 0.0);
   const int family = d.family;
   const bool fit_intercept = d.fit_intercept != 0;
-  const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
-  const double wscale_update = 1.0 - alpha * gamma;                  // :234
   const double n_d = d.n_total, rn_d = 1.0 / n_d;
   const double g_scale = 1.0 / n_d;                                  // AddWeighted(g_sum, ..., 1/n)
-  const double ls_one = ls_at(1u);                                    // the SAGA step always lags by one
-  const double bg = beta * gamma;                                    // penalties.h:49: beta * gamma * scaling / w_scale
-  const double bg_ls1 = bg * ls_one;
   double b = d.b[0], gb = d.gb[0];                                   // intercept, g_sum_intercept: every lane the same
-  double W = 1.0;                                                    // w_scale  :227
-  double q_prev = gamma / W;                                         // gamma / w_scale as the catch-up sees it
-  double q_t = 0.0, tau1_t = 0.0, tauc = 0.0, Wp_t = 0.0;            // see `prepare`
+  uint32_t hs = 0xffffffffu;                                         // lane i: sample and gradient of draw u with u % 64 == i
+  double hg = 0.0;
 
-  unsigned it_outer = 0;
-  int converged = 0;
-  int64_t t = ctl.stream_off;
-  const int64_t t_last = ctl.stream_off + (int64_t)ctl.max_epochs * nit - 1;
-  auto clampt = [&](int64_t x) { return x < t_last ? x : t_last; };
-
-  // ---- fill the pipeline: stream (t .. t+3), row pointers (t .. t+2), row (t, t+1), state (t) ----
-  uint32_t s0 = d.stream[clampt(t)], s1 = d.stream[clampt(t + 1)], s2 = d.stream[clampt(t + 2)],
-           s3 = d.stream[clampt(t + 3)];
-  int64_t a0 = d.ptr[s0], e0 = d.ptr[s0 + 1];
-  int64_t a1 = d.ptr[s1], e1 = d.ptr[s1 + 1];
-  int64_t a2 = d.ptr[s2], e2 = d.ptr[s2 + 1];
-  int idx0 = 0, idx1 = 0;
-  double val0 = 0.0, val1 = 0.0;
-  if (a0 + lane < e0) {
-    idx0 = d.idx[a0 + lane];
-    val0 = d.val[a0 + lane];
-  }
-  if (a1 + lane < e1) {
-    idx1 = d.idx[a1 + lane];
-    val1 = d.val[a1 + lane];
-  }
-  double y0 = d.y[s0], m0 = d.M[s0];
-  double w0 = 0.0, G0 = 0.0, lsc0 = 0.0;
+  // a slot, as registers
+  int64_t avail = 0;                  // slots known to be filled
+#ifdef SGDNET_PHASE_TIMING
+  unsigned long long cons_spins = 0, cons_waits = 0;
+#endif
+  bool stalled = false;               // the producer stopped feeding the ring: give up with an error instead of spinning
+  int idx_n;
+  double val_n, h_sl, h_q0, h_q1, y_n, m_n, W_n, Wp_n, qp_n, qt_n, tau1_n;
+  auto read_slot = [&](int64_t u) {
+    if (u >= avail) {
+      unsigned spins = 0;
+      for (;;) {
+        avail = (int64_t)ctrl_load(ctrl);
+        if (u < avail) break;
+        if (++spins > kK1xSpinLimit) {
+          stalled = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+#ifdef SGDNET_PHASE_TIMING
+      cons_spins += spins;
+      ++cons_waits;
+#endif
+    }
+    const int slot = (int)(u & (kRing - 1));
+    lanes_publish();
+    idx_n = ridx[slot * kWave + lane];
+    val_n = rval[slot * kWave + lane];
+    const SGD_LDS(double)* h = rhdr + slot * kSlotHdr;
+    h_sl = h[0];
+    h_q0 = h[1];
+    y_n = h[2];
+    m_n = h[3];
+    W_n = h[4];
+    Wp_n = h[5];
+    qp_n = h[6];
+    qt_n = h[7];
+    tau1_n = h[8];
+    h_q1 = h[9];
+    lanes_publish();
+    if (lane == 0) ctrl[1] = (unsigned long long)(u + 1);            // (the LDS runs these reads before this store)
+  };
+  double w0 = 0.0, G0 = 0.0, lsc0 = 0.0, tauc = 0.0;
   unsigned lag0 = 0u;
-  // state of the draw in hand, from memory (first draw of a launch or an epoch, after a long row, after a
-  // scale reset): everything older has been stored and waited for
+  // state of the draw whose slot is in the *_n registers, from memory
   auto fetch_state = [&](unsigned it_of_draw) {
+    const int len_n = (int)(__double_as_longlong(h_sl) >> 32);
     w0 = 0.0;
     G0 = 0.0;
     lag0 = it_of_draw;
-    if (a0 + lane < e0 && e0 - a0 <= kWave) {
-      w0 = w[idx0];
-      G0 = G[idx0];
-      lag0 = lag[idx0];
+    if (lane < len_n && len_n <= kWave) {
+      w0 = w[idx_n];
+      G0 = G[idx_n];
+      lag0 = lag[idx_n];
     }
     lsc0 = ls_at(it_of_draw - lag0);
+    tauc = bg * lsc0 / W_n;
   };
-  // Everything the coming draw divides by w_scale, in ONE division: W is w_scale as its catch-up sees it, Wp what
-  // the draw leaves behind ((W < SMALL ? 1 : W) * update, :285-297).  Lanes 0..61 take the soft threshold of their
-  // catch-up, beta*gamma*lag_scaling / W; lane 62 the SAGA step's, beta*gamma*lag_scaling[1] / Wp; lane 63
-  // gamma / Wp -- the quotients the reference forms, formed once (a division costs a lone wavefront ~300 cycles).
-  auto prepare = [&]() {
-    const double Wp = (W < kSmall ? 1.0 : W) * wscale_update;
-    const double bgl = bg * lsc0;
-    const double num = lane == 63 ? gamma : (lane == 62 ? bg_ls1 : bgl);
-    const double den = lane >= 62 ? Wp : W;
-    const double r = num / den;
-    q_t = readlane_d(r, 63);
-    tau1_t = readlane_d(r, 62);
-    tauc = r;
-    if (e0 - a0 > 62) tauc = bgl / W;       // a row that needs lanes 62 and 63 for itself
-    Wp_t = Wp;
-#ifdef K1_DBG_PREP
-    q_t = gamma / Wp;
-    tau1_t = bg_ls1 / Wp;
-    tauc = bgl / W;
-#endif
-  };
+  read_slot(0);
   fetch_state(0u);
-  prepare();
-#ifdef SGDNET_PHASE_TIMING
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define K1_STAMP(i) do { const unsigned long long now_ = clock64(); ph[i] += now_ - last_; last_ = now_; } while (0)
-#else
-#define K1_STAMP(i) ((void)0)
-#endif
 
+  unsigned it_outer = 0;
+  int converged = 0;
+  int64_t u = 0;
   do {
-    for (unsigned it = 0; it < nit; ++it, ++t) {
-#ifdef SGDNET_PHASE_TIMING
-      unsigned long long last_ = clock64();
-#endif
-      // ---- the draw in hand, and the requests of the draws behind it -------------------------------
-      const uint32_t s = s0;                                         // :261
-      const int64_t q0 = a0, q1 = e0;
-      const int idx_c = idx0;
-      const double val_c = val0;
-      const double y_c = y0, m_c = m0;
-      const int len = (int)((q1 - q0) < (int64_t)(kWave + 1) ? (q1 - q0) : (int64_t)(kWave + 1));
+    double W_end = 1.0;
+    for (unsigned it = 0; it < nit; ++it, ++u) {
+      // ---- the draw in hand -----------------------------------------------------------------------
+      const long long sl = __double_as_longlong(h_sl);
+      const uint32_t s = (uint32_t)(sl & 0xffffffffll);             // :261
+      const int len = (int)(sl >> 32);
+      const int64_t q0 = __double_as_longlong(h_q0), q1 = __double_as_longlong(h_q1);
+      const int idx_c = idx_n;
+      const double val_c = val_n, y_c = y_n;
+      double m_c = m_n;
+      const double W = W_n, Wp = Wp_n, q_prev = qp_n, q_t = qt_n, tau1_t = tau1_n;
       const bool shortrow = len <= kWave;
       const bool mine = lane < len && shortrow;
-      s0 = s1;
-      s1 = s2;
-      s2 = s3;
-      a0 = a1;
-      e0 = e1;
-      a1 = a2;
-      e1 = e2;
-      idx0 = idx1;
-      val0 = val1;
-      // w / g_sum / lag of the next draw, requested before this draw's stores (forwarded below) and before the
-      // requests that go to HBM
-      const bool mine_n = a0 + lane < e0 && e0 - a0 <= kWave;
-      double w_n = 0.0, G_n = 0.0;
-      unsigned lag_n = it + 1u;
-      if (mine_n) {
-        w_n = w[idx0];
-        G_n = G[idx0];
-        lag_n = lag[idx0];
-      }
-      y0 = d.y[s0];
-      m0 = d.M[s0];
-      idx1 = 0;
-      val1 = 0.0;
-      if (a1 + lane < e1) {
-        idx1 = d.idx[a1 + lane];
-        val1 = d.val[a1 + lane];
-      }
-      a2 = d.ptr[s2];
-      e2 = d.ptr[s2 + 1];
-      s3 = d.stream[clampt(t + 4)];
-      // which lane of this draw, if any, holds the feature a lane of the next draw asked for
-      unsigned cand = 0u;
-      bool collide = false;
-      if (shortrow) {
-        const int h_c = idx_c & (kOwnSlots - 1), h_n = idx0 & (kOwnSlots - 1);
-        // (lanes talk through the LDS here: the compiler must neither forward a lane's own store to its load
-        // nor drop the first store as dead -- the LDS itself runs a wavefront's operations in order)
-        if (mine) owner[h_c] = (unsigned char)(lane + 1);
-        lanes_publish();
-        const unsigned chk = mine ? owner[h_c] : (unsigned)(lane + 1);
-        cand = mine_n ? owner[h_n] : 0u;
-        lanes_publish();
-        if (mine) owner[h_c] = 0;
-        collide = __ballot(chk != (unsigned)(lane + 1)) != 0ull;   // two features of this row share a slot: compare instead
-#ifdef K1_DBG_MATCH
-        collide = true;
-#endif
-      }
+      // ---- the next draw's slot is asked for now and looked at after this draw's catch-up ----
+      read_slot(u + 1);
+      if (stalled) break;
+      const int r0 = (int)(u & (kWave - 1));
 
-      K1_STAMP(0);
       double wj = w0, Gj = G0;
       double acc = 0.0;
+      int len_nx = 0;
+      bool mine_n = false, collide = false;
+      double w_n = 0.0, G_n = 0.0;
+      unsigned lag_n = it + 1u, cand = 0u;
       if (shortrow) {
         // LaggedUpdate(it_inner): catch-up of the sample's features  :263-272
         const unsigned lagged = it - lag0;
@@ -621,32 +763,54 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
           } else {
             const double f = q_prev * lsc0;
             const double v = wj - f * Gj;
-            wj = l1 ? soft_threshold(v, tauc) : v;
+            wj = l1 ? k1_soft(v, tauc, plain_soft) : v;
           }
         }
         // linear predictor, ascending feature order  :274 (products past the row are +0.0: adding them changes nothing)
         sx[lane] = mine ? val_c * wj : 0.0;
         lanes_publish();
-        K1_STAMP(1);
-#ifdef K1_DBG_SUM
-        { const double wx_ = mine ? val_c * wj : 0.0; for (int e = 0; e < len; ++e) acc += readlane_d(wx_, e); }
-#else
-        for (int eb = 0; eb < len; eb += 8) {
-#pragma unroll
-          for (int u = 0; u < 8; ++u) acc += sx[eb + u];
+        // ---- the next draw: w / g_sum / lag, requested before this draw's stores (forwarded below) ----
+        len_nx = (int)(__double_as_longlong(h_sl) >> 32);
+        mine_n = lane < len_nx && len_nx <= kWave;
+        if (mine_n) {
+          w_n = w[idx_n];
+          G_n = G[idx_n];
+          lag_n = lag[idx_n];
         }
-#endif
+        // which lane of this draw, if any, holds the feature a lane of the next draw asked for
+        {
+          const int h_c = idx_c & (kOwnSlots - 1), h_n = idx_n & (kOwnSlots - 1);
+          if (mine) owner[h_c] = (unsigned char)(lane + 1);
+          lanes_publish();
+          const unsigned chk = mine ? owner[h_c] : (unsigned)(lane + 1);
+          cand = mine_n ? owner[h_n] : 0u;
+          lanes_publish();
+          if (mine) owner[h_c] = 0;
+          collide = __ballot(chk != (unsigned)(lane + 1)) != 0ull;   // two features of this row share a slot: compare instead
+        }
+        for (int eb = 0; eb < len; eb += 4) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc += sx[eb + e];
+        }
       } else {
-        __syncthreads();                     // the stores of the draws before it
+        // ---- the next draw: w / g_sum / lag, requested before this draw's stores (forwarded below) ----
+        len_nx = (int)(__double_as_longlong(h_sl) >> 32);
+        mine_n = lane < len_nx && len_nx <= kWave;
+        if (mine_n) {
+          w_n = w[idx_n];
+          G_n = G[idx_n];
+          lag_n = lag[idx_n];
+        }
+        wave_mem_sync();                     // the stores of the draws before it
         for (int64_t q = q0 + lane; q < q1; q += kWave) {
           const int64_t j = d.idx[q];
           const unsigned lagged = it - lag[j];
           if (lagged != 0u) {
-            penalty_apply_q(penalty, 1, w + j, G + j, W, ls_at(lagged), q_prev, gamma, beta);
+            penalty_apply_q(penalty, 1, (double*)(w + j), (double*)(G + j), W, ls_at(lagged), q_prev, gamma, beta);
             lag[j] = it;
           }
         }
-        __syncthreads();
+        wave_mem_sync();
         for (int64_t base = q0; base < q1; base += kWave) {
           const int64_t q = base + lane;
           const double wx = q < q1 ? d.val[q] * w[d.idx[q]] : 0.0;
@@ -654,19 +818,29 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
           for (int e = 0; e < cnt; ++e) acc += readlane_d(wx, e);
         }
       }
+      // gradient memory: a draw of the same sample among the last 64 supersedes the producer's copy
+      {
+        const unsigned long long mask = __ballot(hs == s);
+        if (mask != 0ull) {
+          const unsigned long long rot = r0 ? ((mask >> r0) | (mask << (kWave - r0))) : mask;   // bit k: lane (k + r0) % 64, age 64 - k
+          const int kk = 63 - __builtin_clzll(rot);
+          m_c = readlane_d(hg, (kk + r0) & (kWave - 1));
+        }
+      }
       const double lp = acc * W + b;
-      K1_STAMP(2);
 
       // gradient, gradient memory  :279-282
       double g;
       if (family == SGDNET_BINOMIAL)
-        g = 1.0 - y_c - 1.0 / (1.0 + sgd_exp_from(lp, sexp));
+        g = 1.0 - y_c - 1.0 / (1.0 + sgd_exp_lds(lp, sexp));
       else
         g = lp - y_c;
       const double gc = g - m_c;
-      K1_STAMP(3);
       if (lane == 0) d.M[s] = g;
-      if (s0 == s) m0 = g;                  // the next draw repeats this sample: forward its memory
+      if (lane == r0) {
+        hs = s;
+        hg = g;
+      }
 
       // rescale + unlag whenever wscale becomes too small  :285-295
       bool refetch = !shortrow;
@@ -675,36 +849,43 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
           w[idx_c] = wj;
           lag[idx_c] = it;
         }
-        __syncthreads();
+        wave_mem_sync();
         for (int64_t j = lane; j < p; j += kWave) {
           const unsigned lagged = it - lag[j];
-          if (lagged != 0u) penalty_apply(penalty, 1, w + j, G + j, W, ls_at(lagged), gamma, beta);
+          if (lagged != 0u) penalty_apply(penalty, 1, (double*)(w + j), (double*)(G + j), W, ls_at(lagged), gamma, beta);
           w[j] *= W;
           lag[j] = it;
         }
-        __syncthreads();
+        wave_mem_sync();
         if (mine) wj = w[idx_c];
         refetch = true;
       }
-      W = Wp_t;                                                      // :297 (after the reset, if any)
+      W_end = Wp;                                                    // :297 (after the reset, if any)
 
       if (fit_intercept) {                                           // :300-304
         const double gck = div_by_n_exact(gc, n_d, rn_d);
         gb = gb + gck;
         b -= gamma * (gb * 0.01 + gck);
       }
-      K1_STAMP(4);
+
+      // the next draw's lag scaling and catch-up threshold, from the lag as loaded: a feature this draw forwards
+      // below lags by zero and needs neither (a division here is off the path from this draw's stores to the next)
+      double lsc_e = 0.0, tauc_e = 0.0;
+      if (!refetch && it + 1u < nit) {
+        lsc_e = ls_at((it + 1u) - lag_n);
+        tauc_e = bg * lsc_e / W_n;
+      }
 
       if (shortrow) {
         if (mine) {
           wj += val_c * gc * (-q_t);                                 // AddWeighted(w, ..., -gamma/wscale)  :306-313
           // LaggedUpdate(it_inner + 1): the SAGA step (the feature was caught up to `it`, so it lags by one) :316-325
           if (group) {
-            penalty_apply_q(penalty, 1, &wj, &Gj, W, ls_one, q_t, gamma, beta);
+            penalty_apply_q(penalty, 1, &wj, &Gj, Wp, ls_one, q_t, gamma, beta);
           } else {
             const double f = q_t * ls_one;
             const double v = wj - f * Gj;
-            wj = l1 ? soft_threshold(v, tau1_t) : v;
+            wj = l1 ? k1_soft(v, tau1_t, plain_soft) : v;
           }
           Gj += val_c * gc * g_scale;                                // AddWeighted(g_sum, ..., 1/n)  :328-335
           w[idx_c] = wj;
@@ -718,22 +899,19 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
           const int64_t j = d.idx[q];
           const unsigned lagged = (it + 1u) - lag[j];
           if (lagged != 0u) {
-            penalty_apply_q(penalty, 1, w + j, G + j, W, ls_at(lagged), q_t, gamma, beta);
+            penalty_apply_q(penalty, 1, (double*)(w + j), (double*)(G + j), Wp, ls_at(lagged), q_t, gamma, beta);
             lag[j] = it + 1u;
           }
           G[j] += d.val[q] * gc * g_scale;
         }
       }
-      q_prev = q_t;
 
-      K1_STAMP(5);
       // ---- hand the next draw its state ------------------------------------------------------------
       if (refetch || it + 1u == nit) {
         // memory was rewritten behind the request (or is about to be, by Reset): ask again once the stores are in
         if (it + 1u < nit) {
-          __syncthreads();
+          wave_mem_sync();
           fetch_state(it + 1u);
-          prepare();
         }
       } else {
         bool hit = false;
@@ -743,12 +921,12 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
           hit = cand != 0u;
           if (__ballot(hit) != 0ull) {
             const int je = __shfl(idx_c, src & (kWave - 1), kWave);     // every lane takes part: the source lanes must be live
-            hit = hit && je == idx0;
+            hit = hit && je == idx_n;
           }
         } else {
           for (int e = 0; e < len; ++e) {
             const int je = __builtin_amdgcn_readlane(idx_c, e);
-            if (mine_n && idx0 == je) {
+            if (mine_n && idx_n == je) {
               src = e;
               hit = true;
             }
@@ -766,30 +944,34 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
         w0 = w_n;
         G0 = G_n;
         lag0 = lag_n;
-        lsc0 = ls_at((it + 1u) - lag_n);
-        prepare();
+        lsc0 = lsc_e;
+        tauc = tauc_e;
       }
-      K1_STAMP(6);
     }
 
+    if (stalled) break;
     // Reset(n_samples): unlag and rescale  :340-348
-    __syncthreads();
+    wave_mem_sync();
     for (int64_t j = lane; j < p; j += kWave) {
       const unsigned lagged = nit - lag[j];
-      if (lagged != 0u) penalty_apply(penalty, 1, w + j, G + j, W, ls_at(lagged), gamma, beta);
-      w[j] *= W;
+      if (lagged != 0u) penalty_apply(penalty, 1, (double*)(w + j), (double*)(G + j), W_end, ls_at(lagged), gamma, beta);
+      w[j] *= W_end;
       lag[j] = 0u;
     }
-    W = 1.0;
-    q_prev = gamma / W;
-    __syncthreads();
+    wave_mem_sync();
 
-    converged = convergence_check(w, d.w_prev, p, ctl.tol, lane);    // :367
+    converged = convergence_check((double*)w, d.w_prev, p, ctl.tol, lane);    // :367
     ++it_outer;
-    __syncthreads();
+    wave_mem_sync();
     fetch_state(0u);
-    prepare();
   } while (!converged && it_outer < ctl.max_epochs);                 // :371
+  if (lane == 0) ctrl[2] = 1ull;                                      // the producer may be waiting for a free slot
+#ifdef SGDNET_PHASE_TIMING
+  if (d.dbg && lane == 0) {
+    d.dbg[10] += cons_spins;
+    d.dbg[11] += cons_waits;
+  }
+#endif
 
   if constexpr (kLds) {
     for (int64_t i = lane; i < p; i += kWave) {
@@ -797,16 +979,11 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_k1_kernel(SagaDev d, 
       d.G[i] = G[i];
     }
   }
-#ifdef SGDNET_PHASE_TIMING
-  if (d.dbg && lane == 0)
-    for (int i = 0; i < 8; ++i) d.dbg[i] += ph[i];
-#endif
-#undef K1_STAMP
   if (lane == 0) {
     d.b[0] = b;
     d.gb[0] = gb;
     ctl.out[0] = (int)it_outer;
-    ctl.out[1] = converged;
+    ctl.out[1] = stalled ? -2 : converged;
   }
 }
 
@@ -1670,7 +1847,8 @@ bool sparse_exact_k1_eligible(const SagaDev& d) {
 }
 
 size_t sparse_exact_k1_lds_bytes(const SagaDev& d, int64_t nit, bool allow_stage, int* ls_cache, int* stage_state) {
-  const size_t cap = 160 * 1024 - 256 - kK1FixedLds;
+  const size_t fixed = kK1xFixedLds;
+  const size_t cap = 160 * 1024 - 256 - fixed;
   const size_t state = (sizeof(double) * 2 + sizeof(unsigned)) * (size_t)d.p;
   const size_t want = (size_t)nit + 1;
   const size_t floor_entries = want < 2048 ? want : 2048;
@@ -1679,22 +1857,22 @@ size_t sparse_exact_k1_lds_bytes(const SagaDev& d, int64_t nit, bool allow_stage
   if (entries > want) entries = want;
   *ls_cache = (int)entries;
   *stage_state = stage ? 1 : 0;
-  return (kK1FixedLds + sizeof(double) * entries + (stage ? state : 0) + 15) & ~size_t(15);
+  return (fixed + sizeof(double) * entries + (stage ? state : 0) + 15) & ~size_t(15);
 }
 
-int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
-                           hipStream_t st) {
-  if (ctl.use_lds) {
-    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_sparse_exact_k1_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(saga_sparse_exact_k1_kernel<true>, dim3(1), dim3(kWave), lds_bytes, st, d, lam, ctl);
-  } else {
-    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_sparse_exact_k1_kernel<false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(saga_sparse_exact_k1_kernel<false>, dim3(1), dim3(kWave), lds_bytes, st, d, lam, ctl);
-  }
+template <typename Kern>
+static int launch_k1_t(Kern kern, int threads, const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                       hipStream_t st) {
+  SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds_bytes, st, d, lam, ctl);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
+}
+
+int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st) {
+  return ctl.use_lds ? launch_k1_t(saga_sparse_exact_k1x_kernel<true>, 2 * kWave, d, lam, ctl, lds_bytes, st)
+                     : launch_k1_t(saga_sparse_exact_k1x_kernel<false>, 2 * kWave, d, lam, ctl, lds_bytes, st);
 }
 
 int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,

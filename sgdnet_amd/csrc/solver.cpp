@@ -1436,11 +1436,11 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     static const int wide_ok = exp_env_int("SGDNET_EXACT_WIDE", 1);
     const bool wide = !s->sparse && !lds_small && wide_ok && dense_exact_wide_threads(s->d) > 0;
     // sparse x, one response, no implicit centring: the register-resident iteration (option exact_row_registers:
-    // 0 keeps the general kernel, 2 keeps the state out of the LDS even where it fits)
+    // 0 keeps the general kernel; 2 keeps w, g_sum and lag out of the LDS even where they fit)
     const int k1_opt = option(kOptExactRowRegisters);
     const bool k1 = s->sparse && k1_opt != 0 && sparse_exact_k1_eligible(s->d);
     int k1_cache = 0, k1_stage = 0;
-    const size_t k1_lds = k1 ? sparse_exact_k1_lds_bytes(s->d, draws_per_epoch, k1_opt != 2, &k1_cache, &k1_stage) : 0;
+    const size_t k1_lds = k1 ? sparse_exact_k1_lds_bytes(s->d, draws_per_epoch, k1_opt == 1, &k1_cache, &k1_stage) : 0;
     const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true)
                                       : (wide ? dense_exact_wide_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true));
     const bool stage = lds_full <= lds_cap;
@@ -1481,6 +1481,10 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       int out[2] = {0, 0};
       SGD_HIP_TRY(hipMemcpyAsync(out, s->out_dev, sizeof(out), hipMemcpyDeviceToHost, s->st));
       SGD_HIP_TRY(hipStreamSynchronize(s->st));
+      if (out[1] < 0) {
+        set_error("exact mode: the sample-order producer of the sparse kernel stalled (internal error)");
+        return SGDNET_EHIP;
+      }
       if (losses) {
         double sum = 0.0;
         rc = device_loss_sum(s, &sum);
@@ -1489,14 +1493,12 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       }
 #ifdef SGDNET_PHASE_TIMING
       if (k1 && s->d.dbg && out[0] > 0) {
-        unsigned long long ph[8];
-        SGD_HIP_TRY(hipMemcpy(ph, s->d.dbg, sizeof(ph), hipMemcpyDeviceToHost));
-        (void)hipMemset(s->d.dbg, 0, sizeof(ph));
-        const double its = (double)out[0] * (double)draws_per_epoch;
-        fprintf(stderr, "[sgdnet] register-resident sparse kernel, cycles per draw: requests %.0f, catch-up %.0f, sum %.0f, gradient %.0f, "
-                        "scale+intercept %.0f, step+stores %.0f, forward %.0f\n",
-                (double)ph[0] / its, (double)ph[1] / its, (double)ph[2] / its, (double)ph[3] / its, (double)ph[4] / its, (double)ph[5] / its,
-                (double)ph[6] / its);
+        (void)hipDeviceSynchronize();
+        unsigned long long c[12];
+        SGD_HIP_TRY(hipMemcpy(c, s->d.dbg, sizeof(c), hipMemcpyDeviceToHost));
+        (void)hipMemset(s->d.dbg, 0, sizeof(c));
+        fprintf(stderr, "[sgdnet] producer/consumer sparse kernel, %d x %lld draws: producer waited %llu times (%llu polls), consumer %llu times (%llu polls)\n",
+                out[0], (long long)draws_per_epoch, c[9], c[8], c[11], c[10]);
       }
       if (wide && s->d.dbg && out[0] > 0) {   // development aid: shader-clock cycles of thread 0 per phase of the wide kernel
         unsigned long long ph[6];
