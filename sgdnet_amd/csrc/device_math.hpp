@@ -29,9 +29,11 @@ __device__ __forceinline__ double soft_threshold(double x, double s) {
 }
 
 // penalty(w, j, w_scale, scaling, g_sum) for one feature column (K entries).
-__device__ __forceinline__ void penalty_apply(int penalty, int K, double* wj, const double* gj,
-                                              double w_scale, double scaling, double gamma,
-                                              double beta) {
+// (WP / GP: pointers to the K coefficients / gradient averages of the feature, in whatever address space the
+// kernel keeps them -- a pointer that may be LDS or global becomes a FLAT access, which drains both counters)
+template <typename WP, typename GP>
+__device__ __forceinline__ void penalty_apply(int penalty, int K, WP wj, GP gj, double w_scale, double scaling,
+                                              double gamma, double beta) {
   if (penalty == SGDNET_RIDGE) {
     const double f = gamma / w_scale * scaling;
     for (int k = 0; k < K; ++k) wj[k] -= f * gj[k];
@@ -63,8 +65,9 @@ __device__ __forceinline__ void penalty_apply(int penalty, int K, double* wj, co
 
 // The same with q = gamma / w_scale formed once by the caller (gamma / w_scale * scaling is that quotient
 // times scaling: the same doubles), for kernels that apply the penalty several times per iteration.
-__device__ __forceinline__ void penalty_apply_q(int penalty, int K, double* wj, const double* gj, double w_scale,
-                                                double scaling, double q, double gamma, double beta) {
+template <typename WP, typename GP>
+__device__ __forceinline__ void penalty_apply_q(int penalty, int K, WP wj, GP gj, double w_scale, double scaling, double q,
+                                                double gamma, double beta) {
   const double f = q * scaling;
   if (penalty == SGDNET_RIDGE) {
     for (int k = 0; k < K; ++k) wj[k] -= f * gj[k];
@@ -93,7 +96,8 @@ __device__ __forceinline__ void penalty_apply_q(int penalty, int K, double* wj, 
 }
 
 // LogSumExp over K linear predictors, ascending order.
-__device__ __forceinline__ double log_sum_exp(const double* lp, int K) {
+template <typename LP>
+__device__ __forceinline__ double log_sum_exp(LP lp, int K) {
   double mx = lp[0];
   for (int k = 1; k < K; ++k) mx = lp[k] > mx ? lp[k] : mx;
   double s = 0.0;
@@ -102,8 +106,8 @@ __device__ __forceinline__ double log_sum_exp(const double* lp, int K) {
 }
 
 // g_k for class k given all K linear predictors; y points at column s of y (Ky rows).
-__device__ __forceinline__ double family_gradient_k(int family, int K, int k, const double* lp,
-                                                    const double* ys) {
+template <typename LP>
+__device__ __forceinline__ double family_gradient_k(int family, int K, int k, LP lp, const double* ys) {
   switch (family) {
     case SGDNET_GAUSSIAN:
       return lp[0] - ys[0];

@@ -22,6 +22,13 @@ namespace {
 
 constexpr int kWave = 64;
 
+// Pointers into the LDS carry their address space in the type, and a kernel whose state lives either in the LDS or
+// in memory is compiled once for each (StatePtr<kLds>): a pointer that may be either becomes a FLAT access, which
+// waits for the vector-memory AND the LDS counter to drain -- i.e. for every prefetch and store in flight.
+#define SGD_LDS(T) __attribute__((address_space(3))) T
+template <bool kLds> struct K1State { using D = double*; using U = unsigned*; };
+template <> struct K1State<true> { using D = SGD_LDS(double)*; using U = SGD_LDS(unsigned)*; };
+
 // The workgroup is ONE wavefront, whose LDS operations execute in program order: when all
 // shared state lives in LDS, ordering lanes against each other only needs the compiler to keep
 // program order and the LDS queue to drain -- NOT `s_waitcnt vmcnt(0)`, which __syncthreads()
@@ -93,8 +100,8 @@ __device__ __forceinline__ double softmax_gradient_lanes(double lp, int K, int l
 }
 
 // ConvergenceCheck (src/utils.h:240-262), executed by the whole wave.
-__device__ __forceinline__ int convergence_check(const double* w, double* w_prev, int64_t len,
-                                                 double tol, int lane) {
+template <typename WP>
+__device__ __forceinline__ int convergence_check(WP w, double* w_prev, int64_t len, double tol, int lane) {
   double max_change = 0.0, max_size = 0.0;
   bool finite = true;
   for (int64_t i = lane; i < len; i += kWave) {
@@ -120,6 +127,7 @@ __device__ __forceinline__ int convergence_check(const double* w, double* w_prev
 //   [slp K][sgc K][sb K][sgb K][sval 64][LS cache kLsCache][sidx 64 int][w KP][G KP][lag p u32]
 constexpr int kLsCache = 2048;
 
+template <bool kLds>
 __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, const LamParams* lamp,
                                                                   ExactCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -127,26 +135,30 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
   const int K = d.K;
   const int64_t p = d.p;
   const int64_t KP = (int64_t)K * p;
-  const bool lds_only = ctl.use_lds != 0;
+  constexpr bool lds_only = kLds;
 
-  double* slp = reinterpret_cast<double*>(smem);
-  double* sgc = slp + K;
-  double* sb = sgc + K;          // intercept, kept on chip for the whole launch
-  double* sgb = sb + K;          // g_sum_intercept
-  double* sval = sgb + K;        // the drawn row, staged for the ascending-order dot product
-  double* sls = sval + kWave;    // first kLsCache entries of lag_scaling
-  int* sidx = reinterpret_cast<int*>(sls + kLsCache);
-  double* w = d.w;
-  double* G = d.G;
-  unsigned* lag = d.lag;
-  if (ctl.use_lds) {
-    w = reinterpret_cast<double*>(sidx + kWave);
+  SGD_LDS(double)* slp = (SGD_LDS(double)*)smem;
+  SGD_LDS(double)* sgc = slp + K;
+  SGD_LDS(double)* sb = sgc + K;          // intercept, kept on chip for the whole launch
+  SGD_LDS(double)* sgb = sb + K;          // g_sum_intercept
+  SGD_LDS(double)* sval = sgb + K;        // the drawn row, staged for the ascending-order dot product
+  SGD_LDS(double)* sls = sval + kWave;    // first kLsCache entries of lag_scaling
+  SGD_LDS(int)* sidx = (SGD_LDS(int)*)(sls + kLsCache);
+  typename K1State<kLds>::D w;
+  typename K1State<kLds>::D G;
+  typename K1State<kLds>::U lag;
+  if constexpr (kLds) {
+    w = (SGD_LDS(double)*)(sidx + kWave);
     G = w + KP;
-    lag = reinterpret_cast<unsigned*>(G + KP);
+    lag = (SGD_LDS(unsigned)*)(G + KP);
     for (int64_t i = lane; i < KP; i += kWave) {
       w[i] = d.w[i];
       G[i] = d.G[i];
     }
+  } else {
+    w = d.w;
+    G = d.G;
+    lag = d.lag;
   }
   const unsigned nit = (unsigned)ctl.nit;
   const double* LS = ctl.LS;
@@ -159,7 +171,11 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
   for (int64_t i = lane; i < KP; i += kWave) d.w_prev[i] = w[i];     // :251
   wave_sync(lds_only);
 
-  auto ls_at = [&](unsigned m) -> double { return m < (unsigned)kLsCache ? sls[m] : LS[m]; };
+  auto ls_at = [&](unsigned m) -> double {   // (not a select between an LDS and a global address)
+    double v = sls[m < (unsigned)kLsCache ? m : 0u];
+    if (m >= (unsigned)kLsCache) v = LS[m];
+    return v;
+  };
 
   const int penalty = lamp->penalty;
   const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
@@ -390,7 +406,7 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
     wave_sync(lds_only);
   } while (!converged && it_outer < ctl.max_epochs);                 // :371
 
-  if (ctl.use_lds) {
+  if constexpr (kLds) {
     for (int64_t i = lane; i < KP; i += kWave) {
       d.w[i] = w[i];
       d.G[i] = G[i];
@@ -456,9 +472,6 @@ __device__ __forceinline__ double k1_soft(double x, double s, bool plain) {
   return t > 0.0 ? copysign(t, x) : 0.0;
 }
 
-#define SGD_LDS(T) __attribute__((address_space(3))) T
-template <bool kLds> struct K1State { using D = double*; using U = unsigned*; };
-template <> struct K1State<true> { using D = SGD_LDS(double)*; using U = SGD_LDS(unsigned)*; };
 SGD_DEFINE_EXP(sgd_exp_lds, const SGD_LDS(double)*)
 
 // one counter of the ring, the same value in every lane and known to be so
@@ -806,7 +819,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
           const int64_t j = d.idx[q];
           const unsigned lagged = it - lag[j];
           if (lagged != 0u) {
-            penalty_apply_q(penalty, 1, (double*)(w + j), (double*)(G + j), W, ls_at(lagged), q_prev, gamma, beta);
+            penalty_apply_q(penalty, 1, w + j, G + j, W, ls_at(lagged), q_prev, gamma, beta);
             lag[j] = it;
           }
         }
@@ -852,7 +865,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
         wave_mem_sync();
         for (int64_t j = lane; j < p; j += kWave) {
           const unsigned lagged = it - lag[j];
-          if (lagged != 0u) penalty_apply(penalty, 1, (double*)(w + j), (double*)(G + j), W, ls_at(lagged), gamma, beta);
+          if (lagged != 0u) penalty_apply(penalty, 1, w + j, G + j, W, ls_at(lagged), gamma, beta);
           w[j] *= W;
           lag[j] = it;
         }
@@ -899,7 +912,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
           const int64_t j = d.idx[q];
           const unsigned lagged = (it + 1u) - lag[j];
           if (lagged != 0u) {
-            penalty_apply_q(penalty, 1, (double*)(w + j), (double*)(G + j), Wp, ls_at(lagged), q_t, gamma, beta);
+            penalty_apply_q(penalty, 1, w + j, G + j, Wp, ls_at(lagged), q_t, gamma, beta);
             lag[j] = it + 1u;
           }
           G[j] += d.val[q] * gc * g_scale;
@@ -954,13 +967,13 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
     wave_mem_sync();
     for (int64_t j = lane; j < p; j += kWave) {
       const unsigned lagged = nit - lag[j];
-      if (lagged != 0u) penalty_apply(penalty, 1, (double*)(w + j), (double*)(G + j), W_end, ls_at(lagged), gamma, beta);
+      if (lagged != 0u) penalty_apply(penalty, 1, w + j, G + j, W_end, ls_at(lagged), gamma, beta);
       w[j] *= W_end;
       lag[j] = 0u;
     }
     wave_mem_sync();
 
-    converged = convergence_check((double*)w, d.w_prev, p, ctl.tol, lane);    // :367
+    converged = convergence_check(w, d.w_prev, p, ctl.tol, lane);    // :367
     ++it_outer;
     wave_mem_sync();
     fetch_state(0u);
@@ -1877,11 +1890,8 @@ int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCt
 
 int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
                         hipStream_t st) {
-  SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_sparse_exact_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-  hipLaunchKernelGGL(saga_sparse_exact_kernel, dim3(1), dim3(kWave), lds_bytes, st, d, lam, ctl);
-  SGD_HIP_TRY(hipGetLastError());
-  return SGDNET_OK;
+  return ctl.use_lds ? launch_k1_t(saga_sparse_exact_kernel<true>, kWave, d, lam, ctl, lds_bytes, st)
+                     : launch_k1_t(saga_sparse_exact_kernel<false>, kWave, d, lam, ctl, lds_bytes, st);
 }
 
 // Workgroup size and LDS of the wide dense kernel; 0 threads: not eligible (more than 16 classes).
