@@ -455,7 +455,7 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
 // lane, and takes the latest match instead.
 // --------------------------------------------------------------------------
 constexpr int kOwnSlots = 8192;                                   // bytes: feature (hashed) -> lane of the draw in hand
-constexpr int kK1Sum = kWave + 8;                                 // products of the draw in hand, padded to whole blocks
+constexpr int kK1Sum = kWave + 16;                                // products of the draw in hand, padded to whole blocks
 constexpr size_t kK1FixedLds = sizeof(double) * (kK1Sum + 128) + kOwnSlots;
 
 constexpr int kRing = 16;                                          // slots (a power of two)
@@ -742,9 +742,18 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
   unsigned it_outer = 0;
   int converged = 0;
   int64_t u = 0;
+#ifdef SGDNET_PHASE_TIMING
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define K1_STAMP(i) do { const unsigned long long now_ = clock64(); ph[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define K1_STAMP(i) ((void)0)
+#endif
   do {
     double W_end = 1.0;
     for (unsigned it = 0; it < nit; ++it, ++u) {
+#ifdef SGDNET_PHASE_TIMING
+      unsigned long long last_ = clock64();
+#endif
       // ---- the draw in hand -----------------------------------------------------------------------
       const long long sl = __double_as_longlong(h_sl);
       const uint32_t s = (uint32_t)(sl & 0xffffffffll);             // :261
@@ -761,6 +770,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
       if (stalled) break;
       const int r0 = (int)(u & (kWave - 1));
 
+      K1_STAMP(0);
       double wj = w0, Gj = G0;
       double acc = 0.0;
       int len_nx = 0;
@@ -782,6 +792,12 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
         // linear predictor, ascending feature order  :274 (products past the row are +0.0: adding them changes nothing)
         sx[lane] = mine ? val_c * wj : 0.0;
         lanes_publish();
+        // (the first sixteen products are asked back at once, and before the requests below: read four at a time
+        // inside the adding loop, every block paid an LDS round trip of its own -- 1500 cycles for 30 entries)
+        double pr[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pr[e] = sx[e];
+        lanes_publish();
         // ---- the next draw: w / g_sum / lag, requested before this draw's stores (forwarded below) ----
         len_nx = (int)(__double_as_longlong(h_sl) >> 32);
         mine_n = lane < len_nx && len_nx <= kWave;
@@ -801,9 +817,18 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
           if (mine) owner[h_c] = 0;
           collide = __ballot(chk != (unsigned)(lane + 1)) != 0ull;   // two features of this row share a slot: compare instead
         }
-        for (int eb = 0; eb < len; eb += 4) {
+        for (int base = 0;;) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc += sx[eb + e];
+          for (int blk = 0; blk < 4; ++blk) {
+            if (base + 4 * blk < len) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc += pr[4 * blk + e];
+            }
+          }
+          base += 16;
+          if (base >= len) break;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) pr[e] = sx[base + e];
         }
       } else {
         // ---- the next draw: w / g_sum / lag, requested before this draw's stores (forwarded below) ----
@@ -831,6 +856,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
           for (int e = 0; e < cnt; ++e) acc += readlane_d(wx, e);
         }
       }
+      K1_STAMP(1);
       // gradient memory: a draw of the same sample among the last 64 supersedes the producer's copy
       {
         const unsigned long long mask = __ballot(hs == s);
@@ -855,6 +881,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
         hg = g;
       }
 
+      K1_STAMP(2);
       // rescale + unlag whenever wscale becomes too small  :285-295
       bool refetch = !shortrow;
       if (W < kSmall) {
@@ -889,6 +916,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
         tauc_e = bg * lsc_e / W_n;
       }
 
+      K1_STAMP(3);
       if (shortrow) {
         if (mine) {
           wj += val_c * gc * (-q_t);                                 // AddWeighted(w, ..., -gamma/wscale)  :306-313
@@ -919,6 +947,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
         }
       }
 
+      K1_STAMP(4);
       // ---- hand the next draw its state ------------------------------------------------------------
       if (refetch || it + 1u == nit) {
         // memory was rewritten behind the request (or is about to be, by Reset): ask again once the stores are in
@@ -960,6 +989,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
         lsc0 = lsc_e;
         tauc = tauc_e;
       }
+      K1_STAMP(5);
     }
 
     if (stalled) break;
@@ -983,8 +1013,10 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
   if (d.dbg && lane == 0) {
     d.dbg[10] += cons_spins;
     d.dbg[11] += cons_waits;
+    for (int i = 0; i < 6; ++i) d.dbg[i] += ph[i];
   }
 #endif
+#undef K1_STAMP
 
   if constexpr (kLds) {
     for (int64_t i = lane; i < p; i += kWave) {

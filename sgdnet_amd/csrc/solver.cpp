@@ -1499,6 +1499,9 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         (void)hipMemset(s->d.dbg, 0, sizeof(c));
         fprintf(stderr, "[sgdnet] producer/consumer sparse kernel, %d x %lld draws: producer waited %llu times (%llu polls), consumer %llu times (%llu polls)\n",
                 out[0], (long long)draws_per_epoch, c[9], c[8], c[11], c[10]);
+        const double its = (double)out[0] * (double)draws_per_epoch;
+        fprintf(stderr, "[sgdnet]   consumer cycles per draw: slot+requests %.0f, catch-up+sum %.0f, gradient %.0f, scale+intercept+early threshold %.0f, "
+                        "step+stores %.0f, forward %.0f\n", c[0] / its, c[1] / its, c[2] / its, c[3] / its, c[4] / its, c[5] / its);
       }
       if (wide && s->d.dbg && out[0] > 0) {   // development aid: shader-clock cycles of thread 0 per phase of the wide kernel
         unsigned long long ph[6];
