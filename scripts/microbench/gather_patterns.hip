@@ -22,7 +22,7 @@
 #include <vector>
 #define CK(x) do{hipError_t e=(x); if(e!=hipSuccess){printf("%s failed %s\n",#x,hipGetErrorString(e)); exit(1);} }while(0)
 
-enum { REC = 1, XCHG = 2, LD = 4, LOG = 8, RING = 16, ST = 32, INREC = 64, NT = 128, WT = 256, NTST = 512, XREC = 1024 };
+enum { REC = 1, XCHG = 2, LD = 4, LOG = 8, RING = 16, ST = 32, INREC = 64, NT = 128, WT = 256, NTST = 512, XREC = 1024, XRECW = 2048 };
 
 struct Args {
   char* rec;
@@ -76,6 +76,11 @@ __global__ __launch_bounds__(1024) void k(Args a) {
           old[u] = __longlong_as_double((long long)__hip_atomic_exchange(
               reinterpret_cast<unsigned long long*>(a.rec + (size_t)s[u] * 128 + 120), (unsigned long long)__double_as_longlong(nv),
               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (MODE & XRECW)                      // the same exchange at workgroup scope: performed in this XCD's L2 (valid
+                                               // only if every draw of a sample runs on one XCD)
+          old[u] = __longlong_as_double((long long)__hip_atomic_exchange(
+              reinterpret_cast<unsigned long long*>(a.rec + (size_t)s[u] * 128 + 120), (unsigned long long)__double_as_longlong(nv),
+              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (MODE & LOG) a.log[base + it + u] = nv + old[u];
         if (MODE & ST) a.M[s[u]] = nv + old[u];
         if (MODE & INREC) {
@@ -187,6 +192,9 @@ int main(int argc, char** argv) {
   run<4, REC | INREC>("rec + st into the record", a, draws, 256, st);
   run<4, REC | XREC>("rec + dependent xchg INTO the record", a, draws, 256, st);
   run<8, REC | XREC>("rec + dependent xchg INTO the record", a, draws, 256, st);
+  run<4, REC | XRECW>("rec + xchg INTO the record, workgroup scope", a, draws, 256, st);
+  run<8, REC | XRECW>("rec + xchg INTO the record, workgroup scope", a, draws, 256, st);
+  run<4, REC | XREC>("rec + dependent xchg INTO the record (again)", a, draws, 256, st);
   run<4, REC | XCHG>("rec + dependent xchg (again)", a, draws, 256, st);
   run<4, REC | INREC>("rec + st into the record (again)", a, draws, 256, st);
   run<4, REC | INREC | WT>("rec + st into the record (sc0 sc1)", a, draws, 256, st);
