@@ -32,10 +32,11 @@
 extern "C" {
 #endif
 
-/* 2: sgdnet_control carries losses_sink / losses_ctx, sgdnet_set_option exists.  A caller compiled against
+/* 2: sgdnet_control carries losses_sink / losses_ctx, sgdnet_set_option exists.  3: sgdnet_auc_*_rng, the option
+ * exact_row_registers, sgdnet_solver_rng_layout (additions only).  A caller compiled against
  * another version must not pass its structs: the shim and the Python binding compare sgdnet_abi_version()
  * with this constant when they load the library. */
-#define SGDNET_ABI_VERSION 2
+#define SGDNET_ABI_VERSION 3
 
 /* error codes */
 #define SGDNET_OK          0
@@ -391,6 +392,13 @@ int sgdnet_auc_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t
                       int device, double* out);
 int sgdnet_auc_dense(const double* x, int64_t n, int64_t p, const double* y, const double* a0, const double* beta,
                      int n_lambda, const double* tie, int device, double* out);
+/* The same with the tie breakers drawn on the device: stats::runif(2n) per lambda, in lambda order, from *rng, which
+ * is left where 2 n n_lambda calls of unif_rand() leave R's generator (round 3; before, the caller drew them). */
+int sgdnet_auc_sparse_rng(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+                          const double* y, const double* a0, const double* beta, int n_lambda, sgdnet_rng* rng,
+                          int device, double* out);
+int sgdnet_auc_dense_rng(const double* x, int64_t n, int64_t p, const double* y, const double* a0, const double* beta,
+                         int n_lambda, sgdnet_rng* rng, int device, double* out);
 int sgdnet_predict_sparse(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx,
                           const double* values, int n_classes, const double* a0, const double* beta,
                           int n_lambda, int device, double* link);

@@ -29,10 +29,10 @@ EXPORTS = [
     "sgdnet_solver_sync_end", "sgdnet_solver_set_n_total",
     "sgdnet_solver_export_delta_weighted_async", "sgdnet_solver_set_virtual_shards", "sgdnet_solver_set_merge_period",
     "sgdnet_score_sparse", "sgdnet_score_dense", "sgdnet_predict_sparse", "sgdnet_predict_dense",
-    "sgdnet_auc_sparse", "sgdnet_auc_dense",
+    "sgdnet_auc_sparse", "sgdnet_auc_dense", "sgdnet_auc_sparse_rng", "sgdnet_auc_dense_rng",
     "sgdnet_solver_rng_layout", "sgdnet_solver_rng_open", "sgdnet_solver_rng_next", "sgdnet_solver_rng_done", "sgdnet_solver_rng_close",
 ]
-ABI_VERSION = 2   # include/sgdnet_hip.h: SGDNET_ABI_VERSION
+ABI_VERSION = 3   # include/sgdnet_hip.h: SGDNET_ABI_VERSION
 MEASURES = {"deviance": 0, "mse": 1, "mae": 2, "class": 3, "auc": 4}
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}

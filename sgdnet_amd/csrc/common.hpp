@@ -228,6 +228,7 @@ int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_sa
 // jump-ahead of R's Mersenne-Twister (mt_jump.cpp, r_rng_device.hip)
 bool mt_jump_poly(uint64_t J, uint32_t* out624);
 void mt_jump_host(const sgdnet_rng* in, const uint32_t* poly624, sgdnet_rng* out);
+int launch_rng_unif(const uint32_t* state_in, uint32_t* state_out, uint32_t* raw, double* out, int64_t count, hipStream_t st);
 int launch_rng_jump(const uint32_t* state_in, uint32_t* state_out, const uint32_t* poly_dev, int gens,
                     hipStream_t st, int max_wgs = 0);
 int rng_generators_per_workgroup();

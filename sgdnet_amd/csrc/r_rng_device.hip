@@ -311,6 +311,37 @@ __global__ __launch_bounds__(256) void r_mt_convert_kernel(uint32_t* out, int64_
   }
 }
 
+// unif_rand() itself (tempering, scaling to [0, 1), fixup into (0, 1)): the draws stats::runif() hands score()'s AUC
+// for its tie breakers (R/score.R:221)
+__global__ __launch_bounds__(256) void r_mt_unif_kernel(const uint32_t* raw, double* out, int64_t count) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
+    uint32_t y = raw[i];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    const double i2_32m1 = 2.328306437080797e-10;
+    double u = (double)y * 2.3283064365386963e-10;
+    if (u <= 0.0) u = 0.5 * i2_32m1;
+    if (1.0 - u <= 0.0) u = 1.0 - 0.5 * i2_32m1;
+    out[i] = u;
+  }
+}
+
+// `count` consecutive unif_rand() of the generator in state_in (one sgdnet_rng on the device) into out; raw: scratch of
+// `count` words; state_out (may alias state_in): the generator after them
+int launch_rng_unif(const uint32_t* state_in, uint32_t* state_out, uint32_t* raw, double* out, int64_t count,
+                    hipStream_t st) {
+  hipLaunchKernelGGL(r_mt_state_kernel, dim3(1), dim3(kRngBlock * kGenPerWg), 0, st, state_in, state_out, raw, count,
+                     count, 1);
+  int grid = (int)((count + 256 * 8 - 1) / (256 * 8));
+  if (grid < 1) grid = 1;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(r_mt_unif_kernel, dim3(grid), dim3(256), 0, st, raw, out, count);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
 // state_in -> state_out (may alias); raw words then draws into out[0, count)
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards, const double* shard_size, int gens, int64_t run_len) {

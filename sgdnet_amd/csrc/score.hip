@@ -228,7 +228,7 @@ struct DevBufs {
 int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
               const double* x_dense, const double* y, int y_rows, int family, int n_classes, const double* a0,
               const double* beta, int n_lambda, int measure, int device, double* out, double* link,
-              const double* tie = nullptr) {
+              const double* tie = nullptr, sgdnet_rng* rng = nullptr) {
   const bool auc = measure == SGDNET_MEASURE_AUC;
   if (n < 1 || p < 1 || n_lambda < 1 || n_classes < 1 || !a0 || !beta || (!out && !link) ||
       (out && (!y || y_rows < 1)) || family < SGDNET_GAUSSIAN || family > SGDNET_MGAUSSIAN ||
@@ -304,6 +304,7 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
   unsigned long long *key_a = nullptr, *key_b = nullptr, *u_d = nullptr;
   unsigned *idx_a = nullptr, *idx_b = nullptr, *neg_d = nullptr, *before_d = nullptr;
   double* tie_d = nullptr;
+  uint32_t *rng_d = nullptr, *raw_d = nullptr;
   void* tmp_d = nullptr;
   size_t tmp_bytes = 0;
   int64_t n1 = 0;
@@ -321,7 +322,11 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
         (rc = bufs.upload<unsigned>(&idx_a, nullptr, (size_t)n, st)) || (rc = bufs.upload<unsigned>(&idx_b, nullptr, (size_t)n, st)) ||
         (rc = bufs.upload<unsigned>(&neg_d, nullptr, (size_t)n, st)) || (rc = bufs.upload<unsigned>(&before_d, nullptr, (size_t)n, st)))
       return rc;
-    if (tie && (rc = bufs.upload<double>(&tie_d, nullptr, (size_t)2 * n, st))) return rc;
+    if ((tie || rng) && (rc = bufs.upload<double>(&tie_d, nullptr, (size_t)2 * n, st))) return rc;
+    // tie breakers drawn here: the caller's generator moves to the device and back (R/score.R:221: runif(2 n) per lambda)
+    if (rng && ((rc = bufs.upload<uint32_t>(&rng_d, reinterpret_cast<const uint32_t*>(rng), sizeof(sgdnet_rng) / 4, st)) ||
+                (rc = bufs.upload<uint32_t>(&raw_d, nullptr, (size_t)2 * n, st))))
+      return rc;
     SGD_HIP_TRY(hipMemsetAsync(u_d, 0, sizeof(unsigned long long) * n_lambda, st));
     size_t b1 = 0, b2 = 0;
     SGD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, b1, key_a, key_b, idx_a, idx_b, (int)n, 0, 64, st));
@@ -352,7 +357,11 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
     if (auc) {
       const unsigned g = (unsigned)((n + 255) / 256);
       for (int l = 0; l < L; ++l) {
-        if (tie) SGD_HIP_TRY(hipMemcpyAsync(tie_d, tie + (size_t)2 * n * (l0 + l), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+        if (rng) {
+          if ((rc = launch_rng_unif(rng_d, rng_d, raw_d, tie_d, 2 * n, st))) return rc;
+        } else if (tie) {
+          SGD_HIP_TRY(hipMemcpyAsync(tie_d, tie + (size_t)2 * n * (l0 + l), sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+        }
         hipLaunchKernelGGL(auc_keys_kernel, dim3(g), dim3(256), 0, st, link_d, n, L, l, a.y, tie_d, key_a, idx_a);
         // stable order by the tie breaker first, then by the probability
         SGD_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp_d, tmp_bytes, key_a, key_b, idx_a, idx_b, (int)n, 0, 64, st));
@@ -375,6 +384,7 @@ int run_score(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx
   }
   if (auc) {
     std::vector<unsigned long long> u((size_t)n_lambda);
+    if (rng) SGD_HIP_TRY(hipMemcpyAsync(rng, rng_d, sizeof(sgdnet_rng), hipMemcpyDeviceToHost, st));
     SGD_HIP_TRY(hipMemcpyAsync(u.data(), u_d, sizeof(unsigned long long) * n_lambda, hipMemcpyDeviceToHost, st));
     SGD_HIP_TRY(hipStreamSynchronize(st));
     // exp(log(sum) - log(n1) - log(n0)), as R/score.R:225-227 forms it
@@ -434,6 +444,27 @@ int sgdnet_auc_dense(const double* x, int64_t n, int64_t p, const double* y, con
                      int n_lambda, const double* tie, int device, double* out) {
   return sgdnet::run_score(n, p, nullptr, nullptr, nullptr, x, y, 1, SGDNET_BINOMIAL, 1, a0, beta, n_lambda,
                            SGDNET_MEASURE_AUC, device, out, nullptr, tie);
+}
+
+int sgdnet_auc_sparse_rng(int64_t n, int64_t p, const int64_t* rowptr, const int32_t* colidx, const double* values,
+                          const double* y, const double* a0, const double* beta, int n_lambda, sgdnet_rng* rng,
+                          int device, double* out) {
+  if (!rng) {
+    sgdnet::set_error("sgdnet_auc_sparse_rng: no generator");
+    return SGDNET_EINVAL;
+  }
+  return sgdnet::run_score(n, p, rowptr, colidx, values, nullptr, y, 1, SGDNET_BINOMIAL, 1, a0, beta, n_lambda,
+                           SGDNET_MEASURE_AUC, device, out, nullptr, nullptr, rng);
+}
+
+int sgdnet_auc_dense_rng(const double* x, int64_t n, int64_t p, const double* y, const double* a0, const double* beta,
+                         int n_lambda, sgdnet_rng* rng, int device, double* out) {
+  if (!rng) {
+    sgdnet::set_error("sgdnet_auc_dense_rng: no generator");
+    return SGDNET_EINVAL;
+  }
+  return sgdnet::run_score(n, p, nullptr, nullptr, nullptr, x, y, 1, SGDNET_BINOMIAL, 1, a0, beta, n_lambda,
+                           SGDNET_MEASURE_AUC, device, out, nullptr, nullptr, rng);
 }
 
 }  // extern "C"

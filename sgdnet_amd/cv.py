@@ -138,13 +138,10 @@ def cv_sgdnet(x, y, alpha=1, lambda_=None, nfolds=10, foldid=None, type_measure=
         train = sel if train_on == "fold" else ~sel
         test = ~train
         fit = one_fit(x[train], y[train], lam[i], alpha[i], dev, fit_seed)
-        tie = None
-        if type_measure == "auc" and sequential:
-            # R/score.R auc(): stats::runif(2 n) per lambda, in column order, from the global generator -- the
-            # draws order equal probabilities AND move the stream the next fold's fit starts from
-            m, L = int(np.sum(test)), lam[i].size
-            tie = rng.unif(2 * m * L).reshape(L, 2 * m).T
-        return i, j, score(fit, x[test], y[test], type_measure, device=dev, tie_break=tie)
+        # R/score.R auc(): stats::runif(2 n) per lambda, in column order, from the global generator -- the draws order
+        # equal probabilities AND move the stream the next fold's fit starts from; drawn on the device (sgdnet_auc_*_rng)
+        tie_rng = rng if (type_measure == "auc" and sequential) else None
+        return i, j, score(fit, x[test], y[test], type_measure, device=dev, rng=tie_rng)
 
     jobs = [(i, j, (i * nfolds + j) % len(devices), seed + 1000 + i * nfolds + j)
             for i in range(alpha.size) for j in range(nfolds)]               # (alpha, fold, worker, seed)

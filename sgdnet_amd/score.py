@@ -38,7 +38,7 @@ def auc(y01, prob, weights=None, tie_break=None):
     return float(np.exp(wauc - np.log(sumw1) - np.log(sumw2)))
 
 
-def _score_device(fit, x, y, type_measure, s, device, tie_break=None):
+def _score_device(fit, x, y, type_measure, s, device, tie_break=None, rng=None):
     """sgdnet_score_* (score.hip): linear predictors, per-sample losses and their means in one
     kernel on the GPU; x never leaves sample-major form and no (n, n_lambda) array is built.
     "auc": sgdnet_auc_* -- probabilities, two stable radix sorts (tie breaker, probability), a scan of
@@ -79,7 +79,10 @@ def _score_device(fit, x, y, type_measure, s, device, tie_break=None):
                                        if np.ndim(tie_break) == 2 else np.tile(np.asarray(tie_break, dtype=np.float64), L))
             if tie.size != 2 * n_new * L:
                 raise ValueError("tie_break needs 2 n entries (or a (2 n, n_lambda) array)")
-        common = (dptr(yy), dptr(a0), dptr(beta), C.c_int(L), dptr(tie) if tie is not None else None, C.c_int(device),
+        if rng is not None and tie is not None:
+            raise ValueError("pass tie_break or rng, not both")
+        common = (dptr(yy), dptr(a0), dptr(beta), C.c_int(L),
+                  C.byref(rng.state) if rng is not None else (dptr(tie) if tie is not None else None), C.c_int(device),
                   dptr(out))
     if type_measure == "auc" and sp.issparse(x):
         X = sp.csr_matrix(x, dtype=np.float64)
@@ -87,11 +90,13 @@ def _score_device(fit, x, y, type_measure, s, device, tie_break=None):
         ptr = np.ascontiguousarray(X.indptr, dtype=np.int64)
         idx = np.ascontiguousarray(X.indices, dtype=np.int32)
         val = np.ascontiguousarray(X.data, dtype=np.float64)
-        check(Lh.sgdnet_auc_sparse(C.c_int64(X.shape[0]), C.c_int64(p), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
-                                   idx.ctypes.data_as(C.POINTER(C.c_int32)), dptr(val), *common))
+        fn = Lh.sgdnet_auc_sparse_rng if rng is not None else Lh.sgdnet_auc_sparse
+        check(fn(C.c_int64(X.shape[0]), C.c_int64(p), ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                 idx.ctypes.data_as(C.POINTER(C.c_int32)), dptr(val), *common))
     elif type_measure == "auc":
         X = np.ascontiguousarray(x, dtype=np.float64)
-        check(Lh.sgdnet_auc_dense(dptr(X), C.c_int64(X.shape[0]), C.c_int64(p), *common))
+        fn = Lh.sgdnet_auc_dense_rng if rng is not None else Lh.sgdnet_auc_dense
+        check(fn(dptr(X), C.c_int64(X.shape[0]), C.c_int64(p), *common))
     elif sp.issparse(x):
         X = sp.csr_matrix(x, dtype=np.float64)
         X.sort_indices()
@@ -110,20 +115,26 @@ def _score_device(fit, x, y, type_measure, s, device, tie_break=None):
     return out
 
 
-def score(fit, x, y, type_measure="deviance", s=None, device=None, tie_break=None):
+def score(fit, x, y, type_measure="deviance", s=None, device=None, tie_break=None, rng=None):
     """score.sgdnet_<family>: one value per lambda (or per entry of s).
     device: evaluate on that GPU.  tie_break ("auc" only): the reference orders equal probabilities by
     stats::runif(2n) drawn per lambda; pass those draws (2n values used for every lambda, or a (2n, n_lambda)
-    array) to reproduce it, default: sample order."""
+    array) to reproduce it, default: sample order.  rng (an RRng; "auc" on a device only): draw them on the device
+    from that generator instead -- 2n per lambda, in lambda order -- and leave it where R's would be."""
     fam = fit.family
     if type_measure not in _MEASURES[fam]:
         raise ValueError("'arg' should be one of " + ", ".join(f"'{m}'" for m in _MEASURES[fam]))
     s = fit.lambda_ if s is None else s
     y = np.asarray(y)
+    if rng is not None and type_measure == "auc" and device is None:
+        if tie_break is not None:
+            raise ValueError("pass tie_break or rng, not both")
+        m, L = y.shape[0], np.size(s)
+        tie_break = rng.unif(2 * m * L).reshape(L, 2 * m).T          # the host mirror of sgdnet_auc_*_rng
     if device is not None:
         if type_measure == "deviance" and fam in ("gaussian", "mgaussian"):
             type_measure = "mse"                                  # R/score.R:63, 180: the same number
-        return _score_device(fit, x, y, type_measure, s, device, tie_break)
+        return _score_device(fit, x, y, type_measure, s, device, tie_break, rng if type_measure == "auc" else None)
     if fam == "gaussian":                                         # R/score.R:55-70
         yh = predict(fit, x, s)
         d = yh - y.reshape(-1, 1)

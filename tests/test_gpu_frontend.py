@@ -181,6 +181,16 @@ def test_device_auc_breaks_ties_like_the_reference(sa, sparse):
         assert np.allclose(host, dev, rtol=1e-13, atol=0), (host, dev)
     assert not np.allclose(sa.score(fit, xt, yt, "auc", tie_break=shared), sa.score(fit, xt, yt, "auc"))   # ties matter here
     assert abs(host[0] - 0.5) < 0.15                                # intercept only: the area of a coin flip
+    # round 3: the draws made on the device from an R generator (sgdnet_auc_*_rng) -- the same areas as with the
+    # generator's draws made on the host, and the generator left in the same state
+    r_host, r_dev = sa.RRng(5), sa.RRng(5)
+    drawn = r_host.unif(2 * m * L).reshape(L, 2 * m).T
+    want = sa.score(fit, xt, yt, "auc", device=0, tie_break=drawn)
+    got = sa.score(fit, xt, yt, "auc", device=0, rng=r_dev)
+    assert np.array_equal(got, want)
+    assert r_dev.unif(3).tolist() == r_host.unif(3).tolist()
+    r_h2 = sa.RRng(5)
+    assert np.allclose(sa.score(fit, xt, yt, "auc", rng=r_h2), want, rtol=1e-13, atol=0)   # host mirror of the same protocol
 
 
 @pytest.mark.gpu
