@@ -62,7 +62,7 @@ class OracleBackend:
         import importlib
         CV = importlib.import_module("sgdnet_amd.cv")
         S = importlib.import_module("sgdnet_amd.score")
-        with _patched(CV, sgdnet=R.oracle_sgdnet, score=lambda fit, xx, yy, m, device=None, tie_break=None: S.score(fit, xx, yy, m, tie_break=tie_break)):
+        with _patched(CV, sgdnet=R.oracle_sgdnet, score=lambda fit, xx, yy, m, device=None, tie_break=None, rng=None: S.score(fit, xx, yy, m, tie_break=tie_break, rng=rng)):
             return CV.cv_sgdnet(x, y, rng=rng, densify=True, **kw)
 
 
