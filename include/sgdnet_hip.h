@@ -171,8 +171,11 @@ int sgdnet_device_count(void);
 /*                        response and explicit x keeps the drawn row's      */
 /*                        coefficients in registers for the whole draw and   */
 /*                        requests the next draw's a draw ahead (same bits,  */
-/*                        DESIGN.md 4.1); 0: the general kernel; 2: as 1 but */
-/*                        the state stays in memory where the LDS would fit it*/
+/*                        DESIGN.md 4.1), with several consumer wavefronts   */
+/*                        where draws seldom share a feature; 0: the general */
+/*                        kernel; 2: one consumer, state kept in memory; 3:  */
+/*                        several consumers wherever that is legal; 4: one   */
+/*                        consumer always                                    */
 /* Unknown names and out-of-range values return SGDNET_EINVAL.  Options are  */
 /* read when a fit starts; changing them during a fit on another thread      */
 /* affects later fits only.                                                  */

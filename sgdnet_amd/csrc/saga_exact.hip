@@ -1033,6 +1033,446 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
 }
 
 // --------------------------------------------------------------------------
+// Several consumers (round 3, last step): draws whose supports are disjoint only meet in the intercept, so kCons
+// consumer wavefronts take the draws round robin (draw u -> wavefront u % kCons) and everything but the intercept
+// chain of different draws overlaps.  What keeps the result the reference's, bit for bit:
+//   * registration, in draw order: a draw stamps its features in an LDS table (feature, hashed -> index of the last
+//     draw that holds it) and reads the stamps it replaces; a stamp inside the window of draws still in flight means
+//     "wait until every draw up to that one has completed" (a collision of the hash only makes a draw wait for more);
+//   * completion: a wavefront publishes a draw as complete once its stores of w / g_sum / lag are acknowledged
+//     (s_waitcnt vmcnt(0), taken right after the NEXT draw's registration so that it costs nothing); readers load
+//     the state past the L1;
+//   * the chain, in draw order: wait for b(u-1), form the linear predictor, the gradient and b(u), publish; the last
+//     64 (sample, gradient) pairs travel with it through the LDS for draws that repeat a sample;
+//   * the epoch end (Reset, ConvergenceCheck) between barriers of the consumers.
+// w / g_sum / lag stay in memory (L2): with them in the LDS the window p <= 4800 is also the one where neighbouring
+// draws share features all the time.  Rows longer than a wavefront and lambdas whose w_scale can fall below SMALL
+// inside an epoch take the two-wavefront kernel above (the host decides: sparse_exact_k1m_eligible).
+// Every wait loop gives up after kK1xSpinLimit polls or when another wavefront has raised the abort flag.
+// --------------------------------------------------------------------------
+constexpr int kCons = 6;
+constexpr int kDepSlots = 16384;
+constexpr int kK1mCtrl = 8;         // produced, registered, chain_done, stop/abort, barrier count, converged, epochs, spare
+constexpr size_t kK1mFixedLds = sizeof(double) * ((size_t)kCons * kK1Sum + 128 + kRing * (kWave + kSlotHdr) + 4 + kWave) +
+                                sizeof(unsigned long long) * (kK1mCtrl + kRing + kWave) +
+                                sizeof(int) * (kRing * kWave) + sizeof(unsigned) * (kWave + kDepSlots);
+
+__global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_kernel(SagaDev d, const LamParams* lamp,
+                                                                                    ExactCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int T = (kCons + 1) * kWave;
+  const int64_t p = d.p;
+  const unsigned L = (unsigned)ctl.ls_cache;
+  SGD_LDS(double)* sx_all = (SGD_LDS(double)*)smem;                           // [kCons][kK1Sum]
+  SGD_LDS(double)* sexp = sx_all + kCons * kK1Sum;                            // [128]
+  SGD_LDS(double)* rval = sexp + 128;                                         // [kRing][kWave]
+  SGD_LDS(double)* rhdr = rval + kRing * kWave;                               // [kRing][kSlotHdr]
+  SGD_LDS(double)* chainv = rhdr + kRing * kSlotHdr;                          // b, g_sum_intercept, w_scale at the epoch end, spare
+  SGD_LDS(double)* hist_g = chainv + 4;                                       // [kWave]
+  volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(hist_g + kWave);   // [kK1mCtrl]
+  volatile SGD_LDS(unsigned long long)* readslot = ctrl + kK1mCtrl;           // [kRing]: slot u % kRing was read for draw u
+  volatile SGD_LDS(unsigned long long)* done_slot = readslot + kRing;         // [kWave]: draw u complete -> [u % 64] = u + 1
+  SGD_LDS(int)* ridx = (SGD_LDS(int)*)(done_slot + kWave);                    // [kRing][kWave]
+  SGD_LDS(unsigned)* hist_s = (SGD_LDS(unsigned)*)(ridx + kRing * kWave);     // [kWave]
+  SGD_LDS(unsigned)* lastw = hist_s + kWave;                                  // [kDepSlots]
+  SGD_LDS(double)* sls = (SGD_LDS(double)*)(lastw + kDepSlots);               // [L]
+  double* w = d.w;
+  double* G = d.G;
+  unsigned* lag = d.lag;
+  const unsigned nit = (unsigned)ctl.nit;
+  const double* LS = ctl.LS;
+  for (unsigned i = tid; i < L; i += T) sls[i] = LS[i];
+  for (int i = tid; i < 128; i += T) sexp[i] = SGD_EXP_TABPTR[i];
+  for (int i = tid; i < kDepSlots; i += T) lastw[i] = 0u;
+  for (int i = tid; i < kCons * kK1Sum; i += T) sx_all[i] = 0.0;
+  if (tid < kK1mCtrl) ctrl[tid] = 0ull;
+  if (tid < kRing) readslot[tid] = 0ull;
+  if (tid < kWave) {
+    done_slot[tid] = 0ull;
+    hist_s[tid] = 0xffffffffu;
+    hist_g[tid] = 0.0;
+  }
+  if (tid == 0) {
+    chainv[0] = d.b[0];
+    chainv[1] = d.gb[0];
+    chainv[2] = 1.0;
+  }
+  for (int64_t j = tid; j < p; j += T) lag[j] = 0u;                   // saga-sparse.h:225
+  for (int64_t i = tid; i < p; i += T) d.w_prev[i] = w[i];            // :251
+  __syncthreads();                                                    // the last barrier all wavefronts meet
+
+  const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
+  const double wscale_update = 1.0 - alpha * gamma;                  // :234
+  const double bg = beta * gamma;                                    // penalties.h:49: beta * gamma * scaling / w_scale
+  const double ls_one = 1u < L ? sls[1] : LS[1];                     // the SAGA step always lags by one
+  const double bg_ls1 = bg * ls_one;
+  const int64_t total = (int64_t)ctl.max_epochs * nit;               // draws of this launch, unless it converges first
+  const int64_t t_last = ctl.stream_off + total - 1;
+  // waits: true when the condition came true, false when the launch is being abandoned
+  auto aborted = [&]() -> bool { return ctrl_load(ctrl + 3) != 0ull; };
+  auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* c, unsigned long long target) -> bool {
+    unsigned spins = 0;
+    while (ctrl_load(c) < target) {
+      if ((spins & 15u) == 15u && aborted()) return false;
+      if (++spins > kK1xSpinLimit) {
+        if (lane == 0) ctrl[3] = 2ull;
+        return false;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+  };
+
+  if (wave == kCons) {
+    // ================================ producer ================================
+    auto stream_at = [&](int64_t u) -> uint32_t {
+      const int64_t x = ctl.stream_off + u;
+      return d.stream[x < t_last ? x : t_last];
+    };
+    const bool gl = lane < 16;
+    uint32_t sv = gl ? stream_at(lane) : 0u, sv_n = gl ? stream_at(16 + lane) : 0u;
+    int64_t pa = 0, pe = 0;
+    double yv = 0.0, mv = 0.0;
+    if (gl) {
+      pa = d.ptr[sv];
+      pe = d.ptr[sv + 1];
+      yv = d.y[sv];
+      mv = d.M[sv];
+    }
+    double W = 1.0;                    // w_scale before the first draw of the batch in hand
+    unsigned itp = 0;
+    bool stop = false;
+    for (int64_t ub = 0; ub <= total && !stop; ub += 16) {
+      const uint32_t sv_nn = gl ? stream_at(ub + 32 + lane) : 0u;
+      int64_t pa_n = 0, pe_n = 0;
+      double yv_n = 0.0, mv_n = 0.0;
+      if (gl) {
+        pa_n = d.ptr[sv_n];
+        pe_n = d.ptr[sv_n + 1];
+        yv_n = d.y[sv_n];
+        mv_n = __hip_atomic_load(d.M + sv_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // the data-independent numbers of the sixteen draws at once: lane l works for draw l % 16; lanes 0..15 divide
+      // gamma by w_scale before the draw, 16..31 gamma by w_scale after it, 32..47 the SAGA step's threshold
+      const int di = lane & 15;
+      double Wb = W, Wa = W;           // before / after draw di
+      unsigned itq = itp;
+      double Wnext = W;
+      unsigned itnext = itp;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        // (no reset inside an epoch here: the host sends such lambdas to the two-wavefront kernel)
+        const double before = Wnext;
+        const double after = before * wscale_update;
+        if (q == di) {
+          Wb = before;
+          Wa = after;
+        }
+        Wnext = after;
+        if (++itnext == nit) {                                     // Reset(n_samples) :340-348 leaves w_scale = 1
+          itnext = 0;
+          Wnext = 1.0;
+        }
+      }
+      (void)itq;
+      const int kind = lane >> 4;
+      const double quot = (kind == 2 ? bg_ls1 : gamma) / (kind == 0 ? Wb : Wa);
+      for (int i0 = 0; i0 < 16 && !stop; i0 += 4) {
+        int idx4[4];
+        double val4[4];
+        int64_t a4[4], e4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          a4[j] = readlane_ll(pa, i0 + j);
+          e4[j] = readlane_ll(pe, i0 + j);
+          idx4[j] = 0;
+          val4[j] = 0.0;
+          if (a4[j] + lane < e4[j]) {
+            idx4[j] = d.idx[a4[j] + lane];
+            val4[j] = d.val[a4[j] + lane];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t u = ub + i0 + j;
+          if (u > total || stop) break;
+          const int slot = (int)(u & (kRing - 1));
+          if (u >= kRing && !wait_ge(readslot + slot, (unsigned long long)(u - kRing + 1))) {
+            stop = true;
+            break;
+          }
+          const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)sv, i0 + j);
+          const double y_u = readlane_d(yv, i0 + j), m_u = readlane_d(mv, i0 + j);
+          const int64_t rlen = e4[j] - a4[j];
+          const int len_u = (int)(rlen < (int64_t)(kWave + 1) ? rlen : (int64_t)(kWave + 1));
+          const double W_u = readlane_d(Wb, i0 + j), Wp_u = readlane_d(Wa, i0 + j);
+          const double qp_u = readlane_d(quot, i0 + j), qt_u = readlane_d(quot, 16 + i0 + j),
+                       tau1_u = readlane_d(quot, 32 + i0 + j);
+          ridx[slot * kWave + lane] = idx4[j];
+          rval[slot * kWave + lane] = val4[j];
+          double hv = __longlong_as_double(((long long)len_u << 32) | (long long)s_u);
+          hv = lane == 1 ? __longlong_as_double(a4[j]) : hv;
+          hv = lane == 2 ? y_u : hv;
+          hv = lane == 3 ? m_u : hv;
+          hv = lane == 4 ? W_u : hv;
+          hv = lane == 5 ? Wp_u : hv;
+          hv = lane == 6 ? qp_u : hv;
+          hv = lane == 7 ? qt_u : hv;
+          hv = lane == 8 ? tau1_u : hv;
+          hv = lane == 9 ? __longlong_as_double(e4[j]) : hv;
+          if (lane < kSlotHdr) rhdr[slot * kSlotHdr + lane] = hv;
+          lanes_publish();
+          if (lane == 0) ctrl[0] = (unsigned long long)(u + 1);
+        }
+      }
+      W = Wnext;
+      itp = itnext;
+      sv = sv_n;
+      sv_n = sv_nn;
+      pa = pa_n;
+      pe = pe_n;
+      yv = yv_n;
+      mv = mv_n;
+    }
+    return;
+  }
+
+  // ================================ consumers ================================
+  const int c = wave;
+  SGD_LDS(double)* sx = sx_all + c * kK1Sum;
+  auto ls_at = [&](unsigned m) -> double {
+    double v = sls[m < L ? m : 0u];
+    if (m >= L) v = LS[m];
+    return v;
+  };
+  const int penalty = lamp->penalty;
+  const bool group = penalty == SGDNET_GROUPLASSO;
+  const bool l1 = penalty == SGDNET_ELASTICNET;
+  const bool plain_soft = !(wscale_update > 0.0 && bg >= 0.0);
+  const int family = d.family;
+  const bool fit_intercept = d.fit_intercept != 0;
+  const double n_d = d.n_total, rn_d = 1.0 / n_d;
+  const double g_scale = 1.0 / n_d;
+  unsigned long long bar_target = 0ull;
+  bool ok = true;
+  // a barrier of the consumers (the producer does not take part)
+  auto consumers_meet = [&]() {
+    lanes_publish();
+    bar_target += kCons;
+    if (lane == 0) __hip_atomic_fetch_add((SGD_LDS(unsigned long long)*)(ctrl + 4), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ok) ok = wait_ge(ctrl + 4, bar_target);
+    lanes_publish();
+  };
+
+  unsigned it_outer = 0;
+  int converged = 0;
+  int64_t base = 0;                   // draws before this epoch
+  int64_t u_prev = -1;                // my last draw whose completion is not published yet
+  do {
+    for (unsigned it = (unsigned)c; it < nit && ok; it += kCons) {
+      const int64_t u = base + it;
+      // ---- the slot ----
+      if (!(ok = wait_ge(ctrl + 0, (unsigned long long)(u + 1)))) break;
+      const int slot = (int)(u & (kRing - 1));
+      lanes_publish();
+      const int idx_c = ridx[slot * kWave + lane];
+      const double val_c = rval[slot * kWave + lane];
+      const SGD_LDS(double)* h = rhdr + slot * kSlotHdr;
+      const long long sl = __double_as_longlong(h[0]);
+      const double y_c = h[2];
+      double m_c = h[3];
+      const double W = h[4], Wp = h[5], q_prev = h[6], q_t = h[7], tau1_t = h[8];
+      lanes_publish();
+      if (lane == 0) readslot[slot] = (unsigned long long)(u + 1);
+      const uint32_t s = (uint32_t)(sl & 0xffffffffll);             // :261
+      const int len = (int)(sl >> 32);
+      const bool mine = lane < len;                                  // (rows of at most 64 entries only: the host's rule)
+      // ---- registration, in draw order ----
+      if (!(ok = wait_ge(ctrl + 1, (unsigned long long)u))) break;
+      const int hsl = idx_c & (kDepSlots - 1);
+      const unsigned prev = mine ? lastw[hsl] : 0u;
+      lanes_publish();
+      if (mine) lastw[hsl] = it + 1u;
+      lanes_publish();
+      if (lane == 0) ctrl[1] = (unsigned long long)(u + 1);
+      // ---- my previous draw is complete once its stores are acknowledged ----
+      wave_mem_sync();
+      if (u_prev >= 0 && lane == 0) done_slot[u_prev & (kWave - 1)] = (unsigned long long)(u_prev + 1);
+      // ---- draws in flight that hold one of my features ----
+      {
+        unsigned need = prev;
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned o = (unsigned)__shfl_xor((int)need, off, kWave);
+          need = o > need ? o : need;
+        }
+        need = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+        if (need != 0u) {
+          const unsigned v_it = need - 1u;                           // the latest earlier draw sharing a feature (or a hash slot)
+          const unsigned lo = it + 1u > (unsigned)kCons ? it + 1u - (unsigned)kCons : 0u;
+          for (unsigned dd = lo; dd <= v_it && dd < it && ok; ++dd)
+            ok = wait_ge(done_slot + ((base + dd) & (kWave - 1)), (unsigned long long)(base + dd + 1));
+          if (!ok) break;
+        }
+      }
+      // ---- w / g_sum / lag of my features (past the L1: other wavefronts of this CU wrote them) ----
+      double wj = 0.0, Gj = 0.0;
+      unsigned lag0 = it;
+      if (mine) {
+        wj = __hip_atomic_load(w + idx_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Gj = __hip_atomic_load(G + idx_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lag0 = __hip_atomic_load(lag + idx_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // LaggedUpdate(it_inner): catch-up of the sample's features  :263-272
+      const unsigned lagged = it - lag0;
+      if (mine && lagged != 0u) {
+        const double lsc0 = ls_at(lagged);
+        if (group) {
+          penalty_apply_q(penalty, 1, &wj, &Gj, W, lsc0, q_prev, gamma, beta);
+        } else {
+          const double f = q_prev * lsc0;
+          const double v = wj - f * Gj;
+          wj = l1 ? k1_soft(v, bg * lsc0 / W, plain_soft) : v;
+        }
+      }
+      // linear predictor, ascending feature order  :274
+      sx[lane] = mine ? val_c * wj : 0.0;
+      lanes_publish();
+      double acc = 0.0;
+      {
+        double pr[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pr[e] = sx[e];
+        for (int eb = 0;;) {
+#pragma unroll
+          for (int blk = 0; blk < 4; ++blk) {
+            if (eb + 4 * blk < len) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc += pr[4 * blk + e];
+            }
+          }
+          eb += 16;
+          if (eb >= len) break;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) pr[e] = sx[eb + e];
+        }
+      }
+      // ---- the chain, in draw order ----
+      if (!(ok = wait_ge(ctrl + 2, (unsigned long long)u))) break;
+      lanes_publish();
+      double b = chainv[0], gb = chainv[1];
+      const int r0 = (int)(u & (kWave - 1));
+      {
+        const unsigned hs = hist_s[lane];
+        const double hg = hist_g[lane];
+        const unsigned long long mask = __ballot(hs == s);
+        if (mask != 0ull) {
+          const unsigned long long rot = r0 ? ((mask >> r0) | (mask << (kWave - r0))) : mask;   // bit k: lane (k + r0) % 64, age 64 - k
+          const int kk = 63 - __builtin_clzll(rot);
+          m_c = readlane_d(hg, (kk + r0) & (kWave - 1));
+        }
+      }
+      const double lp = acc * W + b;
+      double g;                                                      // :279-282
+      if (family == SGDNET_BINOMIAL)
+        g = 1.0 - y_c - 1.0 / (1.0 + sgd_exp_lds(lp, sexp));
+      else
+        g = lp - y_c;
+      const double gc = g - m_c;
+      if (fit_intercept) {                                           // :300-304
+        const double gck = div_by_n_exact(gc, n_d, rn_d);
+        gb = gb + gck;
+        b -= gamma * (gb * 0.01 + gck);
+      }
+      if (lane == 0) {
+        chainv[0] = b;
+        chainv[1] = gb;
+        if (it + 1u == nit) chainv[2] = Wp;                          // w_scale as Reset finds it
+        hist_s[r0] = s;
+        hist_g[r0] = g;
+      }
+      lanes_publish();
+      if (lane == 0) ctrl[2] = (unsigned long long)(u + 1);
+      // ---- the rest of the draw ----
+      if (lane == 0) d.M[s] = g;
+      if (mine) {
+        wj += val_c * gc * (-q_t);                                   // AddWeighted(w, ..., -gamma/wscale)  :306-313
+        if (group) {                                                 // LaggedUpdate(it_inner + 1)  :316-325
+          penalty_apply_q(penalty, 1, &wj, &Gj, Wp, ls_one, q_t, gamma, beta);
+        } else {
+          const double f = q_t * ls_one;
+          const double v = wj - f * Gj;
+          wj = l1 ? k1_soft(v, tau1_t, plain_soft) : v;
+        }
+        Gj += val_c * gc * g_scale;                                  // AddWeighted(g_sum, ..., 1/n)  :328-335
+        w[idx_c] = wj;
+        G[idx_c] = Gj;
+        lag[idx_c] = it + 1u;
+      }
+      u_prev = u;
+    }
+    // my last draw of the epoch
+    wave_mem_sync();
+    if (u_prev >= 0 && lane == 0) done_slot[u_prev & (kWave - 1)] = (unsigned long long)(u_prev + 1);
+    u_prev = -1;
+    consumers_meet();                                                // every draw of the epoch is in memory
+    if (!ok) break;
+    // Reset(n_samples): unlag and rescale  :340-348 (features dealt round robin to the consumers)
+    {
+      const double W_end = chainv[2];
+      for (int64_t j = (int64_t)c * kWave + lane; j < p; j += kCons * kWave) {
+        double wv = __hip_atomic_load(w + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double Gv = __hip_atomic_load(G + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned lagged = nit - __hip_atomic_load(lag + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lagged != 0u) penalty_apply(penalty, 1, &wv, &Gv, W_end, ls_at(lagged), gamma, beta);
+        w[j] = wv * W_end;
+        lag[j] = 0u;
+      }
+      for (int i = c * kWave + lane; i < kDepSlots; i += kCons * kWave) lastw[i] = 0u;
+    }
+    wave_mem_sync();
+    consumers_meet();
+    if (!ok) break;
+    ++it_outer;
+    if (c == 0) {
+      // ConvergenceCheck  :367 (w as the other consumers left it: past the L1)
+      double max_change = 0.0, max_size = 0.0;
+      bool finite = true;
+      for (int64_t i = lane; i < p; i += kWave) {
+        const double v = __hip_atomic_load(w + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        finite = finite && (fabs(v) <= 1.79769313486231570815e+308);
+        max_change = fmax(max_change, fabs(v - d.w_prev[i]));
+        max_size = fmax(max_size, fabs(v));
+        d.w_prev[i] = v;
+      }
+      int conv = 0;
+      if (__ballot(!finite) == 0ull) {
+        max_change = wave_max(max_change);
+        max_size = wave_max(max_size);
+        const bool all_zero = (max_size == 0.0) && (max_change == 0.0);
+        const bool no_change = (max_size != 0.0) && (max_change / max_size <= ctl.tol);
+        conv = (all_zero || no_change) ? 1 : 0;
+      }
+      if (lane == 0) ctrl[5] = (unsigned long long)conv;
+    }
+    consumers_meet();
+    if (!ok) break;
+    converged = (int)ctrl_load(ctrl + 5);
+    base += nit;
+  } while (!converged && it_outer < ctl.max_epochs);                 // :371
+  if (lane == 0 && ctrl_load(ctrl + 3) == 0ull) ctrl[3] = 1ull;       // the producer may be waiting for a free slot
+
+  if (c == 0 && lane == 0) {
+    d.b[0] = chainv[0];
+    d.gb[0] = chainv[1];
+    ctl.out[0] = (int)it_outer;
+    ctl.out[1] = (!ok || ctrl_load(ctrl + 3) == 2ull) ? -2 : converged;
+  }
+}
+
+// --------------------------------------------------------------------------
 // Dense variant: no lag, all-feature penalty every iteration (saga-dense.h:179-180),
 // intercept without the 0.01 decay (:170-173).  Lanes stride the features for
 // the three O(pK) passes; lane k owns class k.
@@ -1918,6 +2358,45 @@ static int launch_k1_t(Kern kern, int threads, const SagaDev& d, const LamParams
 int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st) {
   return ctl.use_lds ? launch_k1_t(saga_sparse_exact_k1x_kernel<true>, 2 * kWave, d, lam, ctl, lds_bytes, st)
                      : launch_k1_t(saga_sparse_exact_k1x_kernel<false>, 2 * kWave, d, lam, ctl, lds_bytes, st);
+}
+
+// The multi-consumer kernel: LDS = its fixed part + the lag_scaling cache (w, g_sum, lag stay in memory).
+size_t sparse_exact_k1m_lds_bytes(int64_t nit, int* ls_cache) {
+  const size_t cap = 160 * 1024 - 256 - kK1mFixedLds;
+  size_t entries = cap / sizeof(double);
+  if (entries > (size_t)nit + 1) entries = (size_t)nit + 1;
+  *ls_cache = (int)entries;
+  return (kK1mFixedLds + sizeof(double) * entries + 15) & ~size_t(15);
+}
+
+int sparse_exact_k1m_consumers() { return kCons; }
+
+int launch_sparse_exact_k1m(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st) {
+  return launch_k1_t(saga_sparse_exact_k1m_kernel, (kCons + 1) * kWave, d, lam, ctl, lds_bytes, st);
+}
+
+// longest row of the sample-major matrix (the register-resident kernels hold a row in one wavefront)
+__global__ void row_max_kernel(const int64_t* ptr, int64_t n, int* out) {
+  int m = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t len = ptr[i + 1] - ptr[i];
+    const int l = len > 0x7fffffff ? 0x7fffffff : (int)len;
+    m = l > m ? l : m;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(m, off, kWave);
+    m = o > m ? o : m;
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
+}
+
+int launch_row_max(const int64_t* ptr, int64_t n, int* out_dev, hipStream_t st) {
+  SGD_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(int), st));
+  int grid = (int)((n + 255) / 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(row_max_kernel, dim3(grid), dim3(256), 0, st, ptr, n, out_dev);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
 }
 
 int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,

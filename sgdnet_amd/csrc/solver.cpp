@@ -86,6 +86,7 @@ struct sgdnet_solver {
     int64_t run_len = 0;   // virtual shards: draws per run of the layout (0: one run = the epoch)
   } pipe;
   int64_t nnz = 0;
+  int row_max = -1;             // longest row of sparse x (found on the device when an exact run first asks)
   bool penalty_set = false;
   // cached epoch graph
   // captured epochs, one per (batch, draws) shape; gexec is the one selected by ensure_graph
@@ -778,7 +779,7 @@ struct OptionDef {
 };
 const OptionDef kOptionDefs[sgdnet::kOptCount] = {
     {"virtual_shards", -1, -1, 8}, {"rng_generators", 0, 0, 64},     {"window_eigenvalue", 1, 0, 1},
-    {"host_setup", 0, 0, 1},       {"exact_epoch_blocks", 1, 0, 1}, {"exact_row_registers", 1, 0, 2},
+    {"host_setup", 0, 0, 1},       {"exact_epoch_blocks", 1, 0, 1}, {"exact_row_registers", 1, 0, 4},
 };
 std::atomic<int> g_options[sgdnet::kOptCount] = {{-1}, {0}, {1}, {0}, {1}, {1}};
 int find_option(const char* name) {
@@ -1436,11 +1437,35 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     static const int wide_ok = exp_env_int("SGDNET_EXACT_WIDE", 1);
     const bool wide = !s->sparse && !lds_small && wide_ok && dense_exact_wide_threads(s->d) > 0;
     // sparse x, one response, no implicit centring: the register-resident iteration (option exact_row_registers:
-    // 0 keeps the general kernel; 2 keeps w, g_sum and lag out of the LDS even where they fit)
+    // 0 keeps the general kernel; 2 keeps w, g_sum and lag out of the LDS even where they fit; 4: as 1 without the
+    // multi-consumer kernel)
     const int k1_opt = option(kOptExactRowRegisters);
     const bool k1 = s->sparse && k1_opt != 0 && sparse_exact_k1_eligible(s->d);
     int k1_cache = 0, k1_stage = 0;
-    const size_t k1_lds = k1 ? sparse_exact_k1_lds_bytes(s->d, draws_per_epoch, k1_opt == 1, &k1_cache, &k1_stage) : 0;
+    size_t k1_lds = k1 ? sparse_exact_k1_lds_bytes(s->d, draws_per_epoch, k1_opt == 1 || k1_opt == 4, &k1_cache, &k1_stage) : 0;
+    // ... and with several consumer wavefronts where draws seldom share a feature (1: where the rule below expects it
+    // to pay; 3: wherever it is legal; 2, 4: never).  Legal: every row fits a wavefront and w_scale cannot fall below
+    // SMALL inside an epoch (the producer forms its sequence without the reset of saga-sparse.h:285-295).
+    bool k1m = false;
+    if (k1 && (k1_opt == 1 || k1_opt == 3)) {
+      if (s->row_max < 0) {
+        rc = launch_row_max(s->d.ptr, s->d.n, s->out_dev, s->st);
+        if (rc) return rc;
+        int rm = 0;
+        SGD_HIP_TRY(hipMemcpyAsync(&rm, s->out_dev, sizeof(int), hipMemcpyDeviceToHost, s->st));
+        SGD_HIP_TRY(hipStreamSynchronize(s->st));
+        s->row_max = rm;
+      }
+      const double upd = 1.0 - s->lam.alpha * s->lam.gamma;
+      const bool may_reset = !(upd > 0.0) || (double)draws_per_epoch * std::log(upd) < -30.0;   // SMALL = e^-31.4
+      const double avg = (double)s->nnz / (double)s->d.n;
+      const double share = (double)(sparse_exact_k1m_consumers() - 1) * avg * avg / (double)s->d.p;   // P(a draw in flight shares a feature)
+      k1m = s->row_max <= 64 && !may_reset && draws_per_epoch >= 64 && (k1_opt == 3 || share < 0.25);
+      if (k1m) {
+        k1_lds = sparse_exact_k1m_lds_bytes(draws_per_epoch, &k1_cache);
+        k1_stage = 0;
+      }
+    }
     const size_t lds_full = s->sparse ? sparse_exact_lds_bytes(s->d, true)
                                       : (wide ? dense_exact_wide_lds_bytes(s->d, true) : dense_exact_lds_bytes(s->d, true));
     const bool stage = lds_full <= lds_cap;
@@ -1472,7 +1497,8 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         ctl.use_lds = k1_stage;
         ctl.ls_cache = k1_cache;
       }
-      rc = k1 ? launch_sparse_exact_k1(s->d, s->lam_dev, ctl, k1_lds, s->st)
+      rc = k1m ? launch_sparse_exact_k1m(s->d, s->lam_dev, ctl, k1_lds, s->st)
+         : k1 ? launch_sparse_exact_k1(s->d, s->lam_dev, ctl, k1_lds, s->st)
          : s->sparse ? launch_sparse_exact(s->d, s->lam_dev, ctl, lds, s->st)
                      : (lds_small ? launch_dense_exact_small(s->d, s->lam.penalty, s->lam_dev, ctl, lds_small, s->st)
                         : wide    ? launch_dense_exact_wide(s->d, s->lam_dev, ctl, lds, s->st)

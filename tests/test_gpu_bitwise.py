@@ -98,7 +98,7 @@ ROW_REGISTER_CASES = {
 
 
 @pytest.mark.parametrize("case", sorted(ROW_REGISTER_CASES))
-@pytest.mark.parametrize("registers", [0, 1, 2])
+@pytest.mark.parametrize("registers", [0, 1, 2, 3, 4])
 def test_register_resident_sparse_kernel_is_bit_identical(sa, det, case, registers):
     """Round 3: `saga_sparse_exact_k1_kernel` (one response: the row's lanes keep w, g_sum and lag of their features
     in registers for the whole draw, the state of the next draw is requested a draw ahead and forwarded where two
@@ -118,7 +118,7 @@ def test_register_resident_sparse_kernel_is_bit_identical(sa, det, case, registe
         assert np.array_equal(got[2][name], ref[2][name]), name
 
 
-@pytest.mark.parametrize("registers", [0, 1, 2])
+@pytest.mark.parametrize("registers", [0, 1, 2, 3, 4])
 def test_register_resident_kernel_with_repeated_draws_and_early_stop(sa, det, registers):
     # the same sample drawn several times in a row (its gradient memory and every feature are forwarded), and a
     # tolerance that stops the launch inside its block of epochs
