@@ -1050,20 +1050,28 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
 // inside an epoch take the two-wavefront kernel above (the host decides: sparse_exact_k1m_eligible).
 // Every wait loop gives up after kK1xSpinLimit polls or when another wavefront has raised the abort flag.
 // --------------------------------------------------------------------------
-constexpr int kCons = 6;
+#ifndef K1M_CONS
+#define K1M_CONS 6
+#endif
+#ifndef K1M_ROWS
+#define K1M_ROWS 4
+#endif
+constexpr int kCons = K1M_CONS;
+constexpr int kProd = 2;               // producer wavefronts: draw i of a batch of sixteen belongs to producer i % kProd
+constexpr int kProdRows = K1M_ROWS;    // rows the producer keeps in flight
 constexpr int kDepSlots = 16384;
 constexpr int kK1mCtrl = 8;         // produced, registered, chain_done, stop/abort, barrier count, converged, epochs, spare
 constexpr size_t kK1mFixedLds = sizeof(double) * ((size_t)kCons * kK1Sum + 128 + kRing * (kWave + kSlotHdr) + 4 + kWave) +
-                                sizeof(unsigned long long) * (kK1mCtrl + kRing + kWave) +
+                                sizeof(unsigned long long) * (kK1mCtrl + 2 * kRing + kWave) +
                                 sizeof(int) * (kRing * kWave) + sizeof(unsigned) * (kWave + kDepSlots);
 
-__global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_kernel(SagaDev d, const LamParams* lamp,
+__global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m_kernel(SagaDev d, const LamParams* lamp,
                                                                                     ExactCtl ctl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  constexpr int T = (kCons + 1) * kWave;
+  constexpr int T = (kCons + kProd) * kWave;
   const int64_t p = d.p;
   const unsigned L = (unsigned)ctl.ls_cache;
   SGD_LDS(double)* sx_all = (SGD_LDS(double)*)smem;                           // [kCons][kK1Sum]
@@ -1074,7 +1082,8 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
   SGD_LDS(double)* hist_g = chainv + 4;                                       // [kWave]
   volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(hist_g + kWave);   // [kK1mCtrl]
   volatile SGD_LDS(unsigned long long)* readslot = ctrl + kK1mCtrl;           // [kRing]: slot u % kRing was read for draw u
-  volatile SGD_LDS(unsigned long long)* done_slot = readslot + kRing;         // [kWave]: draw u complete -> [u % 64] = u + 1
+  volatile SGD_LDS(unsigned long long)* filled = readslot + kRing;            // [kRing]: slot u % kRing holds draw u
+  volatile SGD_LDS(unsigned long long)* done_slot = filled + kRing;           // [kWave]: draw u complete -> [u % 64] = u + 1
   SGD_LDS(int)* ridx = (SGD_LDS(int)*)(done_slot + kWave);                    // [kRing][kWave]
   SGD_LDS(unsigned)* hist_s = (SGD_LDS(unsigned)*)(ridx + kRing * kWave);     // [kWave]
   SGD_LDS(unsigned)* lastw = hist_s + kWave;                                  // [kDepSlots]
@@ -1089,7 +1098,10 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
   for (int i = tid; i < kDepSlots; i += T) lastw[i] = 0u;
   for (int i = tid; i < kCons * kK1Sum; i += T) sx_all[i] = 0.0;
   if (tid < kK1mCtrl) ctrl[tid] = 0ull;
-  if (tid < kRing) readslot[tid] = 0ull;
+  if (tid < kRing) {
+    readslot[tid] = 0ull;
+    filled[tid] = 0ull;
+  }
   if (tid < kWave) {
     done_slot[tid] = 0ull;
     hist_s[tid] = 0xffffffffu;
@@ -1113,9 +1125,14 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
   const int64_t t_last = ctl.stream_off + total - 1;
   // waits: true when the condition came true, false when the launch is being abandoned
   auto aborted = [&]() -> bool { return ctrl_load(ctrl + 3) != 0ull; };
+  unsigned long long spin_count[5] = {0, 0, 0, 0, 0};   // slot, registration, dependency, chain, barrier (phase-timing builds report them)
+  int spin_kind = 0;
   auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* c, unsigned long long target) -> bool {
     unsigned spins = 0;
     while (ctrl_load(c) < target) {
+#ifdef SGDNET_PHASE_TIMING
+      ++spin_count[spin_kind];
+#endif
       if ((spins & 15u) == 15u && aborted()) return false;
       if (++spins > kK1xSpinLimit) {
         if (lane == 0) ctrl[3] = 2ull;
@@ -1126,14 +1143,20 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
     return true;
   };
 
-  if (wave == kCons) {
-    // ================================ producer ================================
+  if (wave >= kCons) {
+    // ================================ producers ================================
+    // kProd of them: draw i of every batch of sixteen belongs to producer i % kProd, which gathers its 16 / kProd stream
+    // entries, row pointers, responses and gradient memories one per lane, keeps kProdRows rows in flight and fills
+    // its slots as the consumers free them.  Both run the whole w_scale sequence (sixteen multiplications a batch).
+    const int q = wave - kCons;
+    constexpr int kOwn = 16 / kProd;                                  // my draws per batch
     auto stream_at = [&](int64_t u) -> uint32_t {
       const int64_t x = ctl.stream_off + u;
       return d.stream[x < t_last ? x : t_last];
     };
-    const bool gl = lane < 16;
-    uint32_t sv = gl ? stream_at(lane) : 0u, sv_n = gl ? stream_at(16 + lane) : 0u;
+    const bool gl = lane < kOwn;
+    const int mine_i = (lane & (kOwn - 1)) * kProd + q;               // my lane's draw inside a batch
+    uint32_t sv = gl ? stream_at(mine_i) : 0u, sv_n = gl ? stream_at(16 + mine_i) : 0u;
     int64_t pa = 0, pe = 0;
     double yv = 0.0, mv = 0.0;
     if (gl) {
@@ -1145,29 +1168,28 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
     double W = 1.0;                    // w_scale before the first draw of the batch in hand
     unsigned itp = 0;
     bool stop = false;
-    for (int64_t ub = 0; ub <= total && !stop; ub += 16) {
-      const uint32_t sv_nn = gl ? stream_at(ub + 32 + lane) : 0u;
+    for (int64_t ub = 0; ub < total && !stop; ub += 16) {
+      const uint32_t sv_nn = gl ? stream_at(ub + 32 + mine_i) : 0u;
       int64_t pa_n = 0, pe_n = 0;
       double yv_n = 0.0, mv_n = 0.0;
       if (gl) {
         pa_n = d.ptr[sv_n];
         pe_n = d.ptr[sv_n + 1];
         yv_n = d.y[sv_n];
+        // (the consumers' stores of draws more than 64 back are long in L2; read past this CU's L1)
         mv_n = __hip_atomic_load(d.M + sv_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // the data-independent numbers of the sixteen draws at once: lane l works for draw l % 16; lanes 0..15 divide
-      // gamma by w_scale before the draw, 16..31 gamma by w_scale after it, 32..47 the SAGA step's threshold
-      const int di = lane & 15;
-      double Wb = W, Wa = W;           // before / after draw di
-      unsigned itq = itp;
+      // the data-independent numbers of my draws at once: lane l works for my draw l % kOwn; lanes [0, kOwn) divide
+      // gamma by w_scale before the draw, [kOwn, 2 kOwn) gamma by w_scale after it, [2 kOwn, 3 kOwn) the SAGA
+      // step's threshold by the latter (no reset inside an epoch here: the host sends such lambdas elsewhere)
+      double Wb = W, Wa = W;
       double Wnext = W;
       unsigned itnext = itp;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        // (no reset inside an epoch here: the host sends such lambdas to the two-wavefront kernel)
+      for (int t16 = 0; t16 < 16; ++t16) {
         const double before = Wnext;
         const double after = before * wscale_update;
-        if (q == di) {
+        if (t16 == mine_i) {
           Wb = before;
           Wa = after;
         }
@@ -1177,17 +1199,16 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
           Wnext = 1.0;
         }
       }
-      (void)itq;
-      const int kind = lane >> 4;
+      const int kind = lane / kOwn;
       const double quot = (kind == 2 ? bg_ls1 : gamma) / (kind == 0 ? Wb : Wa);
-      for (int i0 = 0; i0 < 16 && !stop; i0 += 4) {
-        int idx4[4];
-        double val4[4];
-        int64_t a4[4], e4[4];
+      for (int l0 = 0; l0 < kOwn && !stop; l0 += kProdRows) {
+        int idx4[kProdRows];
+        double val4[kProdRows];
+        int64_t a4[kProdRows], e4[kProdRows];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          a4[j] = readlane_ll(pa, i0 + j);
-          e4[j] = readlane_ll(pe, i0 + j);
+        for (int j = 0; j < kProdRows; ++j) {
+          a4[j] = readlane_ll(pa, l0 + j);
+          e4[j] = readlane_ll(pe, l0 + j);
           idx4[j] = 0;
           val4[j] = 0.0;
           if (a4[j] + lane < e4[j]) {
@@ -1196,21 +1217,21 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
           }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int64_t u = ub + i0 + j;
-          if (u > total || stop) break;
+        for (int j = 0; j < kProdRows; ++j) {
+          const int64_t u = ub + (int64_t)(l0 + j) * kProd + q;
+          if (u >= total || stop) break;
           const int slot = (int)(u & (kRing - 1));
           if (u >= kRing && !wait_ge(readslot + slot, (unsigned long long)(u - kRing + 1))) {
             stop = true;
             break;
           }
-          const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)sv, i0 + j);
-          const double y_u = readlane_d(yv, i0 + j), m_u = readlane_d(mv, i0 + j);
+          const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)sv, l0 + j);
+          const double y_u = readlane_d(yv, l0 + j), m_u = readlane_d(mv, l0 + j);
           const int64_t rlen = e4[j] - a4[j];
           const int len_u = (int)(rlen < (int64_t)(kWave + 1) ? rlen : (int64_t)(kWave + 1));
-          const double W_u = readlane_d(Wb, i0 + j), Wp_u = readlane_d(Wa, i0 + j);
-          const double qp_u = readlane_d(quot, i0 + j), qt_u = readlane_d(quot, 16 + i0 + j),
-                       tau1_u = readlane_d(quot, 32 + i0 + j);
+          const double W_u = readlane_d(Wb, l0 + j), Wp_u = readlane_d(Wa, l0 + j);
+          const double qp_u = readlane_d(quot, l0 + j), qt_u = readlane_d(quot, kOwn + l0 + j),
+                       tau1_u = readlane_d(quot, 2 * kOwn + l0 + j);
           ridx[slot * kWave + lane] = idx4[j];
           rval[slot * kWave + lane] = val4[j];
           double hv = __longlong_as_double(((long long)len_u << 32) | (long long)s_u);
@@ -1225,7 +1246,7 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
           hv = lane == 9 ? __longlong_as_double(e4[j]) : hv;
           if (lane < kSlotHdr) rhdr[slot * kSlotHdr + lane] = hv;
           lanes_publish();
-          if (lane == 0) ctrl[0] = (unsigned long long)(u + 1);
+          if (lane == 0) filled[slot] = (unsigned long long)(u + 1);
         }
       }
       W = Wnext;
@@ -1263,6 +1284,7 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
     lanes_publish();
     bar_target += kCons;
     if (lane == 0) __hip_atomic_fetch_add((SGD_LDS(unsigned long long)*)(ctrl + 4), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    spin_kind = 4;
     if (ok) ok = wait_ge(ctrl + 4, bar_target);
     lanes_publish();
   };
@@ -1275,8 +1297,9 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
     for (unsigned it = (unsigned)c; it < nit && ok; it += kCons) {
       const int64_t u = base + it;
       // ---- the slot ----
-      if (!(ok = wait_ge(ctrl + 0, (unsigned long long)(u + 1)))) break;
+      spin_kind = 0;
       const int slot = (int)(u & (kRing - 1));
+      if (!(ok = wait_ge(filled + slot, (unsigned long long)(u + 1)))) break;
       lanes_publish();
       const int idx_c = ridx[slot * kWave + lane];
       const double val_c = rval[slot * kWave + lane];
@@ -1291,6 +1314,7 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
       const int len = (int)(sl >> 32);
       const bool mine = lane < len;                                  // (rows of at most 64 entries only: the host's rule)
       // ---- registration, in draw order ----
+      spin_kind = 1;
       if (!(ok = wait_ge(ctrl + 1, (unsigned long long)u))) break;
       const int hsl = idx_c & (kDepSlots - 1);
       const unsigned prev = mine ? lastw[hsl] : 0u;
@@ -1298,8 +1322,10 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
       if (mine) lastw[hsl] = it + 1u;
       lanes_publish();
       if (lane == 0) ctrl[1] = (unsigned long long)(u + 1);
-      // ---- my previous draw is complete once its stores are acknowledged ----
-      wave_mem_sync();
+      // ---- my previous draw is complete once its stores of w / g_sum / lag are acknowledged: everything but the
+      // youngest vector-memory operation, which is its gradient-memory store (a line in HBM: ~2 us to acknowledge,
+      // and nobody waits for it -- the chain hands the gradient on through the LDS) ----
+      asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
       if (u_prev >= 0 && lane == 0) done_slot[u_prev & (kWave - 1)] = (unsigned long long)(u_prev + 1);
       // ---- draws in flight that hold one of my features ----
       {
@@ -1312,6 +1338,7 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
         if (need != 0u) {
           const unsigned v_it = need - 1u;                           // the latest earlier draw sharing a feature (or a hash slot)
           const unsigned lo = it + 1u > (unsigned)kCons ? it + 1u - (unsigned)kCons : 0u;
+          spin_kind = 2;
           for (unsigned dd = lo; dd <= v_it && dd < it && ok; ++dd)
             ok = wait_ge(done_slot + ((base + dd) & (kWave - 1)), (unsigned long long)(base + dd + 1));
           if (!ok) break;
@@ -1360,6 +1387,7 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
         }
       }
       // ---- the chain, in draw order ----
+      spin_kind = 3;
       if (!(ok = wait_ge(ctrl + 2, (unsigned long long)u))) break;
       lanes_publish();
       double b = chainv[0], gb = chainv[1];
@@ -1396,7 +1424,6 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
       lanes_publish();
       if (lane == 0) ctrl[2] = (unsigned long long)(u + 1);
       // ---- the rest of the draw ----
-      if (lane == 0) d.M[s] = g;
       if (mine) {
         wj += val_c * gc * (-q_t);                                   // AddWeighted(w, ..., -gamma/wscale)  :306-313
         if (group) {                                                 // LaggedUpdate(it_inner + 1)  :316-325
@@ -1411,6 +1438,7 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
         G[idx_c] = Gj;
         lag[idx_c] = it + 1u;
       }
+      if (lane == 0) d.M[s] = g;                                     // the youngest store of the draw (see vmcnt(1) above)
       u_prev = u;
     }
     // my last draw of the epoch
@@ -1464,6 +1492,10 @@ __global__ __launch_bounds__((kCons + 1) * kWave) void saga_sparse_exact_k1m_ker
   } while (!converged && it_outer < ctl.max_epochs);                 // :371
   if (lane == 0 && ctrl_load(ctrl + 3) == 0ull) ctrl[3] = 1ull;       // the producer may be waiting for a free slot
 
+#ifdef SGDNET_PHASE_TIMING
+  if (d.dbg && lane == 0)
+    for (int q = 0; q < 5; ++q) atomicAdd(d.dbg + 16 + q, spin_count[q]);
+#endif
   if (c == 0 && lane == 0) {
     d.b[0] = chainv[0];
     d.gb[0] = chainv[1];
@@ -2372,7 +2404,7 @@ size_t sparse_exact_k1m_lds_bytes(int64_t nit, int* ls_cache) {
 int sparse_exact_k1m_consumers() { return kCons; }
 
 int launch_sparse_exact_k1m(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st) {
-  return launch_k1_t(saga_sparse_exact_k1m_kernel, (kCons + 1) * kWave, d, lam, ctl, lds_bytes, st);
+  return launch_k1_t(saga_sparse_exact_k1m_kernel, (kCons + kProd) * kWave, d, lam, ctl, lds_bytes, st);
 }
 
 // longest row of the sample-major matrix (the register-resident kernels hold a row in one wavefront)

@@ -1518,7 +1518,15 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         losses[done] = sum / (double)s->d.n;
       }
 #ifdef SGDNET_PHASE_TIMING
-      if (k1 && s->d.dbg && out[0] > 0) {
+      if (k1m && s->d.dbg && out[0] > 0) {
+        (void)hipDeviceSynchronize();
+        unsigned long long c[5];
+        SGD_HIP_TRY(hipMemcpy(c, s->d.dbg + 16, sizeof(c), hipMemcpyDeviceToHost));
+        (void)hipMemset(s->d.dbg + 16, 0, sizeof(c));
+        const double its = (double)out[0] * (double)draws_per_epoch;
+        fprintf(stderr, "[sgdnet] multi-consumer sparse kernel, polls per draw: slot %.2f, registration %.2f, dependency %.2f, chain %.2f, barrier %.3f\n",
+                c[0] / its, c[1] / its, c[2] / its, c[3] / its, c[4] / its);
+      } else if (k1 && s->d.dbg && out[0] > 0) {
         (void)hipDeviceSynchronize();
         unsigned long long c[12];
         SGD_HIP_TRY(hipMemcpy(c, s->d.dbg, sizeof(c), hipMemcpyDeviceToHost));
