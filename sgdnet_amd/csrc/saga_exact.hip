@@ -473,6 +473,17 @@ __device__ __forceinline__ double k1_soft(double x, double s, bool plain) {
 }
 
 SGD_DEFINE_EXP(sgd_exp_lds, const SGD_LDS(double)*)
+// ... and with the 64-entry table spread over the lanes of the wavefront (entry j in lane j): a lookup is four
+// v_readlane instead of an LDS round trip -- for the serial part of the multi-consumer kernel.  The argument is the
+// same in every lane there, so the index is too.
+struct LaneExpTab {
+  double hi, lo;
+  __device__ __forceinline__ double operator[](int i) const {
+    const int jj = __builtin_amdgcn_readfirstlane(i >> 1);
+    return readlane_d((i & 1) ? lo : hi, jj);
+  }
+};
+SGD_DEFINE_EXP(sgd_exp_lanes, const LaneExpTab&)
 
 // one counter of the ring, the same value in every lane and known to be so
 __device__ __forceinline__ unsigned long long ctrl_load(const volatile SGD_LDS(unsigned long long)* c) {
@@ -1127,9 +1138,12 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
   auto aborted = [&]() -> bool { return ctrl_load(ctrl + 3) != 0ull; };
   unsigned long long spin_count[5] = {0, 0, 0, 0, 0};   // slot, registration, dependency, chain, barrier (phase-timing builds report them)
   int spin_kind = 0;
-  auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* c, unsigned long long target) -> bool {
+  auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* c, unsigned long long target, bool eager = false) -> bool {
     unsigned spins = 0;
-    while (ctrl_load(c) < target) {
+    for (;;) {
+      const unsigned long long now = ctrl_load(c);
+      if (now >= target) break;
+      const bool next_in_line = eager && now + 1ull >= target;       // the wavefront whose turn comes next does not sleep
 #ifdef SGDNET_PHASE_TIMING
       ++spin_count[spin_kind];
 #endif
@@ -1138,7 +1152,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
         if (lane == 0) ctrl[3] = 2ull;
         return false;
       }
-      __builtin_amdgcn_s_sleep(1);
+      if (!next_in_line) __builtin_amdgcn_s_sleep(1);
     }
     return true;
   };
@@ -1277,6 +1291,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
   const bool fit_intercept = d.fit_intercept != 0;
   const double n_d = d.n_total, rn_d = 1.0 / n_d;
   const double g_scale = 1.0 / n_d;
+  const LaneExpTab exp_tab{SGD_EXP_TABPTR[2 * lane], SGD_EXP_TABPTR[2 * lane + 1]};   // lane j: 2^(j/64) = hi + lo
   unsigned long long bar_target = 0ull;
   bool ok = true;
   // a barrier of the consumers (the producer does not take part)
@@ -1320,8 +1335,19 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       const unsigned prev = mine ? lastw[hsl] : 0u;
       lanes_publish();
       if (mine) lastw[hsl] = it + 1u;
+      // ... and the sample: the latest of the 64 draws before this one that drew it too, if any, hands its gradient on
+      const int r0 = (int)(u & (kWave - 1));
+      const unsigned long long same = __ballot(hist_s[lane] == s);
+      int repeat_lane = -1;
+      if (same != 0ull) {
+        const unsigned long long rot = r0 ? ((same >> r0) | (same << (kWave - r0))) : same;     // bit k: lane (k + r0) % 64, age 64 - k
+        repeat_lane = ((63 - __builtin_clzll(rot)) + r0) & (kWave - 1);
+      }
       lanes_publish();
-      if (lane == 0) ctrl[1] = (unsigned long long)(u + 1);
+      if (lane == 0) {
+        hist_s[r0] = s;
+        ctrl[1] = (unsigned long long)(u + 1);
+      }
       // ---- my previous draw is complete once its stores of w / g_sum / lag are acknowledged: everything but the
       // youngest vector-memory operation, which is its gradient-memory store (a line in HBM: ~2 us to acknowledge,
       // and nobody waits for it -- the chain hands the gradient on through the LDS) ----
@@ -1387,25 +1413,16 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
         }
       }
       // ---- the chain, in draw order ----
+      const double aw = acc * W;
       spin_kind = 3;
-      if (!(ok = wait_ge(ctrl + 2, (unsigned long long)u))) break;
+      if (!(ok = wait_ge(ctrl + 2, (unsigned long long)u, true))) break;
       lanes_publish();
       double b = chainv[0], gb = chainv[1];
-      const int r0 = (int)(u & (kWave - 1));
-      {
-        const unsigned hs = hist_s[lane];
-        const double hg = hist_g[lane];
-        const unsigned long long mask = __ballot(hs == s);
-        if (mask != 0ull) {
-          const unsigned long long rot = r0 ? ((mask >> r0) | (mask << (kWave - r0))) : mask;   // bit k: lane (k + r0) % 64, age 64 - k
-          const int kk = 63 - __builtin_clzll(rot);
-          m_c = readlane_d(hg, (kk + r0) & (kWave - 1));
-        }
-      }
-      const double lp = acc * W + b;
+      if (repeat_lane >= 0) m_c = hist_g[repeat_lane];               // (that draw's chain step is behind us)
+      const double lp = aw + b;
       double g;                                                      // :279-282
       if (family == SGDNET_BINOMIAL)
-        g = 1.0 - y_c - 1.0 / (1.0 + sgd_exp_lds(lp, sexp));
+        g = 1.0 - y_c - 1.0 / (1.0 + sgd_exp_lanes(lp, exp_tab));
       else
         g = lp - y_c;
       const double gc = g - m_c;
@@ -1418,7 +1435,6 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
         chainv[0] = b;
         chainv[1] = gb;
         if (it + 1u == nit) chainv[2] = Wp;                          // w_scale as Reset finds it
-        hist_s[r0] = s;
         hist_g[r0] = g;
       }
       lanes_publish();
