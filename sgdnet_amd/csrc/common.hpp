@@ -180,7 +180,6 @@ int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCt
 size_t sparse_exact_k1m_lds_bytes(int64_t nit, int* ls_cache);
 int sparse_exact_k1m_consumers();
 int launch_sparse_exact_k1m(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st);
-int launch_row_max(const int64_t* ptr, int64_t n, int* out_dev, hipStream_t st);
 size_t dense_exact_small_lds_bytes(const SagaDev& d, int64_t nit);
 int dense_exact_wide_threads(const SagaDev& d);
 size_t dense_exact_wide_lds_bytes(const SagaDev& d, bool stage_state);

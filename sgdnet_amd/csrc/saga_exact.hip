@@ -1057,8 +1057,9 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
 //     64 (sample, gradient) pairs travel with it through the LDS for draws that repeat a sample;
 //   * the epoch end (Reset, ConvergenceCheck) between barriers of the consumers.
 // w / g_sum / lag stay in memory (L2): with them in the LDS the window p <= 4800 is also the one where neighbouring
-// draws share features all the time.  Rows longer than a wavefront and lambdas whose w_scale can fall below SMALL
-// inside an epoch take the two-wavefront kernel above (the host decides: sparse_exact_k1m_eligible).
+// draws share features all the time.  A row longer than a wavefront works on memory and alone: it waits for every draw
+// before it and every draw behind it waits for it (a stamp of its own at registration).  Lambdas whose w_scale can fall
+// below SMALL inside an epoch take the two-wavefront kernel above (the host decides).
 // Every wait loop gives up after kK1xSpinLimit polls or when another wavefront has raised the abort flag.
 // --------------------------------------------------------------------------
 #ifndef K1M_CONS
@@ -1323,18 +1324,26 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       const double y_c = h[2];
       double m_c = h[3];
       const double W = h[4], Wp = h[5], q_prev = h[6], q_t = h[7], tau1_t = h[8];
+      const double h1 = h[1], h9 = h[9];
       lanes_publish();
       if (lane == 0) readslot[slot] = (unsigned long long)(u + 1);
       const uint32_t s = (uint32_t)(sl & 0xffffffffll);             // :261
       const int len = (int)(sl >> 32);
-      const bool mine = lane < len;                                  // (rows of at most 64 entries only: the host's rule)
+      const bool longrow = len > kWave;                              // works on memory, alone: see below
+      const bool mine = lane < len && !longrow;
+      const int64_t q0 = __double_as_longlong(h1), q1 = __double_as_longlong(h9);
       // ---- registration, in draw order ----
       spin_kind = 1;
       if (!(ok = wait_ge(ctrl + 1, (unsigned long long)u))) break;
       const int hsl = idx_c & (kDepSlots - 1);
-      const unsigned prev = mine ? lastw[hsl] : 0u;
+      unsigned prev = mine ? lastw[hsl] : 0u;
+      // a row longer than the wavefront is a dependency of everything behind it and depends on everything before it
+      const unsigned long_before = (unsigned)ctrl_load(ctrl + 6);
+      prev = prev > long_before ? prev : long_before;
+      if (longrow) prev = it;
       lanes_publish();
       if (mine) lastw[hsl] = it + 1u;
+      if (longrow && lane == 0) ctrl[6] = (unsigned long long)(it + 1u);
       // ... and the sample: the latest of the 64 draws before this one that drew it too, if any, hands its gradient on
       const int r0 = (int)(u & (kWave - 1));
       const unsigned long long same = __ballot(hist_s[lane] == s);
@@ -1370,6 +1379,28 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
           if (!ok) break;
         }
       }
+      double acc = 0.0;
+      if (longrow) {
+        // every earlier draw is complete and acknowledged: catch-up and the ordered sum on memory (:263-274), past the L1
+        for (int64_t qq = q0 + lane; qq < q1; qq += kWave) {
+          const int64_t jf = d.idx[qq];
+          const unsigned lagged_l = it - __hip_atomic_load(lag + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lagged_l != 0u) {
+            double wv = __hip_atomic_load(w + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double Gv = __hip_atomic_load(G + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            penalty_apply_q(penalty, 1, &wv, &Gv, W, ls_at(lagged_l), q_prev, gamma, beta);
+            w[jf] = wv;
+            lag[jf] = it;
+          }
+        }
+        wave_mem_sync();
+        for (int64_t base_q = q0; base_q < q1; base_q += kWave) {
+          const int64_t qq = base_q + lane;
+          const double wx = qq < q1 ? d.val[qq] * __hip_atomic_load(w + d.idx[qq], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+          const int cnt = (q1 - base_q) < (int64_t)kWave ? (int)(q1 - base_q) : kWave;
+          for (int e = 0; e < cnt; ++e) acc += readlane_d(wx, e);
+        }
+      }
       // ---- w / g_sum / lag of my features (past the L1: other wavefronts of this CU wrote them) ----
       double wj = 0.0, Gj = 0.0;
       unsigned lag0 = it;
@@ -1393,8 +1424,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       // linear predictor, ascending feature order  :274
       sx[lane] = mine ? val_c * wj : 0.0;
       lanes_publish();
-      double acc = 0.0;
-      {
+      if (!longrow) {
         double pr[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) pr[e] = sx[e];
@@ -1454,6 +1484,22 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
         G[idx_c] = Gj;
         lag[idx_c] = it + 1u;
       }
+      if (longrow) {
+        const double scaling = -q_t;                                 // :306-335 on memory; the same lane holds an entry in both passes
+        for (int64_t qq = q0 + lane; qq < q1; qq += kWave) {
+          const int64_t jf = d.idx[qq];
+          const double xv = d.val[qq];
+          double wv = __hip_atomic_load(w + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          double Gv = __hip_atomic_load(G + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wv += xv * gc * scaling;
+          const unsigned lagged_l = (it + 1u) - __hip_atomic_load(lag + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lagged_l != 0u) penalty_apply_q(penalty, 1, &wv, &Gv, Wp, ls_at(lagged_l), q_t, gamma, beta);
+          Gv += xv * gc * g_scale;
+          w[jf] = wv;
+          G[jf] = Gv;
+          lag[jf] = it + 1u;
+        }
+      }
       if (lane == 0) d.M[s] = g;                                     // the youngest store of the draw (see vmcnt(1) above)
       u_prev = u;
     }
@@ -1475,6 +1521,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
         lag[j] = 0u;
       }
       for (int i = c * kWave + lane; i < kDepSlots; i += kCons * kWave) lastw[i] = 0u;
+      if (c == 0 && lane == 0) ctrl[6] = 0ull;
     }
     wave_mem_sync();
     consumers_meet();
@@ -2421,30 +2468,6 @@ int sparse_exact_k1m_consumers() { return kCons; }
 
 int launch_sparse_exact_k1m(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st) {
   return launch_k1_t(saga_sparse_exact_k1m_kernel, (kCons + kProd) * kWave, d, lam, ctl, lds_bytes, st);
-}
-
-// longest row of the sample-major matrix (the register-resident kernels hold a row in one wavefront)
-__global__ void row_max_kernel(const int64_t* ptr, int64_t n, int* out) {
-  int m = 0;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t len = ptr[i + 1] - ptr[i];
-    const int l = len > 0x7fffffff ? 0x7fffffff : (int)len;
-    m = l > m ? l : m;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(m, off, kWave);
-    m = o > m ? o : m;
-  }
-  if ((threadIdx.x & (kWave - 1)) == 0) atomicMax(out, m);
-}
-
-int launch_row_max(const int64_t* ptr, int64_t n, int* out_dev, hipStream_t st) {
-  SGD_HIP_TRY(hipMemsetAsync(out_dev, 0, sizeof(int), st));
-  int grid = (int)((n + 255) / 256);
-  if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(row_max_kernel, dim3(grid), dim3(256), 0, st, ptr, n, out_dev);
-  SGD_HIP_TRY(hipGetLastError());
-  return SGDNET_OK;
 }
 
 int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,

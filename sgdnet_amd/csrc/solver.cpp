@@ -86,7 +86,6 @@ struct sgdnet_solver {
     int64_t run_len = 0;   // virtual shards: draws per run of the layout (0: one run = the epoch)
   } pipe;
   int64_t nnz = 0;
-  int row_max = -1;             // longest row of sparse x (found on the device when an exact run first asks)
   bool penalty_set = false;
   // cached epoch graph
   // captured epochs, one per (batch, draws) shape; gexec is the one selected by ensure_graph
@@ -1444,23 +1443,15 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     int k1_cache = 0, k1_stage = 0;
     size_t k1_lds = k1 ? sparse_exact_k1_lds_bytes(s->d, draws_per_epoch, k1_opt == 1 || k1_opt == 4, &k1_cache, &k1_stage) : 0;
     // ... and with several consumer wavefronts where draws seldom share a feature (1: where the rule below expects it
-    // to pay; 3: wherever it is legal; 2, 4: never).  Legal: every row fits a wavefront and w_scale cannot fall below
+    // to pay; 3: wherever it is legal; 2, 4: never).  Legal: w_scale cannot fall below
     // SMALL inside an epoch (the producer forms its sequence without the reset of saga-sparse.h:285-295).
     bool k1m = false;
     if (k1 && (k1_opt == 1 || k1_opt == 3)) {
-      if (s->row_max < 0) {
-        rc = launch_row_max(s->d.ptr, s->d.n, s->out_dev, s->st);
-        if (rc) return rc;
-        int rm = 0;
-        SGD_HIP_TRY(hipMemcpyAsync(&rm, s->out_dev, sizeof(int), hipMemcpyDeviceToHost, s->st));
-        SGD_HIP_TRY(hipStreamSynchronize(s->st));
-        s->row_max = rm;
-      }
       const double upd = 1.0 - s->lam.alpha * s->lam.gamma;
       const bool may_reset = !(upd > 0.0) || (double)draws_per_epoch * std::log(upd) < -30.0;   // SMALL = e^-31.4
       const double avg = (double)s->nnz / (double)s->d.n;
       const double share = (double)(sparse_exact_k1m_consumers() - 1) * avg * avg / (double)s->d.p;   // P(a draw in flight shares a feature)
-      k1m = s->row_max <= 64 && !may_reset && draws_per_epoch >= 64 && (k1_opt == 3 || share < 6.0);   // (measured: 1.2 against 1.4 us at share 2.5, 1.36 against 1.40 at 4.5)
+      k1m = !may_reset && draws_per_epoch >= 64 && (k1_opt == 3 || share < 6.0);   // (measured: 1.2 against 1.4 us at share 2.5, 1.36 against 1.40 at 4.5)
       if (k1m) {
         k1_lds = sparse_exact_k1m_lds_bytes(draws_per_epoch, &k1_cache);
         k1_stage = 0;

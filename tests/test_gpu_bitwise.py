@@ -94,6 +94,8 @@ ROW_REGISTER_CASES = {
     "scale_reset": ("gaussian", "elasticnet", 1500, 60, 0.1, 0.3, 1.0, 1e-3, 2, True),    # wscale < SMALL every ~90 draws
     "scale_reset_ragged": ("gaussian", "elasticnet", 600, 150, (5, 80, 2, 64), 0.3, 1.0, 1e-3, 2, True),
     "state_in_memory": ("binomial", "elasticnet", 25000, 9000, 0.001, 0.05, 2e-5, 2e-5, 2, True),  # lags past the LDS cache
+    # few non-zeros per row in many features (the several-consumer kernel by default), with a long row now and then
+    "heavy_tail": ("binomial", "elasticnet", 4000, 6000, (5, 4, 6, 3, 5, 7, 4, 5, 120, 5, 6, 4, 5, 3, 70, 5, 4, 6, 5, 5), 0.04, 1e-4, 2e-4, 3, True),
 }
 
 
@@ -102,8 +104,10 @@ ROW_REGISTER_CASES = {
 def test_register_resident_sparse_kernel_is_bit_identical(sa, det, case, registers):
     """Round 3: `saga_sparse_exact_k1_kernel` (one response: the row's lanes keep w, g_sum and lag of their features
     in registers for the whole draw, the state of the next draw is requested a draw ahead and forwarded where two
-    draws share a feature) against the det-math restatement -- equal, like the general kernel (option
-    exact_row_registers = 0) it replaces; 2 keeps the state in memory even where the LDS would hold it."""
+    draws share a feature) and `saga_sparse_exact_k1m_kernel` (several consumer wavefronts, registration and the
+    intercept chain in draw order) against the det-math restatement -- equal, like the general kernel (option
+    exact_row_registers = 0) they replace; 1: the default choice, 2: one consumer with the state in memory, 3: several
+    consumers wherever legal (also on the crowded and the long-row cases), 4: one consumer always."""
     from test_gpu_parity import make_problem
     family, penalty, n, p, shape, gamma, alpha, beta, epochs, fit_intercept = ROW_REGISTER_CASES[case]
     if isinstance(shape, tuple):
