@@ -1058,8 +1058,8 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
 //   * the epoch end (Reset, ConvergenceCheck) between barriers of the consumers.
 // w / g_sum / lag stay in memory (L2): with them in the LDS the window p <= 4800 is also the one where neighbouring
 // draws share features all the time.  A row longer than a wavefront works on memory and alone: it waits for every draw
-// before it and every draw behind it waits for it (a stamp of its own at registration).  Lambdas whose w_scale can fall
-// below SMALL inside an epoch take the two-wavefront kernel above (the host decides).
+// before it and every draw behind it waits for it (a stamp of its own at registration); so does the draw that finds
+// w_scale below SMALL and rescales w (the producers know which: the sequence of w_scale does not depend on the data).
 // Every wait loop gives up after kK1xSpinLimit polls or when another wavefront has raised the abort flag.
 // --------------------------------------------------------------------------
 #ifndef K1M_CONS
@@ -1196,14 +1196,14 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       }
       // the data-independent numbers of my draws at once: lane l works for my draw l % kOwn; lanes [0, kOwn) divide
       // gamma by w_scale before the draw, [kOwn, 2 kOwn) gamma by w_scale after it, [2 kOwn, 3 kOwn) the SAGA
-      // step's threshold by the latter (no reset inside an epoch here: the host sends such lambdas elsewhere)
+      // step's threshold by the latter
       double Wb = W, Wa = W;
       double Wnext = W;
       unsigned itnext = itp;
 #pragma unroll
       for (int t16 = 0; t16 < 16; ++t16) {
         const double before = Wnext;
-        const double after = before * wscale_update;
+        const double after = (before < kSmall ? 1.0 : before) * wscale_update;     // :285-297
         if (t16 == mine_i) {
           Wb = before;
           Wa = after;
@@ -1330,6 +1330,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       const uint32_t s = (uint32_t)(sl & 0xffffffffll);             // :261
       const int len = (int)(sl >> 32);
       const bool longrow = len > kWave;                              // works on memory, alone: see below
+      const bool rescale = W < kSmall;                               // the draw that rescales w (:285-295) is alone as well
       const bool mine = lane < len && !longrow;
       const int64_t q0 = __double_as_longlong(h1), q1 = __double_as_longlong(h9);
       // ---- registration, in draw order ----
@@ -1340,10 +1341,10 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       // a row longer than the wavefront is a dependency of everything behind it and depends on everything before it
       const unsigned long_before = (unsigned)ctrl_load(ctrl + 6);
       prev = prev > long_before ? prev : long_before;
-      if (longrow) prev = it;
+      if (longrow || rescale) prev = it;
       lanes_publish();
       if (mine) lastw[hsl] = it + 1u;
-      if (longrow && lane == 0) ctrl[6] = (unsigned long long)(it + 1u);
+      if ((longrow || rescale) && lane == 0) ctrl[6] = (unsigned long long)(it + 1u);
       // ... and the sample: the latest of the 64 draws before this one that drew it too, if any, hands its gradient on
       const int r0 = (int)(u & (kWave - 1));
       const unsigned long long same = __ballot(hist_s[lane] == s);
@@ -1470,6 +1471,24 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       lanes_publish();
       if (lane == 0) ctrl[2] = (unsigned long long)(u + 1);
       // ---- the rest of the draw ----
+      if (rescale) {
+        // rescale + unlag  :285-295: every earlier draw is complete, every later one waits for this one
+        if (mine) {                          // the caught-up features go to memory first
+          w[idx_c] = wj;
+          lag[idx_c] = it;
+        }
+        wave_mem_sync();
+        for (int64_t jf = lane; jf < p; jf += kWave) {
+          double wv = __hip_atomic_load(w + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const double Gv = __hip_atomic_load(G + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned lagged_r = it - __hip_atomic_load(lag + jf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (lagged_r != 0u) penalty_apply(penalty, 1, &wv, &Gv, W, ls_at(lagged_r), gamma, beta);
+          w[jf] = wv * W;
+          lag[jf] = it;
+        }
+        wave_mem_sync();
+        if (mine) wj = __hip_atomic_load(w + idx_c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       if (mine) {
         wj += val_c * gc * (-q_t);                                   // AddWeighted(w, ..., -gamma/wscale)  :306-313
         if (group) {                                                 // LaggedUpdate(it_inner + 1)  :316-325

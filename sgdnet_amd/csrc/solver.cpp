@@ -1443,15 +1443,14 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     int k1_cache = 0, k1_stage = 0;
     size_t k1_lds = k1 ? sparse_exact_k1_lds_bytes(s->d, draws_per_epoch, k1_opt == 1 || k1_opt == 4, &k1_cache, &k1_stage) : 0;
     // ... and with several consumer wavefronts where draws seldom share a feature (1: where the rule below expects it
-    // to pay; 3: wherever it is legal; 2, 4: never).  Legal: w_scale cannot fall below
-    // SMALL inside an epoch (the producer forms its sequence without the reset of saga-sparse.h:285-295).
+    // to pay; 3: wherever it is legal; 2, 4: never).
     bool k1m = false;
     if (k1 && (k1_opt == 1 || k1_opt == 3)) {
       const double upd = 1.0 - s->lam.alpha * s->lam.gamma;
-      const bool may_reset = !(upd > 0.0) || (double)draws_per_epoch * std::log(upd) < -30.0;   // SMALL = e^-31.4
+      const bool odd_scale = !(upd > 0.0);        // w_scale changing sign: the one-consumer kernel's plain soft threshold
       const double avg = (double)s->nnz / (double)s->d.n;
       const double share = (double)(sparse_exact_k1m_consumers() - 1) * avg * avg / (double)s->d.p;   // P(a draw in flight shares a feature)
-      k1m = !may_reset && draws_per_epoch >= 64 && (k1_opt == 3 || share < 6.0);   // (measured: 1.2 against 1.4 us at share 2.5, 1.36 against 1.40 at 4.5)
+      k1m = !odd_scale && draws_per_epoch >= 64 && (k1_opt == 3 || share < 6.0);   // (measured: 1.2 against 1.4 us at share 2.5, 1.36 against 1.40 at 4.5)
       if (k1m) {
         k1_lds = sparse_exact_k1m_lds_bytes(draws_per_epoch, &k1_cache);
         k1_stage = 0;
