@@ -7,8 +7,14 @@
 //                                 (LaggedUpdate :76-100, AddWeighted :114-130, Reset :132-155)
 //   saga_dense_exact_kernel   <-  Saga(), src/saga-dense.h:99-224
 // The chain through `intercept` makes every pair of consecutive iterations
-// dependent, so this kernel is latency-bound by construction;
-// the throughput path is saga_batched.hip.
+// dependent, so these kernels are latency-bound by construction;
+// the throughput path is saga_batched.hip.  Sparse x with one response has two
+// faster forms of the same iteration, bit for bit (round 3):
+//   saga_sparse_exact_k1x_kernel  one producer + one consumer wavefront, the drawn
+//                                 row held in registers for the whole draw
+//   saga_sparse_exact_k1m_kernel  two producers + six consumers taking the draws
+//                                 round robin; registration of a draw's features
+//                                 and the intercept chain run in draw order
 //
 // Lane roles: lanes stride the nonzeros of the drawn sample for the per-feature
 // steps; lane k owns class k for the linear predictor / gradient / intercept.
