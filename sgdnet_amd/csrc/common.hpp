@@ -181,6 +181,9 @@ size_t sparse_exact_k1m_lds_bytes(int64_t nit, int* ls_cache);
 int sparse_exact_k1m_consumers();
 int launch_sparse_exact_k1m(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st);
 size_t dense_exact_small_lds_bytes(const SagaDev& d, int64_t nit);
+size_t dense_exact_small2_lds_bytes(const SagaDev& d, int penalty, int64_t nit);
+int launch_dense_exact_small2(const SagaDev& d, int penalty, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                              hipStream_t st);
 int dense_exact_wide_threads(const SagaDev& d);
 size_t dense_exact_wide_lds_bytes(const SagaDev& d, bool stage_state);
 int launch_dense_exact_wide(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st);

@@ -82,8 +82,13 @@ __device__ __forceinline__ double div_by_n(double a, double n, double rn) {
 // and the plain division is used (elsewhere the result IS the correctly rounded quotient: rn is the correctly
 // rounded reciprocal of an integer-valued n, q0 is within an ulp, the remainder is exact)
 __device__ __forceinline__ double div_by_n_exact(double a, double n, double rn) {
-  if (fabs(a) < 1e-280) return a / n;
-  return div_by_n(a, n, rn);
+  double q = div_by_n(a, n, rn);
+  q = a == 0.0 ? a : q;                                   // a zero keeps its sign, as a / n does
+  // (lanes that hold no coefficient carry a = 0 through here every iteration: tested per lane, they dragged the
+  // whole wavefront through the division sequence -- ~300 cycles of a lone wavefront's 1500 per iteration)
+  const bool tiny = fabs(a) < 1e-280 && a != 0.0;
+  if (__ballot(tiny) != 0ull) q = tiny ? a / n : q;
+  return q;
 }
 
 // Multinomial gradient of class `lane` (families.h:244-260, math.h:25-33) when lane k < K holds the linear
@@ -1144,6 +1149,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
   // waits: true when the condition came true, false when the launch is being abandoned
   auto aborted = [&]() -> bool { return ctrl_load(ctrl + 3) != 0ull; };
   unsigned long long spin_count[5] = {0, 0, 0, 0, 0};   // slot, registration, dependency, chain, barrier (phase-timing builds report them)
+  (void)spin_count;
   int spin_kind = 0;
   auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* c, unsigned long long target, bool eager = false) -> bool {
     unsigned spins = 0;
@@ -2387,6 +2393,322 @@ __global__ __launch_bounds__(kWave) void saga_dense_exact_small_kernel(SagaDev d
   }
 }
 
+// --------------------------------------------------------------------------
+// The small dense kernel for one response with a feeder (round 3): the iteration of saga_dense_exact_small_kernel
+// <family, penalty, one class> with everything that does not depend on the coefficients done by a second wavefront.
+// The producer walks the stream ahead: the drawn row (lane j: x_j), the response, the gradient memory as it stands
+// and the data-independent numbers of the draw -- w_scale before and after it (with the reset of saga-dense.h:162-166),
+// gamma / w_scale and beta gamma / w_scale, sixteen draws per division -- go into a ring of slots in the LDS.  The
+// consumer keeps w_j, g_sum_j in registers and runs dot product (ascending order over v_readlane operands), gradient,
+// intercept, step, penalty and gradient average from the slot: ~90 instructions per draw instead of ~250.
+// Gradient memory and responses live in the LDS as before; the producer's copy of M[s] may predate the consumer's
+// store for one of the last kSmallRing + 4 draws, so the consumer keeps the last 32 (sample, gradient) pairs in
+// registers, one per lane, and takes the latest match.
+// --------------------------------------------------------------------------
+constexpr int kSmallRing = 16;
+constexpr int kSmallHdr = 8;        // doubles per slot header: sample, y, m, w_scale before, after, f, tau, spare
+constexpr size_t kSmall2FixedLds = sizeof(double) * (kSmallRing * (kWave + kSmallHdr) + kWave + 16) + 32;
+
+template <int kFamily, int kPenalty>
+__global__ __launch_bounds__(2 * kWave) void saga_dense_exact_small2_kernel(SagaDev d, const LamParams* lamp,
+                                                                            ExactCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = (int)d.p;
+  const int n = (int)d.n;
+  const unsigned nit = (unsigned)ctl.nit;
+  // LDS carve: [Ml n][yl n][rx kSmallRing*64][rh kSmallRing*kSmallHdr][sx 64+16][ctrl 4 x u64]
+  SGD_LDS(double)* Ml = (SGD_LDS(double)*)smem;
+  SGD_LDS(double)* yl = Ml + n;
+  SGD_LDS(double)* rx = yl + n;
+  SGD_LDS(double)* rh = rx + kSmallRing * kWave;
+  SGD_LDS(double)* sx = rh + kSmallRing * kSmallHdr;                  // [kWave + 16]: the products of the draw in hand
+  volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(sx + kWave + 16);   // produced, consumed, stop
+  for (int i = tid; i < n; i += 2 * kWave) {
+    Ml[i] = d.M[i];
+    yl[i] = d.y[i];
+  }
+  if (tid < 4) ctrl[tid] = 0ull;
+  if (tid < kWave + 16) sx[tid] = 0.0;
+  __syncthreads();                                                    // the last barrier both wavefronts meet
+
+  const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
+  const double wscale_update = 1.0 - alpha * gamma;                   // saga-dense.h:131
+  const double bg = beta * gamma * 1.0;                               // penalties.h: beta * gamma * scaling
+  const int64_t total = (int64_t)ctl.max_epochs * nit;
+
+  if (wave == 1) {
+    // ================================ producer ================================
+    // A batch of sixteen draws ahead: the rows of the next batch are requested before the slots of this one are
+    // filled, so a row has sixteen slot fills to arrive in.
+    const bool gl = lane < 16;
+    const bool act = lane < p;
+    auto stream_batch = [&](int64_t ub) -> uint32_t {
+      const int64_t uu = ub + (lane & 15);
+      return (gl && uu < total) ? d.stream[ctl.stream_off + uu] : 0u;
+    };
+    auto row_of = [&](uint32_t sv, int i) -> double {
+      const uint32_t si = (uint32_t)__builtin_amdgcn_readlane((int)sv, i);
+      return act ? d.xd[(int64_t)si * p + lane] : 0.0;
+    };
+    double W = 1.0;
+    unsigned itp = 0;
+    bool stop = false;
+    int64_t freed = 0;
+    uint32_t sv = stream_batch(0), sv_n = stream_batch(16);
+    double xc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xc[i] = row_of(sv, i);
+    for (int64_t ub = 0; ub < total && !stop; ub += 16) {
+      const uint32_t sv_nn = stream_batch(ub + 32);
+      double xn[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xn[i] = row_of(sv_n, i);
+      // w_scale before / after each of the sixteen draws, then gamma / after (lanes 0..15) and beta gamma / after (16..31)
+      const int di = lane & 15;
+      double Wb = W, Wa = W, Wnext = W;
+      unsigned itnext = itp;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const double before = Wnext;
+        const double after = (before < kSmall ? 1.0 : before) * wscale_update;      // :162-168
+        if (q == di) {
+          Wb = before;
+          Wa = after;
+        }
+        Wnext = after;
+        if (++itnext == nit) {                                      // :188-189: the epoch ends with w_scale = 1
+          itnext = 0;
+          Wnext = 1.0;
+        }
+      }
+      const double quot = (lane < 16 ? gamma : bg) / Wa;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t u = ub + i;
+        if (u < total && !stop) {
+        if (u - freed >= kSmallRing) {
+          unsigned spins = 0;
+          for (;;) {
+            freed = (int64_t)ctrl_load(ctrl + 1);
+            if (u - freed < kSmallRing) break;
+            if (ctrl_load(ctrl + 2) != 0ull || ++spins > kK1xSpinLimit) {
+              stop = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        }
+        if (u < total && !stop) {
+        const int slot = (int)(u & (kSmallRing - 1));
+        const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)sv, i);
+        const double y_u = yl[s_u], m_u = Ml[s_u];
+        const double Wb_u = readlane_d(Wb, i), Wa_u = readlane_d(Wa, i);
+        const double f_u = readlane_d(quot, i), tau_u = readlane_d(quot, 16 + i);
+        rx[slot * kWave + lane] = xc[i];
+        double hv = __longlong_as_double((long long)s_u);
+        hv = lane == 1 ? y_u : hv;
+        hv = lane == 2 ? m_u : hv;
+        hv = lane == 3 ? Wb_u : hv;
+        hv = lane == 4 ? Wa_u : hv;
+        hv = lane == 5 ? f_u : hv;
+        hv = lane == 6 ? tau_u : hv;
+        if (lane < kSmallHdr) rh[slot * kSmallHdr + lane] = hv;
+        lanes_publish();
+        if (lane == 0) ctrl[0] = (unsigned long long)(u + 1);
+        }
+      }
+      W = Wnext;
+      itp = itnext;
+      sv = sv_n;
+      sv_n = sv_nn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) xc[i] = xn[i];
+    }
+    return;
+  }
+
+  // ================================ consumer ================================
+  const bool active = lane < p;
+  double w = active ? d.w[lane] : 0.0;
+  double G = active ? d.G[lane] : 0.0;
+  double w_prev = w;                                                  // saga-dense.h:142
+  double sb = d.b[0], sgb = d.gb[0];                                  // every lane the same
+  if (active) d.w_prev[lane] = w;
+  const double n_d = d.n_total, rn_d = 1.0 / n_d;
+  const bool fit_intercept = d.fit_intercept != 0;
+  const bool plain_soft = !(wscale_update > 0.0 && bg >= 0.0);
+  const LaneExpTab exp_tab{SGD_EXP_TABPTR[2 * lane], SGD_EXP_TABPTR[2 * lane + 1]};   // lane j: 2^(j/64) = hi + lo
+  uint32_t hs = 0xffffffffu;                                          // lane i < 32: sample and gradient of draw u with u % 32 == i
+  double hg = 0.0;
+  int64_t avail = 0;
+  bool stalled = false;
+  // a slot, as registers
+  double x_n, h_s, y_n, m_n, Wb_n, Wa_n, f_n, tau_n;
+  auto read_slot = [&](int64_t u) {
+    if (u >= avail) {
+      unsigned spins = 0;
+      for (;;) {
+        avail = (int64_t)ctrl_load(ctrl);
+        if (u < avail) break;
+        if (++spins > kK1xSpinLimit) {
+          stalled = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    const int slot = (int)(u & (kSmallRing - 1));
+    lanes_publish();
+    x_n = rx[slot * kWave + lane];
+    const SGD_LDS(double)* h = rh + slot * kSmallHdr;
+    h_s = h[0];
+    y_n = h[1];
+    m_n = h[2];
+    Wb_n = h[3];
+    Wa_n = h[4];
+    f_n = h[5];
+    tau_n = h[6];
+    lanes_publish();
+    if (lane == 0) ctrl[1] = (unsigned long long)(u + 1);
+  };
+  read_slot(0);
+
+  unsigned it_outer = 0;
+  int converged = 0;
+  int64_t u = 0;
+#ifdef SGDNET_PHASE_TIMING
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+#define SM2_STAMP(i) do { const unsigned long long now_ = clock64(); ph[i] += now_ - last_; last_ = now_; } while (0)
+#else
+#define SM2_STAMP(i) ((void)0)
+#endif
+  do {
+    double W_end = 1.0;
+    for (unsigned it = 0; it < nit; ++it, ++u) {
+#ifdef SGDNET_PHASE_TIMING
+      unsigned long long last_ = clock64();
+#endif
+      const uint32_t s = (uint32_t)__double_as_longlong(h_s);        // :152
+      const double x = x_n, y_cur = y_n, Wb = Wb_n, Wa = Wa_n, f = f_n, tau = tau_n;
+      double m_old = m_n;
+      if (u + 1 < total) read_slot(u + 1);
+      if (stalled) break;
+#ifdef SM2_Z
+      if (x == 1.2345e300) w += y_cur + Wb + Wa + f + tau + m_old + (double)s;
+      W_end = Wa;
+      continue;
+#endif
+      // gradient memory: a draw of the same sample among the last 32 supersedes the producer's copy
+      const int r0 = (int)(u & 31);
+      {
+        const unsigned mask = (unsigned)(__ballot(lane < 32 && hs == s) & 0xffffffffull);
+        if (mask != 0u) {
+          const unsigned rot = r0 ? ((mask >> r0) | (mask << (32 - r0))) : mask;     // bit k: lane (k + r0) % 32, age 32 - k
+          const int kk = 31 - __builtin_clz(rot);
+          m_old = readlane_d(hg, (kk + r0) & 31);
+        }
+      }
+      SM2_STAMP(0);
+      // linear predictor: ascending-feature sum over v_readlane operands (lanes past the last feature hold zeros), :154
+      // (through the LDS, sixteen at a time: a loop of v_readlane cost ~75 cycles per feature; the +0.0 products of
+      // the lanes past the last feature change no partial sum)
+      sx[lane] = w * x;
+      lanes_publish();
+      double acc = 0.0;
+      {
+        double pr[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) pr[e] = sx[e];
+        for (int eb = 0;;) {
+#pragma unroll
+          for (int blk = 0; blk < 4; ++blk) {
+            if (eb + 4 * blk < p) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc += pr[4 * blk + e];
+            }
+          }
+          eb += 16;
+          if (eb >= p) break;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) pr[e] = sx[eb + e];
+        }
+      }
+      SM2_STAMP(1);
+      const double lp = acc * Wb + sb;
+      double g;
+      if (kFamily == SGDNET_BINOMIAL)
+        g = 1.0 - y_cur - 1.0 / (1.0 + sgd_exp_lanes(lp, exp_tab));
+      else
+        g = lp - y_cur;
+      const double gc = g - m_old;                                    // :156-159
+      if (lane == 0) Ml[s] = g;
+      if (lane == r0) {
+        hs = s;
+        hg = g;
+      }
+      SM2_STAMP(2);
+      if (Wb < kSmall) w *= Wb;                                       // :162-166 (w_scale becomes 1, then :168 -- in Wa)
+      W_end = Wa;
+      if (fit_intercept) {                                            // :170-173
+        const double gck = div_by_n_exact(gc, n_d, rn_d);
+        const double gbk = sgb + gck;
+        sgb = gbk;
+        sb -= gamma * (gbk + gck);
+      }
+      SM2_STAMP(3);
+      // all coefficients: gradient step, penalty, gradient average (:176-183)
+      w -= gc * x * f;                                                // :176
+      if (kPenalty == SGDNET_RIDGE)
+        w -= f * G;                                                   // penalty(w, j, wscale, 1.0, g_sum), :179-180
+      else
+        w = k1_soft(w - f * G, tau, plain_soft);
+      G += div_by_n_exact(gc * x, n_d, rn_d);                         // :183
+      if (!active) {
+        w = 0.0;
+        G = 0.0;
+      }
+      SM2_STAMP(4);
+    }
+    if (stalled) break;
+    w *= W_end;                                                       // :188-189
+    // ConvergenceCheck (src/utils.h:240-262) on the registers
+    {
+      const bool finite = fabs(w) <= 1.79769313486231570815e+308;
+      const double mc = wave_max(fabs(w - w_prev));
+      const double ms = wave_max(fabs(w));
+      w_prev = w;
+      const bool all_zero = (ms == 0.0) && (mc == 0.0);
+      const bool no_change = (ms != 0.0) && (mc / ms <= ctl.tol);
+      converged = (__ballot(!finite) == 0ull) && (all_zero || no_change) ? 1 : 0;
+    }
+    ++it_outer;
+  } while (!converged && it_outer < ctl.max_epochs);
+  if (lane == 0) ctrl[2] = 1ull;                                      // the producer may be waiting for a free slot
+#ifdef SGDNET_PHASE_TIMING
+  if (d.dbg && lane == 0)
+    for (int i = 0; i < 5; ++i) d.dbg[24 + i] += ph[i];
+#endif
+#undef SM2_STAMP
+
+  if (active) {
+    d.w[lane] = w;
+    d.G[lane] = G;
+    d.w_prev[lane] = w_prev;
+  }
+  lanes_publish();
+  for (int i = lane; i < n; i += kWave) d.M[i] = Ml[i];
+  if (lane == 0) {
+    d.b[0] = sb;
+    d.gb[0] = sgb;
+    ctl.out[0] = (int)it_outer;
+    ctl.out[1] = stalled ? -2 : converged;
+  }
+}
+
 // 0 when the small-problem kernel does not apply
 size_t dense_exact_small_lds_bytes(const SagaDev& d, int64_t nit) {
   if (!d.xd || d.K > 16 || (int64_t)d.K * d.p > kWave || d.n > (1 << 20) || nit > (1 << 16)) return 0;
@@ -2403,6 +2725,37 @@ static int launch_small_t(const SagaDev& d, const LamParams* lam, const ExactCtl
                      ctl);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
+}
+
+template <typename Kern>
+static int launch_k1_t(Kern kern, int threads, const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                       hipStream_t st) {
+  SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds_bytes));
+  hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds_bytes, st, d, lam, ctl);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+// 0 when the feeder form does not apply: one response, gaussian or binomial, ridge or elastic net
+size_t dense_exact_small2_lds_bytes(const SagaDev& d, int penalty, int64_t nit) {
+  if (!d.xd || d.K != 1 || d.Ky != 1 || d.p > kWave || d.n > (1 << 20) || nit < 64 ||
+      (d.family != SGDNET_GAUSSIAN && d.family != SGDNET_BINOMIAL) ||
+      (penalty != SGDNET_RIDGE && penalty != SGDNET_ELASTICNET))
+    return 0;
+  const size_t b = sizeof(double) * 2 * (size_t)d.n + kSmall2FixedLds;
+  return b <= 150 * 1024 ? ((b + 15) & ~size_t(15)) : 0;
+}
+
+int launch_dense_exact_small2(const SagaDev& d, int penalty, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
+                              hipStream_t st) {
+  if (d.family == SGDNET_GAUSSIAN)
+    return penalty == SGDNET_RIDGE
+               ? launch_k1_t(saga_dense_exact_small2_kernel<SGDNET_GAUSSIAN, SGDNET_RIDGE>, 2 * kWave, d, lam, ctl, lds_bytes, st)
+               : launch_k1_t(saga_dense_exact_small2_kernel<SGDNET_GAUSSIAN, SGDNET_ELASTICNET>, 2 * kWave, d, lam, ctl, lds_bytes, st);
+  return penalty == SGDNET_RIDGE
+             ? launch_k1_t(saga_dense_exact_small2_kernel<SGDNET_BINOMIAL, SGDNET_RIDGE>, 2 * kWave, d, lam, ctl, lds_bytes, st)
+             : launch_k1_t(saga_dense_exact_small2_kernel<SGDNET_BINOMIAL, SGDNET_ELASTICNET>, 2 * kWave, d, lam, ctl, lds_bytes, st);
 }
 
 int launch_dense_exact_small(const SagaDev& d, int penalty, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
@@ -2465,15 +2818,6 @@ size_t sparse_exact_k1_lds_bytes(const SagaDev& d, int64_t nit, bool allow_stage
   return (fixed + sizeof(double) * entries + (stage ? state : 0) + 15) & ~size_t(15);
 }
 
-template <typename Kern>
-static int launch_k1_t(Kern kern, int threads, const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,
-                       hipStream_t st) {
-  SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds_bytes));
-  hipLaunchKernelGGL(kern, dim3(1), dim3(threads), lds_bytes, st, d, lam, ctl);
-  SGD_HIP_TRY(hipGetLastError());
-  return SGDNET_OK;
-}
 
 int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st) {
   return ctl.use_lds ? launch_k1_t(saga_sparse_exact_k1x_kernel<true>, 2 * kWave, d, lam, ctl, lds_bytes, st)

@@ -1432,6 +1432,9 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     // small dense problems: the register-resident kernel (saga_exact.hip); SGDNET_EXACT_SMALL=0 keeps the general one
     static const int small_ok = exp_env_int("SGDNET_EXACT_SMALL", 1);
     const size_t lds_small = (!s->sparse && small_ok) ? dense_exact_small_lds_bytes(s->d, draws_per_epoch) : 0;
+    // ... with a feeder wavefront where there is one response (SGDNET_EXACT_SMALL2=0 in experiment builds: without)
+    static const int small2_ok = exp_env_int("SGDNET_EXACT_SMALL2", 1);
+    const size_t lds_small2 = (lds_small && small2_ok) ? dense_exact_small2_lds_bytes(s->d, s->lam.penalty, draws_per_epoch) : 0;
     // wider dense rows (up to 16 classes): the workgroup-per-iteration kernel; SGDNET_EXACT_WIDE=0 keeps the one-wavefront one
     static const int wide_ok = exp_env_int("SGDNET_EXACT_WIDE", 1);
     const bool wide = !s->sparse && !lds_small && wide_ok && dense_exact_wide_threads(s->d) > 0;
@@ -1490,7 +1493,8 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       rc = k1m ? launch_sparse_exact_k1m(s->d, s->lam_dev, ctl, k1_lds, s->st)
          : k1 ? launch_sparse_exact_k1(s->d, s->lam_dev, ctl, k1_lds, s->st)
          : s->sparse ? launch_sparse_exact(s->d, s->lam_dev, ctl, lds, s->st)
-                     : (lds_small ? launch_dense_exact_small(s->d, s->lam.penalty, s->lam_dev, ctl, lds_small, s->st)
+                     : (lds_small2 ? launch_dense_exact_small2(s->d, s->lam.penalty, s->lam_dev, ctl, lds_small2, s->st)
+                        : lds_small ? launch_dense_exact_small(s->d, s->lam.penalty, s->lam_dev, ctl, lds_small, s->st)
                         : wide    ? launch_dense_exact_wide(s->d, s->lam_dev, ctl, lds, s->st)
                                   : launch_dense_exact(s->d, s->lam_dev, ctl, lds, s->st));
       if (rc) return rc;
@@ -1508,6 +1512,14 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         losses[done] = sum / (double)s->d.n;
       }
 #ifdef SGDNET_PHASE_TIMING
+      if (lds_small2 && !s->sparse && s->d.dbg && out[0] > 0) {
+        unsigned long long c[5];
+        SGD_HIP_TRY(hipMemcpy(c, s->d.dbg + 24, sizeof(c), hipMemcpyDeviceToHost));
+        (void)hipMemset(s->d.dbg + 24, 0, sizeof(c));
+        const double its = (double)out[0] * (double)draws_per_epoch;
+        fprintf(stderr, "[sgdnet] small dense kernel with feeder, consumer cycles per draw: slot+history %.0f, dot %.0f, gradient+store %.0f, "
+                        "intercept %.0f, step+penalty+average %.0f\n", c[0] / its, c[1] / its, c[2] / its, c[3] / its, c[4] / its);
+      }
       if (k1m && s->d.dbg && out[0] > 0) {
         (void)hipDeviceSynchronize();
         unsigned long long c[5];
