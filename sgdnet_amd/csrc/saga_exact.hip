@@ -1076,12 +1076,8 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
 #ifndef K1M_CONS
 #define K1M_CONS 6
 #endif
-#ifndef K1M_ROWS
-#define K1M_ROWS 4
-#endif
 constexpr int kCons = K1M_CONS;
 constexpr int kProd = 2;               // producer wavefronts: draw i of a batch of sixteen belongs to producer i % kProd
-constexpr int kProdRows = K1M_ROWS;    // rows the producer keeps in flight
 constexpr int kDepSlots = 16384;
 constexpr int kK1mCtrl = 8;         // produced, registered, chain_done, stop/abort, barrier count, converged, epochs, spare
 constexpr size_t kK1mFixedLds = sizeof(double) * ((size_t)kCons * kK1Sum + 128 + kRing * (kWave + kSlotHdr) + 4 + kWave) +
@@ -1172,9 +1168,10 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
 
   if (wave >= kCons) {
     // ================================ producers ================================
-    // kProd of them: draw i of every batch of sixteen belongs to producer i % kProd, which gathers its 16 / kProd stream
-    // entries, row pointers, responses and gradient memories one per lane, keeps kProdRows rows in flight and fills
-    // its slots as the consumers free them.  Both run the whole w_scale sequence (sixteen multiplications a batch).
+    // kProd of them: draw i of every batch of sixteen belongs to producer i % kProd.  A producer works four batches
+    // deep: the stream entries of batch b + 3, the row pointers of b + 2, the rows, responses and gradient memories
+    // of b + 1 (one lane per draw for the gathers, a load per row) are requested before the slots of batch b are
+    // filled, as the consumers free them.  Both run the whole w_scale sequence (sixteen multiplications a batch).
     const int q = wave - kCons;
     constexpr int kOwn = 16 / kProd;                                  // my draws per batch
     auto stream_at = [&](int64_t u) -> uint32_t {
@@ -1183,32 +1180,60 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
     };
     const bool gl = lane < kOwn;
     const int mine_i = (lane & (kOwn - 1)) * kProd + q;               // my lane's draw inside a batch
-    uint32_t sv = gl ? stream_at(mine_i) : 0u, sv_n = gl ? stream_at(16 + mine_i) : 0u;
-    int64_t pa = 0, pe = 0;
-    double yv = 0.0, mv = 0.0;
+    uint32_t sv0 = gl ? stream_at(mine_i) : 0u, sv1 = gl ? stream_at(16 + mine_i) : 0u,
+             sv2 = gl ? stream_at(32 + mine_i) : 0u;
+    int64_t pa0 = 0, pe0 = 0, pa1 = 0, pe1 = 0;
+    double yv0 = 0.0, mv0 = 0.0;
     if (gl) {
-      pa = d.ptr[sv];
-      pe = d.ptr[sv + 1];
-      yv = d.y[sv];
-      mv = d.M[sv];
+      pa0 = d.ptr[sv0];
+      pe0 = d.ptr[sv0 + 1];
+      pa1 = d.ptr[sv1];
+      pe1 = d.ptr[sv1 + 1];
+      yv0 = d.y[sv0];
+      mv0 = d.M[sv0];
+    }
+    int idx0[kOwn];
+    double val0[kOwn];
+#pragma unroll
+    for (int j = 0; j < kOwn; ++j) {
+      const int64_t a = readlane_ll(pa0, j), e = readlane_ll(pe0, j);
+      idx0[j] = 0;
+      val0[j] = 0.0;
+      if (a + lane < e) {
+        idx0[j] = d.idx[a + lane];
+        val0[j] = d.val[a + lane];
+      }
     }
     double W = 1.0;                    // w_scale before the first draw of the batch in hand
     unsigned itp = 0;
     bool stop = false;
     for (int64_t ub = 0; ub < total && !stop; ub += 16) {
-      const uint32_t sv_nn = gl ? stream_at(ub + 32 + mine_i) : 0u;
-      int64_t pa_n = 0, pe_n = 0;
-      double yv_n = 0.0, mv_n = 0.0;
+      // ---- requests of the batches behind this one ----
+      const uint32_t sv3 = gl ? stream_at(ub + 48 + mine_i) : 0u;
+      int64_t pa2 = 0, pe2 = 0;
+      double yv1 = 0.0, mv1 = 0.0;
       if (gl) {
-        pa_n = d.ptr[sv_n];
-        pe_n = d.ptr[sv_n + 1];
-        yv_n = d.y[sv_n];
+        pa2 = d.ptr[sv2];
+        pe2 = d.ptr[sv2 + 1];
+        yv1 = d.y[sv1];
         // (the consumers' stores of draws more than 64 back are long in L2; read past this CU's L1)
-        mv_n = __hip_atomic_load(d.M + sv_n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        mv1 = __hip_atomic_load(d.M + sv1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // the data-independent numbers of my draws at once: lane l works for my draw l % kOwn; lanes [0, kOwn) divide
+      int idx1[kOwn];
+      double val1[kOwn];
+#pragma unroll
+      for (int j = 0; j < kOwn; ++j) {
+        const int64_t a = readlane_ll(pa1, j), e = readlane_ll(pe1, j);
+        idx1[j] = 0;
+        val1[j] = 0.0;
+        if (a + lane < e) {
+          idx1[j] = d.idx[a + lane];
+          val1[j] = d.val[a + lane];
+        }
+      }
+      // ---- the data-independent numbers of my draws at once: lane l works for my draw l % kOwn; lanes [0, kOwn) divide
       // gamma by w_scale before the draw, [kOwn, 2 kOwn) gamma by w_scale after it, [2 kOwn, 3 kOwn) the SAGA
-      // step's threshold by the latter
+      // step's threshold by the latter ----
       double Wb = W, Wa = W;
       double Wnext = W;
       unsigned itnext = itp;
@@ -1228,41 +1253,24 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       }
       const int kind = lane / kOwn;
       const double quot = (kind == 2 ? bg_ls1 : gamma) / (kind == 0 ? Wb : Wa);
-      for (int l0 = 0; l0 < kOwn && !stop; l0 += kProdRows) {
-        int idx4[kProdRows];
-        double val4[kProdRows];
-        int64_t a4[kProdRows], e4[kProdRows];
+      // ---- the slots of this batch ----
 #pragma unroll
-        for (int j = 0; j < kProdRows; ++j) {
-          a4[j] = readlane_ll(pa, l0 + j);
-          e4[j] = readlane_ll(pe, l0 + j);
-          idx4[j] = 0;
-          val4[j] = 0.0;
-          if (a4[j] + lane < e4[j]) {
-            idx4[j] = d.idx[a4[j] + lane];
-            val4[j] = d.val[a4[j] + lane];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < kProdRows; ++j) {
-          const int64_t u = ub + (int64_t)(l0 + j) * kProd + q;
-          if (u >= total || stop) break;
-          const int slot = (int)(u & (kRing - 1));
-          if (u >= kRing && !wait_ge(readslot + slot, (unsigned long long)(u - kRing + 1))) {
-            stop = true;
-            break;
-          }
-          const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)sv, l0 + j);
-          const double y_u = readlane_d(yv, l0 + j), m_u = readlane_d(mv, l0 + j);
-          const int64_t rlen = e4[j] - a4[j];
+      for (int j = 0; j < kOwn; ++j) {
+        const int64_t u = ub + (int64_t)j * kProd + q;
+        const int slot = (int)(u & (kRing - 1));
+        if (u < total && !stop && u >= kRing && !wait_ge(readslot + slot, (unsigned long long)(u - kRing + 1))) stop = true;
+        if (u < total && !stop) {
+          const int64_t a_u = readlane_ll(pa0, j), e_u = readlane_ll(pe0, j);
+          const uint32_t s_u = (uint32_t)__builtin_amdgcn_readlane((int)sv0, j);
+          const double y_u = readlane_d(yv0, j), m_u = readlane_d(mv0, j);
+          const int64_t rlen = e_u - a_u;
           const int len_u = (int)(rlen < (int64_t)(kWave + 1) ? rlen : (int64_t)(kWave + 1));
-          const double W_u = readlane_d(Wb, l0 + j), Wp_u = readlane_d(Wa, l0 + j);
-          const double qp_u = readlane_d(quot, l0 + j), qt_u = readlane_d(quot, kOwn + l0 + j),
-                       tau1_u = readlane_d(quot, 2 * kOwn + l0 + j);
-          ridx[slot * kWave + lane] = idx4[j];
-          rval[slot * kWave + lane] = val4[j];
+          const double W_u = readlane_d(Wb, j), Wp_u = readlane_d(Wa, j);
+          const double qp_u = readlane_d(quot, j), qt_u = readlane_d(quot, kOwn + j), tau1_u = readlane_d(quot, 2 * kOwn + j);
+          ridx[slot * kWave + lane] = idx0[j];
+          rval[slot * kWave + lane] = val0[j];
           double hv = __longlong_as_double(((long long)len_u << 32) | (long long)s_u);
-          hv = lane == 1 ? __longlong_as_double(a4[j]) : hv;
+          hv = lane == 1 ? __longlong_as_double(a_u) : hv;
           hv = lane == 2 ? y_u : hv;
           hv = lane == 3 ? m_u : hv;
           hv = lane == 4 ? W_u : hv;
@@ -1270,7 +1278,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
           hv = lane == 6 ? qp_u : hv;
           hv = lane == 7 ? qt_u : hv;
           hv = lane == 8 ? tau1_u : hv;
-          hv = lane == 9 ? __longlong_as_double(e4[j]) : hv;
+          hv = lane == 9 ? __longlong_as_double(e_u) : hv;
           if (lane < kSlotHdr) rhdr[slot * kSlotHdr + lane] = hv;
           lanes_publish();
           if (lane == 0) filled[slot] = (unsigned long long)(u + 1);
@@ -1278,12 +1286,20 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       }
       W = Wnext;
       itp = itnext;
-      sv = sv_n;
-      sv_n = sv_nn;
-      pa = pa_n;
-      pe = pe_n;
-      yv = yv_n;
-      mv = mv_n;
+      sv0 = sv1;
+      sv1 = sv2;
+      sv2 = sv3;
+      pa0 = pa1;
+      pe0 = pe1;
+      pa1 = pa2;
+      pe1 = pe2;
+      yv0 = yv1;
+      mv0 = mv1;
+#pragma unroll
+      for (int j = 0; j < kOwn; ++j) {
+        idx0[j] = idx1[j];
+        val0[j] = val1[j];
+      }
     }
     return;
   }
