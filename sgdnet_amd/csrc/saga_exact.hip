@@ -1547,6 +1547,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
           lag[jf] = it + 1u;
         }
       }
+      lanes_publish();                                               // (the compiler keeps the stores above above)
       if (lane == 0) d.M[s] = g;                                     // the youngest store of the draw (see vmcnt(1) above)
       u_prev = u;
     }
