@@ -1073,10 +1073,7 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
 // w_scale below SMALL and rescales w (the producers know which: the sequence of w_scale does not depend on the data).
 // Every wait loop gives up after kK1xSpinLimit polls or when another wavefront has raised the abort flag.
 // --------------------------------------------------------------------------
-#ifndef K1M_CONS
-#define K1M_CONS 6
-#endif
-constexpr int kCons = K1M_CONS;
+constexpr int kCons = 6;                // consumer wavefronts (8 and 10 measured slower: the draws meet in the chain)
 constexpr int kProd = 2;               // producer wavefronts: draw i of a batch of sixteen belongs to producer i % kProd
 constexpr int kDepSlots = 16384;
 constexpr int kK1mCtrl = 8;         // produced, registered, chain_done, stop/abort, barrier count, converged, epochs, spare
@@ -2614,11 +2611,6 @@ __global__ __launch_bounds__(2 * kWave) void saga_dense_exact_small2_kernel(Saga
       double m_old = m_n;
       if (u + 1 < total) read_slot(u + 1);
       if (stalled) break;
-#ifdef SM2_Z
-      if (x == 1.2345e300) w += y_cur + Wb + Wa + f + tau + m_old + (double)s;
-      W_end = Wa;
-      continue;
-#endif
       // gradient memory: a draw of the same sample among the last 32 supersedes the producer's copy
       const int r0 = (int)(u & 31);
       {
