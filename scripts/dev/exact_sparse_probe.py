@@ -9,7 +9,8 @@ from test_gpu_parity import make_problem
 
 for family, K, n, p, dens, epochs, reg in [(f, K, n, p, dn, e, r) for (f, K, n, p, dn, e) in (
         ("binomial", 1, 20000, 200, 0.05, 3), ("gaussian", 1, 20000, 1000, 0.03, 3), ("binomial", 1, 200000, 10000, 0.001, 2),
-        ("binomial", 1, 100000, 50000, 0.0002, 2), ("multinomial", 3, 20000, 200, 0.05, 3)) for r in ((0, 1, 3, 4) if K == 1 else (0,))]:
+        ("binomial", 1, 100000, 50000, 0.0002, 2), ("multinomial", 3, 20000, 200, 0.05, 3), ("multinomial", 3, 100000, 10000, 0.001, 2),
+        ("multinomial", 10, 100000, 20000, 0.0005, 2), ("mgaussian", 4, 100000, 10000, 0.001, 2)) for r in ((0, 1, 3, 4) if K == 1 else (0, 1))]:
     sa.set_option("exact_row_registers", reg)
     x, y = make_problem(family, K, n, p, dens, seed=2)
     S = sa.SagaSolver(x, y, family=family, n_classes=K)

@@ -177,6 +177,10 @@ size_t sparse_exact_lds_bytes(const SagaDev& d, bool stage_state);
 bool sparse_exact_k1_eligible(const SagaDev& d);
 size_t sparse_exact_k1_lds_bytes(const SagaDev& d, int64_t nit, bool allow_stage, int* ls_cache, int* stage_state);
 int launch_sparse_exact_k1(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st);
+bool sparse_exact_mc_eligible(const SagaDev& d);
+size_t sparse_exact_mc_lds_bytes();
+int sparse_exact_mc_wavefronts();
+int launch_sparse_exact_mc(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, hipStream_t st);
 size_t sparse_exact_k1m_lds_bytes(int64_t nit, int* ls_cache);
 int sparse_exact_k1m_consumers();
 int launch_sparse_exact_k1m(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st);

@@ -1613,6 +1613,357 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
 }
 
 // --------------------------------------------------------------------------
+// Any number of classes up to 64, rows of any length (round 3): the general iteration of saga_sparse_exact_kernel run
+// by kMc wavefronts at once, draw t on wavefront t % kMc, under the protocol of the kernel above -- registration of a
+// draw's features AND of its sample in draw order (two stamp tables), completion flags, the intercepts handed on in
+// draw order.  No producers: every wavefront keeps the general kernel's own pipeline of requests for its next draw,
+// kMc draws ahead.  The state stays in memory; a wavefront invalidates the L1 once it may touch the state of a draw
+// (buffer_inv sc1: the other wavefronts of this CU wrote it) and publishes a draw as complete when all its stores are
+// acknowledged.  What is serial: the turn at registration (two LDS round trips) and, in draw order, intercept ->
+// linear predictor -> gradient -> intercept; catch-up, the x.w sums, AddWeighted, the SAGA step and the gradient
+// averages of different draws overlap.  w_scale does not depend on the data, so every wavefront steps its own copy
+// kMc draws at a time; the draw that finds it below SMALL rescales w alone, as above.
+// --------------------------------------------------------------------------
+constexpr int kMc = 8;
+constexpr int kMcDep = 16384;        // feature stamps
+constexpr int kMcSam = 8192;         // sample stamps
+constexpr int kMcScratch = 3 * kWave;   // doubles per wavefront: slp[64], sgc[64], sval[64] (+ sidx[64] ints behind them)
+constexpr size_t kMcFixedLds = sizeof(double) * ((size_t)kMc * kMcScratch + 2 * kWave + kLsCache + 2) + sizeof(int) * (kMc * kWave) +
+                               sizeof(unsigned long long) * (8 + kWave) + sizeof(unsigned) * (kMcDep + kMcSam);
+
+__global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaDev d, const LamParams* lamp, ExactCtl ctl) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1);
+  const int c = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int T = kMc * kWave;
+  const int K = d.K;
+  const int64_t p = d.p;
+  const int64_t KP = (int64_t)K * p;
+  SGD_LDS(double)* scratch = (SGD_LDS(double)*)smem;                          // [kMc][kMcScratch]
+  SGD_LDS(double)* sb = scratch + kMc * kMcScratch;                           // [kWave]: intercepts (the chain)
+  SGD_LDS(double)* sgb = sb + kWave;                                          // [kWave]: g_sum_intercept
+  SGD_LDS(double)* sls = sgb + kWave;                                         // [kLsCache]
+  SGD_LDS(double)* wend = sls + kLsCache;                                     // [2]: w_scale as the epoch's last draw leaves it
+  SGD_LDS(int)* sidx_all = (SGD_LDS(int)*)(wend + 2);                         // [kMc][kWave]
+  // registered, chain_done, abort, barrier count, converged, alone stamp, spare, spare
+  volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(sidx_all + kMc * kWave);
+  volatile SGD_LDS(unsigned long long)* done_slot = ctrl + 8;                 // [kWave]
+  SGD_LDS(unsigned)* lastw = (SGD_LDS(unsigned)*)(done_slot + kWave);         // [kMcDep]
+  SGD_LDS(unsigned)* lasts = lastw + kMcDep;                                  // [kMcSam]
+  SGD_LDS(double)* slp = scratch + c * kMcScratch;
+  SGD_LDS(double)* sgc = slp + kWave;
+  SGD_LDS(double)* sval = sgc + kWave;
+  SGD_LDS(int)* sidx = sidx_all + c * kWave;
+  double* w = d.w;
+  double* G = d.G;
+  unsigned* lag = d.lag;
+  const unsigned nit = (unsigned)ctl.nit;
+  const double* LS = ctl.LS;
+  for (int i = tid; i < kLsCache && i <= (int64_t)nit; i += T) sls[i] = LS[i];
+  for (int i = tid; i < kMcDep; i += T) lastw[i] = 0u;
+  for (int i = tid; i < kMcSam; i += T) lasts[i] = 0u;
+  if (tid < 8) ctrl[tid] = 0ull;
+  if (tid < kWave) {
+    done_slot[tid] = 0ull;
+    sb[tid] = tid < K ? d.b[tid] : 0.0;
+    sgb[tid] = tid < K ? d.gb[tid] : 0.0;
+  }
+  for (int64_t j = tid; j < p; j += T) lag[j] = 0u;                   // saga-sparse.h:225
+  for (int64_t i = tid; i < KP; i += T) d.w_prev[i] = w[i];           // :251
+  __syncthreads();                                                    // the last barrier all wavefronts meet
+
+  auto ls_at = [&](unsigned m) -> double {
+    double v = sls[m < (unsigned)kLsCache ? m : 0u];
+    if (m >= (unsigned)kLsCache) v = LS[m];
+    return v;
+  };
+  auto aborted = [&]() -> bool { return ctrl_load(ctrl + 2) != 0ull; };
+  auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* cnt, unsigned long long target, bool eager) -> bool {
+    unsigned spins = 0;
+    for (;;) {
+      const unsigned long long now = ctrl_load(cnt);
+      if (now >= target) break;
+      if ((spins & 15u) == 15u && aborted()) return false;
+      if (++spins > kK1xSpinLimit) {
+        if (lane == 0) ctrl[2] = 2ull;
+        return false;
+      }
+      if (!(eager && now + 1ull >= target)) __builtin_amdgcn_s_sleep(1);
+    }
+    return true;
+  };
+  unsigned long long bar_target = 0ull;
+  bool ok = true;
+  auto meet = [&]() {
+    lanes_publish();
+    bar_target += kMc;
+    if (lane == 0) __hip_atomic_fetch_add((SGD_LDS(unsigned long long)*)(ctrl + 3), 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ok) ok = wait_ge(ctrl + 3, bar_target, false);
+    lanes_publish();
+  };
+
+  const int penalty = lamp->penalty;
+  const double gamma = lamp->gamma, alpha = lamp->alpha, beta = lamp->beta;
+  const double wscale_update = 1.0 - alpha * gamma;                  // :234
+  const double n_d = d.n_total, rn_d = 1.0 / n_d;
+  const int64_t t0 = ctl.stream_off;
+  const int64_t t_last = ctl.stream_off + (int64_t)ctl.max_epochs * nit - 1;
+  auto clampt = [&](int64_t x) { return x < t_last ? x : t_last; };
+
+  unsigned it_outer = 0;
+  int converged = 0;
+  int64_t base = 0;                   // draws before this epoch
+  int64_t u_prev = -1;                // my last draw, complete but not published as such
+  do {
+    // my own pipeline of requests, kMc draws apart: stream entry two of my draws ahead, row pointers and row one ahead
+    int64_t tm = t0 + base + c;                                       // stream position of my draw in hand
+    uint32_t s1 = d.stream[clampt(tm)], s2 = d.stream[clampt(tm + kMc)];
+    int64_t q0_1 = d.ptr[s1], q1_1 = d.ptr[s1 + 1];
+    int idx_1 = 0;
+    double val_1 = 0.0;
+    if (q0_1 + lane < q1_1) {
+      idx_1 = d.idx[q0_1 + lane];
+      val_1 = d.val[q0_1 + lane];
+    }
+    double y_1 = lane < d.Ky ? d.y[(int64_t)s1 * d.Ky + lane] : 0.0;
+    double wscale = 1.0;                                              // :227; before draw 0 of the epoch
+    unsigned ws_it = 0;                                               // the draw `wscale` stands before
+    for (unsigned it = (unsigned)c; it < nit && ok; it += kMc, tm += kMc) {
+      const int64_t u = base + it;
+      // ---- rotate the pipeline ----
+      const uint32_t s = s1;                                          // :261
+      const int64_t q0 = q0_1, q1 = q1_1;
+      const int idx_c = idx_1;
+      const double val_c = val_1;
+      const double y_c = y_1;
+      s1 = s2;
+      s2 = d.stream[clampt(tm + 2 * kMc)];
+      q0_1 = d.ptr[s1];
+      q1_1 = d.ptr[s1 + 1];
+      idx_1 = 0;
+      val_1 = 0.0;
+      if (q0_1 + lane < q1_1) {
+        idx_1 = d.idx[q0_1 + lane];
+        val_1 = d.val[q0_1 + lane];
+      }
+      y_1 = lane < d.Ky ? d.y[(int64_t)s1 * d.Ky + lane] : 0.0;
+      // ---- w_scale before this draw: the data-independent sequence, stepped from where my last draw left it ----
+      for (; ws_it < it; ++ws_it) {
+        if (wscale < kSmall) wscale = 1.0;                            // (the draw that found it there rescaled w)
+        wscale *= wscale_update;
+      }
+      const bool rescale = wscale < kSmall;
+      const bool mine = q0 + lane < q1;                               // this lane holds entry q0 + lane
+      // ---- registration, in draw order: features, sample, and whether the draw runs alone ----
+      if (!(ok = wait_ge(ctrl + 0, (unsigned long long)u, false))) break;
+      unsigned prev = 0u;
+      for (int64_t q = q0 + lane; q < q1; q += kWave) {
+        const int hsl = (q < q0 + kWave ? idx_c : d.idx[q]) & (kMcDep - 1);
+        const unsigned o = lastw[hsl];
+        prev = o > prev ? o : prev;
+      }
+      const unsigned prev_s = lasts[s & (kMcSam - 1)];
+      prev = prev_s > prev ? prev_s : prev;
+      const unsigned alone_before = (unsigned)ctrl_load(ctrl + 5);
+      prev = alone_before > prev ? alone_before : prev;
+      if (rescale) prev = it;
+      lanes_publish();
+      for (int64_t q = q0 + lane; q < q1; q += kWave) lastw[(q < q0 + kWave ? idx_c : d.idx[q]) & (kMcDep - 1)] = it + 1u;
+      if (lane == 0) {
+        lasts[s & (kMcSam - 1)] = it + 1u;
+        if (rescale) ctrl[5] = (unsigned long long)(it + 1u);
+      }
+      lanes_publish();
+      if (lane == 0) ctrl[0] = (unsigned long long)(u + 1);
+      // ---- my previous draw is complete once its stores are acknowledged ----
+      wave_mem_sync();
+      if (u_prev >= 0 && lane == 0) done_slot[u_prev & (kWave - 1)] = (unsigned long long)(u_prev + 1);
+      // ---- draws in flight that hold one of my features or my sample ----
+      {
+        unsigned need = prev;
+        for (int off = 32; off > 0; off >>= 1) {
+          const unsigned o = (unsigned)__shfl_xor((int)need, off, kWave);
+          need = o > need ? o : need;
+        }
+        need = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
+        if (need != 0u) {
+          const unsigned v_it = need - 1u;
+          const unsigned lo = it + 1u > (unsigned)kMc ? it + 1u - (unsigned)kMc : 0u;
+          for (unsigned dd = lo; dd <= v_it && dd < it && ok; ++dd)
+            ok = wait_ge(done_slot + ((base + dd) & (kWave - 1)), (unsigned long long)(base + dd + 1), false);
+          if (!ok) break;
+        }
+      }
+      asm volatile("buffer_inv sc1" ::: "memory");                    // the state other wavefronts of this CU stored
+      const double m_c = lane < K ? d.M[lane + (int64_t)s * K] : 0.0;
+      if (mine && lane < kWave) {
+        sidx[lane] = idx_c;
+        sval[lane] = val_c;
+      }
+
+      // LaggedUpdate(it_inner): catch-up of the sample's features  :263-272
+      const double q_before = gamma / wscale;
+      if (mine) {
+        const int64_t j = idx_c;
+        const unsigned lagged = it - lag[j];
+        if (lagged != 0) {
+          penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_before, gamma, beta);
+          lag[j] = it;
+        }
+      }
+      for (int64_t q = q0 + kWave + lane; q < q1; q += kWave) {
+        const int64_t j = d.idx[q];
+        const unsigned lagged = it - lag[j];
+        if (lagged != 0) {
+          penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_before, gamma, beta);
+          lag[j] = it;
+        }
+      }
+      wave_mem_sync();
+      asm volatile("buffer_inv sc1" ::: "memory");                    // (my own stores, read back by other lanes)
+
+      // x.w per class, ascending feature order  :274 -- everything of the linear predictor but the intercept
+      const int head = (q1 - q0) < kWave ? (int)(q1 - q0) : kWave;
+      double acc = 0.0;
+      if (lane < K) {
+        for (int e = 0; e < head; ++e) acc += sval[e] * w[lane + (int64_t)sidx[e] * K];
+        for (int64_t q = q0 + kWave; q < q1; ++q) acc += d.val[q] * w[lane + (int64_t)d.idx[q] * K];
+      }
+
+      // ---- the chain, in draw order: intercept -> linear predictor -> gradient -> intercept  :274-304 ----
+      if (!(ok = wait_ge(ctrl + 1, (unsigned long long)u, true))) break;
+      lanes_publish();
+      if (lane < K) slp[lane] = acc * wscale + sb[lane];
+      lanes_publish();
+      const double y_first = __shfl(y_c, 0, kWave);
+      double g = 0.0;
+      if (d.family == SGDNET_MULTINOMIAL) {
+        g = softmax_gradient_lanes(lane < K ? slp[lane] : 0.0, K, lane, y_first);
+      } else if (lane < K) {
+        if (d.family == SGDNET_MGAUSSIAN)
+          g = slp[lane] - y_c;
+        else
+          g = family_gradient_k(d.family, K, lane, slp, &y_first);
+      }
+      if (lane < K) {
+        sgc[lane] = g - m_c;
+        d.M[lane + (int64_t)s * K] = g;
+      }
+      if (rescale) {
+        // rescale + unlag  :285-295: every earlier draw is complete, every later one waits for this one
+        wave_mem_sync();
+        asm volatile("buffer_inv sc1" ::: "memory");
+        for (int64_t j = lane; j < p; j += kWave) {
+          const unsigned lagged = it - lag[j];
+          if (lagged != 0) penalty_apply(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), gamma, beta);
+          for (int k = 0; k < K; ++k) w[k + j * K] *= wscale;
+          lag[j] = it;
+        }
+        wscale = 1.0;
+        wave_mem_sync();
+        asm volatile("buffer_inv sc1" ::: "memory");
+      }
+      wscale *= wscale_update;                                       // :297
+      ws_it = it + 1u;
+      const double q_after = gamma / wscale;
+      if (it + 1u == nit && lane == 0) wend[0] = wscale;             // Reset(n_samples) finds w_scale here
+      lanes_publish();
+      if (d.fit_intercept && lane < K) {                             // :300-304
+        const double gck = div_by_n_exact(sgc[lane], n_d, rn_d);
+        const double gbk = sgb[lane] + gck;
+        sgb[lane] = gbk;
+        sb[lane] -= gamma * (gbk * 0.01 + gck);
+      }
+      lanes_publish();
+      if (lane == 0) ctrl[1] = (unsigned long long)(u + 1);
+
+      // AddWeighted(w, ..., -gamma/wscale)  :306-313
+      {
+        const double scaling = -q_after;
+        if (mine) {
+          const int64_t j = idx_c;
+          for (int k = 0; k < K; ++k) w[k + j * K] += val_c * sgc[k] * scaling;
+        }
+        for (int64_t q = q0 + kWave + lane; q < q1; q += kWave) {
+          const int64_t j = d.idx[q];
+          const double v = d.val[q];
+          for (int k = 0; k < K; ++k) w[k + j * K] += v * sgc[k] * scaling;
+        }
+      }
+      // LaggedUpdate(it_inner + 1): the SAGA step  :316-325, then AddWeighted(g_sum, ..., 1/n)  :328-335
+      {
+        const double scaling = 1.0 / n_d;
+        if (mine) {
+          const int64_t j = idx_c;
+          const unsigned lagged = (it + 1) - lag[j];
+          if (lagged != 0) {
+            penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_after, gamma, beta);
+            lag[j] = it + 1;
+          }
+          for (int k = 0; k < K; ++k) G[k + j * K] += val_c * sgc[k] * scaling;
+        }
+        for (int64_t q = q0 + kWave + lane; q < q1; q += kWave) {
+          const int64_t j = d.idx[q];
+          const unsigned lagged = (it + 1) - lag[j];
+          if (lagged != 0) {
+            penalty_apply_q(penalty, K, w + j * K, G + j * K, wscale, ls_at(lagged), q_after, gamma, beta);
+            lag[j] = it + 1;
+          }
+          const double v = d.val[q];
+          for (int k = 0; k < K; ++k) G[k + j * K] += v * sgc[k] * scaling;
+        }
+      }
+      u_prev = u;
+    }
+    // my last draw of the epoch
+    wave_mem_sync();
+    if (u_prev >= 0 && lane == 0) done_slot[u_prev & (kWave - 1)] = (unsigned long long)(u_prev + 1);
+    u_prev = -1;
+    meet();                                                          // every draw of the epoch is in memory
+    if (!ok) break;
+    // Reset(n_samples): unlag and rescale  :340-348 (features dealt round robin to the wavefronts)
+    {
+      const double W_end = wend[0];
+      asm volatile("buffer_inv sc1" ::: "memory");
+      for (int64_t j = (int64_t)c * kWave + lane; j < p; j += kMc * kWave) {
+        const unsigned lagged = nit - lag[j];
+        if (lagged != 0) penalty_apply(penalty, K, w + j * K, G + j * K, W_end, ls_at(lagged), gamma, beta);
+        for (int k = 0; k < K; ++k) w[k + j * K] *= W_end;
+        lag[j] = 0u;
+      }
+      for (int i = c * kWave + lane; i < kMcDep; i += kMc * kWave) lastw[i] = 0u;
+      for (int i = c * kWave + lane; i < kMcSam; i += kMc * kWave) lasts[i] = 0u;
+      if (c == 0 && lane == 0) ctrl[5] = 0ull;
+    }
+    wave_mem_sync();
+    meet();
+    if (!ok) break;
+    ++it_outer;
+    if (c == 0) {
+      asm volatile("buffer_inv sc1" ::: "memory");
+      const int conv = convergence_check(w, d.w_prev, KP, ctl.tol, lane);    // :367
+      if (lane == 0) ctrl[4] = (unsigned long long)conv;
+    }
+    meet();
+    if (!ok) break;
+    converged = (int)ctrl_load(ctrl + 4);
+    base += nit;
+  } while (!converged && it_outer < ctl.max_epochs);                 // :371
+
+  if (c == 0) {
+    for (int k = lane; k < K; k += kWave) {
+      d.b[k] = sb[k];
+      d.gb[k] = sgb[k];
+    }
+    if (lane == 0) {
+      ctl.out[0] = (int)it_outer;
+      ctl.out[1] = (!ok || ctrl_load(ctrl + 2) == 2ull) ? -2 : converged;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // Dense variant: no lag, all-feature penalty every iteration (saga-dense.h:179-180),
 // intercept without the 0.01 decay (:170-173).  Lanes stride the features for
 // the three O(pK) passes; lane k owns class k.
@@ -2846,6 +3197,16 @@ int sparse_exact_k1m_consumers() { return kCons; }
 
 int launch_sparse_exact_k1m(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes, hipStream_t st) {
   return launch_k1_t(saga_sparse_exact_k1m_kernel, (kCons + kProd) * kWave, d, lam, ctl, lds_bytes, st);
+}
+
+// The multi-wavefront general kernel: up to 64 classes, explicit x.
+bool sparse_exact_mc_eligible(const SagaDev& d) {
+  return d.K <= kWave && d.Ky <= kWave && !d.standardize && d.ptr && d.idx && d.val;
+}
+size_t sparse_exact_mc_lds_bytes() { return (kMcFixedLds + 15) & ~size_t(15); }
+int sparse_exact_mc_wavefronts() { return kMc; }
+int launch_sparse_exact_mc(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, hipStream_t st) {
+  return launch_k1_t(saga_sparse_exact_mc_kernel, kMc * kWave, d, lam, ctl, sparse_exact_mc_lds_bytes(), st);
 }
 
 int launch_sparse_exact(const SagaDev& d, const LamParams* lam, const ExactCtl& ctl, size_t lds_bytes,

@@ -39,12 +39,44 @@ def run(sa, po, x, y, *, family, K, penalty, gamma, alpha, beta, epochs, fit_int
 @pytest.mark.parametrize("dense", [False, True])
 def test_exact_kernels_are_bit_identical_to_the_det_oracle(sa, det, family, K, penalty, dense):
     from test_gpu_parity import make_problem
+    if not dense:
+        sa.set_option("exact_row_registers", 3)     # sparse x: the multi-wavefront kernels wherever they are legal
     if dense:
         x, y = make_problem(family, K, 900, 12 if K <= 3 else 6, None, seed=2, dense=True)   # K*p <= 64: the small kernel
     else:
         x, y = make_problem(family, K, 1500, 80, 0.06, seed=2)
     a, b = (1e-3, 0.0) if penalty == "ridge" else (5e-4, 5e-4)
-    ref, got = run(sa, det, x, y, family=family, K=K, penalty=penalty, gamma=0.05, alpha=a, beta=b, epochs=4)
+    try:
+        ref, got = run(sa, det, x, y, family=family, K=K, penalty=penalty, gamma=0.05, alpha=a, beta=b, epochs=4)
+    finally:
+        sa.set_option("exact_row_registers", 1)
+    assert ref[0] == got[0]
+    for name in STATE:
+        assert np.array_equal(got[2][name], ref[2][name]), name
+
+
+MULTI_CLASS_CASES = {
+    # name: (family, K, penalty, n, p, density or row lengths, gamma, alpha, beta, epochs)
+    "multinomial_many_features": ("multinomial", 3, "elasticnet", 6000, 4000, 0.002, 0.05, 1e-4, 2e-4, 3),
+    "multinomial_ten_classes": ("multinomial", 10, "ridge", 3000, 2500, 0.004, 0.05, 1e-3, 0.0, 3),
+    "mgaussian_group_lasso": ("mgaussian", 4, "grouplasso", 3000, 2000, 0.004, 0.03, 1e-4, 3e-4, 3),
+    "multinomial_crowded": ("multinomial", 4, "elasticnet", 900, 20, 0.4, 0.05, 5e-4, 5e-4, 3),
+    "multinomial_scale_reset": ("multinomial", 3, "elasticnet", 1200, 300, 0.03, 0.3, 1.0, 1e-3, 2),
+}
+
+
+@pytest.mark.parametrize("case", sorted(MULTI_CLASS_CASES))
+@pytest.mark.parametrize("registers", [0, 1, 3])
+def test_multi_wavefront_general_kernel_is_bit_identical(sa, det, case, registers):
+    """Round 3: `saga_sparse_exact_mc_kernel` (the general iteration on eight wavefronts at once: features and sample of
+    a draw registered in draw order, the intercepts handed on in draw order) against the det-math restatement -- equal,
+    like the one-wavefront kernel (0); 1: where the host expects it to pay, 3: wherever legal (crowded rows, the
+    mid-epoch rescaling)."""
+    from test_gpu_parity import make_problem
+    family, K, penalty, n, p, dens, gamma, alpha, beta, epochs = MULTI_CLASS_CASES[case]
+    x, y = make_problem(family, K, n, p, dens, seed=13)
+    with sa.option("exact_row_registers", registers):
+        ref, got = run(sa, det, x, y, family=family, K=K, penalty=penalty, gamma=gamma, alpha=alpha, beta=beta, epochs=epochs)
     assert ref[0] == got[0]
     for name in STATE:
         assert np.array_equal(got[2][name], ref[2][name]), name
