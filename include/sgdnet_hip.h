@@ -172,7 +172,8 @@ int sgdnet_device_count(void);
 /*                        coefficients in registers for the whole draw and   */
 /*                        requests the next draw's a draw ahead (same bits,  */
 /*                        DESIGN.md 4.1), with several consumer wavefronts   */
-/*                        where draws seldom share a feature; 0: the general */
+/*                        where draws seldom share a feature (several classes:*/
+/*                        the general iteration on eight wavefronts); 0: the general */
 /*                        kernel; 2: one consumer, state kept in memory; 3:  */
 /*                        several consumers wherever that is legal; 4: one   */
 /*                        consumer always                                    */
