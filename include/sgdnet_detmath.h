@@ -36,14 +36,14 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SGD_EXP_TABPTR (&sgd_exp_tab[0][0])
-#define SGD_LOG_TAB(j, c) sgd_log_tab[j][c]
+#define SGD_LOG_TABPTR (&sgd_log_tab[0][0])
 #elif defined(__HIPCC__)
 /* host pass of a HIP translation unit: the tables are device symbols; the host copies are not needed there */
 #define SGD_EXP_TABPTR ((const double*)0)
-#define SGD_LOG_TAB(j, c) 0.0
+#define SGD_LOG_TABPTR ((const double*)0)
 #else
 #define SGD_EXP_TABPTR (&sgd_exp_tab[0][0])
-#define SGD_LOG_TAB(j, c) sgd_log_tab[j][c]
+#define SGD_LOG_TABPTR (&sgd_log_tab[0][0])
 #endif
 
 SGD_DM_FN uint64_t sgd_d2u(double x) {
@@ -89,28 +89,34 @@ SGD_DEFINE_EXP(sgd_exp_from, const double*)
 
 SGD_DM_FN double sgd_exp(double x) { return sgd_exp_from(x, SGD_EXP_TABPTR); }
 
-SGD_DM_FN double sgd_log(double x) {
-  if (x != x) return x;
-  if (x < 0.0) return sgd_u2d(0x7ff8000000000000ull);                      /* NaN */
-  if (x == 0.0) return sgd_u2d(0xfff0000000000000ull);                     /* -inf */
-  uint64_t u = sgd_d2u(x);
-  if (u == 0x7ff0000000000000ull) return x;
-  int m = 0;
-  if ((u >> 52) == 0) {                                                    /* subnormal: scale up */
-    x *= 18014398509481984.0;                                              /* 2^54 */
-    u = sgd_d2u(x);
-    m = -54;
-  }
-  m += (int)(u >> 52) - 1023;
-  const double Y = sgd_u2d((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);   /* [1, 2) */
-  const int j = (int)((Y - 1.0) * 128.0 + 0.5);                            /* 0..128 */
-  const double F = 1.0 + (double)j * 0.0078125;
-  const double f = Y - F;                                                  /* exact */
-  const double uu = (f + f) / (Y + F);
-  const double v = uu * uu;
-  const double q = uu * v * (0.08333333333333333 + v * (0.0125 + v * 0.002232142857142857));
-  const double md = (double)m;
-  return (md * SGD_LN2_HI + SGD_LOG_TAB(j, 0)) + (uu + (q + (md * SGD_LN2_LO + SGD_LOG_TAB(j, 1))));
+/* `tab`: sgd_log_tab as 258 consecutive doubles, or a copy of it under the kernel's pointer type (see SGD_DEFINE_EXP) */
+#define SGD_DEFINE_LOG(NAME, TABPTR_T) \
+SGD_DM_FN double NAME(double x, TABPTR_T tab) { \
+  if (x != x) return x; \
+  if (x < 0.0) return sgd_u2d(0x7ff8000000000000ull);                      /* NaN */ \
+  if (x == 0.0) return sgd_u2d(0xfff0000000000000ull);                     /* -inf */ \
+  uint64_t u = sgd_d2u(x); \
+  if (u == 0x7ff0000000000000ull) return x; \
+  int m = 0; \
+  if ((u >> 52) == 0) {                                                    /* subnormal: scale up */ \
+    x *= 18014398509481984.0;                                              /* 2^54 */ \
+    u = sgd_d2u(x); \
+    m = -54; \
+  } \
+  m += (int)(u >> 52) - 1023; \
+  const double Y = sgd_u2d((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull);   /* [1, 2) */ \
+  const int j = (int)((Y - 1.0) * 128.0 + 0.5);                            /* 0..128 */ \
+  const double F = 1.0 + (double)j * 0.0078125; \
+  const double f = Y - F;                                                  /* exact */ \
+  const double uu = (f + f) / (Y + F); \
+  const double v = uu * uu; \
+  const double q = uu * v * (0.08333333333333333 + v * (0.0125 + v * 0.002232142857142857)); \
+  const double md = (double)m; \
+  return (md * SGD_LN2_HI + tab[2 * j]) + (uu + (q + (md * SGD_LN2_LO + tab[2 * j + 1]))); \
 }
+SGD_DEFINE_LOG(sgd_log_from, const double*)
+
+SGD_DM_FN double sgd_log(double x) { return sgd_log_from(x, SGD_LOG_TABPTR); }
+
 
 #endif

@@ -15,6 +15,8 @@
 //   saga_sparse_exact_k1m_kernel  two producers + six consumers taking the draws
 //                                 round robin; registration of a draw's features
 //                                 and the intercept chain run in draw order
+// and for several classes the general iteration runs on eight wavefronts at once
+// under the same protocol (saga_sparse_exact_mc_kernel).
 //
 // Lane roles: lanes stride the nonzeros of the drawn sample for the per-feature
 // steps; lane k owns class k for the linear predictor / gradient / intercept.
@@ -484,6 +486,28 @@ __device__ __forceinline__ double k1_soft(double x, double s, bool plain) {
 }
 
 SGD_DEFINE_EXP(sgd_exp_lds, const SGD_LDS(double)*)
+SGD_DEFINE_LOG(sgd_log_lds, const SGD_LDS(double)*)
+
+// softmax_gradient_lanes with the exp / log tables in the LDS (the same functions on copies of the same tables: the
+// same bits): in the multi-wavefront kernel the three table lookups sit on the serial path, and as global loads
+// they queue behind every request the wavefront has in flight
+__device__ __forceinline__ double softmax_gradient_lanes_lds(double lp, int K, int lane, double y_label,
+                                                             const SGD_LDS(double)* etab, const SGD_LDS(double)* ltab) {
+  const bool cls = lane < K;
+  double mx = readlane_d(lp, 0);
+  for (int kk = 1; kk < K; ++kk) {
+    const double v = readlane_d(lp, kk);
+    mx = v > mx ? v : mx;
+  }
+  const double e = sgd_exp_lds((cls ? lp : mx) - mx, etab);
+  double se = 0.0;
+  for (int kk = 0; kk < K; ++kk) se += readlane_d(e, kk);
+  const double lse = sgd_log_lds(se, ltab) + mx;
+  double g = sgd_exp_lds((cls ? lp : lse) - lse, etab);
+  if ((unsigned)lane == (unsigned)(y_label + 0.5)) g -= 1.0;
+  return g;
+}
+
 // ... and with the 64-entry table spread over the lanes of the wavefront (entry j in lane j): a lookup is four
 // v_readlane instead of an LDS round trip -- for the serial part of the multi-consumer kernel.  The argument is the
 // same in every lane there, so the index is too.
@@ -1624,11 +1648,14 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
 // averages of different draws overlap.  w_scale does not depend on the data, so every wavefront steps its own copy
 // kMc draws at a time; the draw that finds it below SMALL rescales w alone, as above.
 // --------------------------------------------------------------------------
-constexpr int kMc = 8;
+#ifndef SGD_MC_WAVES
+#define SGD_MC_WAVES 8
+#endif
+constexpr int kMc = SGD_MC_WAVES;
 constexpr int kMcDep = 16384;        // feature stamps
 constexpr int kMcSam = 8192;         // sample stamps
 constexpr int kMcScratch = 3 * kWave;   // doubles per wavefront: slp[64], sgc[64], sval[64] (+ sidx[64] ints behind them)
-constexpr size_t kMcFixedLds = sizeof(double) * ((size_t)kMc * kMcScratch + 2 * kWave + kLsCache + 2) + sizeof(int) * (kMc * kWave) +
+constexpr size_t kMcFixedLds = sizeof(double) * ((size_t)kMc * kMcScratch + 2 * kWave + kLsCache + 2 + 128 + 258) + sizeof(int) * (kMc * kWave) +
                                sizeof(unsigned long long) * (8 + kWave) + sizeof(unsigned) * (kMcDep + kMcSam);
 
 __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaDev d, const LamParams* lamp, ExactCtl ctl) {
@@ -1645,7 +1672,9 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
   SGD_LDS(double)* sgb = sb + kWave;                                          // [kWave]: g_sum_intercept
   SGD_LDS(double)* sls = sgb + kWave;                                         // [kLsCache]
   SGD_LDS(double)* wend = sls + kLsCache;                                     // [2]: w_scale as the epoch's last draw leaves it
-  SGD_LDS(int)* sidx_all = (SGD_LDS(int)*)(wend + 2);                         // [kMc][kWave]
+  SGD_LDS(double)* etab = wend + 2;                                           // [128]: sgd_exp_tab
+  SGD_LDS(double)* ltab = etab + 128;                                         // [258]: sgd_log_tab
+  SGD_LDS(int)* sidx_all = (SGD_LDS(int)*)(ltab + 258);                       // [kMc][kWave]
   // registered, chain_done, abort, barrier count, converged, alone stamp, spare, spare
   volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(sidx_all + kMc * kWave);
   volatile SGD_LDS(unsigned long long)* done_slot = ctrl + 8;                 // [kWave]
@@ -1661,6 +1690,8 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
   const unsigned nit = (unsigned)ctl.nit;
   const double* LS = ctl.LS;
   for (int i = tid; i < kLsCache && i <= (int64_t)nit; i += T) sls[i] = LS[i];
+  for (int i = tid; i < 128; i += T) etab[i] = SGD_EXP_TABPTR[i];
+  for (int i = tid; i < 258; i += T) ltab[i] = SGD_LOG_TABPTR[i];
   for (int i = tid; i < kMcDep; i += T) lastw[i] = 0u;
   for (int i = tid; i < kMcSam; i += T) lasts[i] = 0u;
   if (tid < 8) ctrl[tid] = 0ull;
@@ -1831,6 +1862,9 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
         for (int64_t q = q0 + kWave; q < q1; ++q) acc += d.val[q] * w[lane + (int64_t)d.idx[q] * K];
       }
 
+      // (what the draw leaves w_scale at, and gamma over it, do not depend on the data: formed ahead of the turn)
+      const double wscale_after = (rescale ? 1.0 : wscale) * wscale_update;          // :285-297
+      const double q_after = gamma / wscale_after;
       // ---- the chain, in draw order: intercept -> linear predictor -> gradient -> intercept  :274-304 ----
       if (!(ok = wait_ge(ctrl + 1, (unsigned long long)u, true))) break;
       lanes_publish();
@@ -1839,17 +1873,14 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
       const double y_first = __shfl(y_c, 0, kWave);
       double g = 0.0;
       if (d.family == SGDNET_MULTINOMIAL) {
-        g = softmax_gradient_lanes(lane < K ? slp[lane] : 0.0, K, lane, y_first);
+        g = softmax_gradient_lanes_lds(lane < K ? slp[lane] : 0.0, K, lane, y_first, etab, ltab);
       } else if (lane < K) {
         if (d.family == SGDNET_MGAUSSIAN)
           g = slp[lane] - y_c;
         else
           g = family_gradient_k(d.family, K, lane, slp, &y_first);
       }
-      if (lane < K) {
-        sgc[lane] = g - m_c;
-        d.M[lane + (int64_t)s * K] = g;
-      }
+      if (lane < K) sgc[lane] = g - m_c;
       if (rescale) {
         // rescale + unlag  :285-295: every earlier draw is complete, every later one waits for this one
         wave_mem_sync();
@@ -1860,13 +1891,11 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
           for (int k = 0; k < K; ++k) w[k + j * K] *= wscale;
           lag[j] = it;
         }
-        wscale = 1.0;
         wave_mem_sync();
         asm volatile("buffer_inv sc1" ::: "memory");
       }
-      wscale *= wscale_update;                                       // :297
+      wscale = wscale_after;                                         // :297
       ws_it = it + 1u;
-      const double q_after = gamma / wscale;
       if (it + 1u == nit && lane == 0) wend[0] = wscale;             // Reset(n_samples) finds w_scale here
       lanes_publish();
       if (d.fit_intercept && lane < K) {                             // :300-304
@@ -1877,6 +1906,7 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
       }
       lanes_publish();
       if (lane == 0) ctrl[1] = (unsigned long long)(u + 1);
+      if (lane < K) d.M[lane + (int64_t)s * K] = g;                  // (a draw of the same sample waits for this draw to complete)
 
       // AddWeighted(w, ..., -gamma/wscale)  :306-313
       {
