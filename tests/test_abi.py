@@ -99,3 +99,13 @@ def test_backend_options_are_the_documented_ones():
         for m in re.finditer(r'getenv\("(SGDNET_[A-Z0-9_]+)"\)', text):
             # progress printing and builds that are never shipped
             assert m.group(1) in ("SGDNET_TRACE", "SGDNET_ABLATE", "SGDNET_PHASE_DUMP"), (f, m.group(1))
+
+
+def test_graft_entry_library_check_passes():
+    """__graft_entry__.build() ends with this check; it once compared the ABI version with a literal."""
+    import importlib
+    import sys
+    sys.path.insert(0, ROOT)
+    ge = importlib.import_module("__graft_entry__")
+    ge.check_library()
+    assert "== 1" not in open(os.path.join(ROOT, "__graft_entry__.py")).read()
