@@ -282,7 +282,20 @@ __global__ __launch_bounds__(kWave) void saga_sparse_exact_kernel(SagaDev d, con
       } else
       for (int k = lane; k < K; k += kWave) {
         double acc = 0.0;
-        for (int e = 0; e < head; ++e) acc += sval[e] * w[k + (int64_t)sidx[e] * K];
+        // (the coefficients of eight entries are requested together, then added in order: one at a time, every
+        // entry paid a round trip of its own)
+        for (int e0 = 0; e0 < head; e0 += 8) {
+          double wv[8], xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ee = e0 + e < head ? e0 + e : head - 1;
+            xv[e] = sval[ee];
+            wv[e] = w[k + (int64_t)sidx[ee] * K];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e0 + e < head) acc += xv[e] * wv[e];
+        }
         for (int64_t q = q0 + kWave; q < q1; ++q) acc += d.val[q] * w[k + (int64_t)d.idx[q] * K];
         slp[k] = acc * wscale + sb[k];
       }
@@ -1858,7 +1871,20 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
       const int head = (q1 - q0) < kWave ? (int)(q1 - q0) : kWave;
       double acc = 0.0;
       if (lane < K) {
-        for (int e = 0; e < head; ++e) acc += sval[e] * w[lane + (int64_t)sidx[e] * K];
+        // (the coefficients of eight entries are requested together, then added in order: one at a time, every
+        // entry paid a round trip of its own)
+        for (int e0 = 0; e0 < head; e0 += 8) {
+          double wv[8], xv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ee = e0 + e < head ? e0 + e : head - 1;
+            xv[e] = sval[ee];
+            wv[e] = w[lane + (int64_t)sidx[ee] * K];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e0 + e < head) acc += xv[e] * wv[e];
+        }
         for (int64_t q = q0 + kWave; q < q1; ++q) acc += d.val[q] * w[lane + (int64_t)d.idx[q] * K];
       }
 
