@@ -90,7 +90,8 @@ def test_backend_options_are_the_documented_ones():
     with sa.option("virtual_shards", 4):
         assert sa.get_option("virtual_shards") == 4
     assert sa.get_option("virtual_shards") == -1
-    for name, bad in (("virtual_shards", 9), ("rng_generators", -1), ("host_setup", 2), ("no_such_option", 0)):
+    for name, bad in (("virtual_shards", 9), ("rng_generators", -1), ("host_setup", 2), ("exact_row_registers", 5),
+                      ("no_such_option", 0)):
         with pytest.raises(sa.SgdnetError):
             sa.set_option(name, bad)
     src = os.path.join(ROOT, "sgdnet_amd", "csrc")
