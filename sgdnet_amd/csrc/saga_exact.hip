@@ -1661,10 +1661,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
 // averages of different draws overlap.  w_scale does not depend on the data, so every wavefront steps its own copy
 // kMc draws at a time; the draw that finds it below SMALL rescales w alone, as above.
 // --------------------------------------------------------------------------
-#ifndef SGD_MC_WAVES
-#define SGD_MC_WAVES 8
-#endif
-constexpr int kMc = SGD_MC_WAVES;
+constexpr int kMc = 8;                  // wavefronts (12 and 16 measured: multinomial slower, mgaussian 10 % faster)
 constexpr int kMcDep = 16384;        // feature stamps
 constexpr int kMcSam = 8192;         // sample stamps
 constexpr int kMcScratch = 3 * kWave;   // doubles per wavefront: slp[64], sgc[64], sval[64] (+ sidx[64] ints behind them)
