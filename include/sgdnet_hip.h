@@ -177,6 +177,12 @@ int sgdnet_device_count(void);
 /*                        kernel; 2: one consumer, state kept in memory; 3:  */
 /*                        several consumers wherever that is legal; 4: one   */
 /*                        consumer always                                    */
+/*   "fused_epoch"        1 (default): a batched epoch on virtual shards      */
+/*                        (sparse x, one response) is ONE launch whose        */
+/*                        workgroups synchronise shard by shard; 0: one       */
+/*                        gather and one sweep launch per batch (what the     */
+/*                        library falls back to by itself when the GPU is     */
+/*                        shared and the launch cannot become resident)       */
 /* Unknown names and out-of-range values return SGDNET_EINVAL.  Options are  */
 /* read when a fit starts; changing them during a fit on another thread      */
 /* affects later fits only.                                                  */
@@ -301,7 +307,8 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
 /* Which gather kernel a batch of `batch` draws uses: 0 = saga_batch_gather_kernel (global
  * atomics), 1 = saga_batch_gather_lds_kernel (LDS-privatised scatter), 2 = the binned form
  * (saga_binned_gather_kernel + saga_binned_sweep_kernel: K x p tables that fit no LDS; valid after a
- * run / enqueue with that batch has sized its scratch). */
+ * run / enqueue with that batch has sized its scratch), 3 = the fused epoch of the virtual shards
+ * (saga_vs_epoch_kernel: gathers, sweeps and merges of a whole epoch in one launch). */
 int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch);
 
 /* 2 * sum_i Loss_i (src/utils.h:304-329) over the resident samples. */

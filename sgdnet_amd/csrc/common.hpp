@@ -39,7 +39,7 @@ inline const char* exp_env_str(const char*) { return nullptr; }
 
 // sgdnet_set_option values (solver.cpp)
 enum Option { kOptVirtualShards = 0, kOptRngGenerators, kOptWindowEigenvalue, kOptHostSetup, kOptExactEpochBlocks,
-              kOptExactRowRegisters, kOptCount };
+              kOptExactRowRegisters, kOptFusedEpoch, kOptCount };
 int option(Option o);
 
 #define SGD_HIP_TRY(expr)                                                              \
@@ -79,6 +79,10 @@ struct SagaDev {
   double* vcw;           // V: c . w of every replica (implicit centring)
   double* vd0;           // one intercept partial per gather workgroup
   double* vref;          // snapshot [g_sum | w | g_sum_b | b] the replicas started from
+  // fused epoch of the virtual shards (saga_vs_epoch_kernel): counters of its in-launch barriers, and the
+  // exchange buffer [2 parities x V published slices | V reference copies | c.w partials]
+  unsigned* vsync;
+  double* vx;
   unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
   int cu_reserve;    // CUs left to the sample-order generators that run beside the epoch (LDS gather grids shrink by it)
   int force_global;  // synchronous sharded mode: always the global-atomic gather (D must be one array)
@@ -151,10 +155,15 @@ struct LamParams {
   int64_t stream_wrap;   // > 0: the epoch's end wraps stream_base at this length (the two-epoch buffer of the sample-order pipeline)
   int64_t draws_per_epoch;
   int batch_seq;         // running batch id (claims)
+  int stream_raw;        // the epoch's slot of the sample-order pipeline holds the generators' raw words: the fused epoch
+                         // kernel turns them into draws itself (round 4; every other consumer gets a converted slot)
   // ConvergenceCheck scratch: bit patterns of max|dw| and max|w|
   unsigned long long max_change_bits;
   unsigned long long max_size_bits;
   double loss_acc;
+  // fused epoch kernel: 0 the epoch ran; 1 the launch could not become resident and changed nothing (the host
+  // runs the epoch as separate launches); 2 a wait inside the epoch timed out (the epoch is void)
+  int fused_abort;
 };
 
 struct ExactCtl {
@@ -214,6 +223,12 @@ int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream
 int launch_vs_merge(const SagaDev& d, int final_merge, hipStream_t st, LamParams* epoch_end = nullptr, int batches = 0);
 int launch_vs_cw(const SagaDev& d, hipStream_t st);
 bool vs_eligible(const SagaDev& d, int m);
+// the whole epoch of the virtual shards in ONE launch (saga_vs_epoch_kernel)
+bool vs_fused_eligible(const SagaDev& d);
+size_t vs_fused_sync_words();
+size_t vs_fused_exchange_doubles(const SagaDev& d, int n_shards);
+int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStream_t st, hipEvent_t ev0 = nullptr,
+                    hipEvent_t ev1 = nullptr);
 bool compact_eligible(const SagaDev& d);
 int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* meta, hipStream_t st);
 int compact_entries(const SagaDev& d);
@@ -233,7 +248,9 @@ int launch_range_moment(const SagaDev& d, const uint16_t* feat_range, unsigned l
 size_t binned_max_range_features(int K);
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,
-                    int gens = 1, int64_t run_len = 0);
+                    int gens = 1, int64_t run_len = 0, int convert = 1, int narrow_cus = 0);
+int launch_rng_convert(uint32_t* out, int64_t count, uint32_t n_samples, hipStream_t st, int n_shards,
+                       const double* shard_size, int64_t run_len, int narrow_cus = 0);
 
 // jump-ahead of R's Mersenne-Twister (mt_jump.cpp, r_rng_device.hip)
 bool mt_jump_poly(uint64_t J, uint32_t* out624);

@@ -11,6 +11,7 @@
 // exactly like unif_rand() and floored.  One wavefront carries the sequence (it is inherently
 // serial across blocks); the other CUs keep running SAGA.
 #include "common.hpp"
+#include "r_rng_word.hpp"
 
 namespace sgdnet {
 
@@ -21,19 +22,6 @@ constexpr int kN = 624, kM = 397;
 __device__ __forceinline__ uint32_t twist(uint32_t a, uint32_t b) {
   const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
   return (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-}
-
-// tempering + unif_rand() scaling/fixup + floor(n * u), as r_rng.cpp does on the host
-__device__ __forceinline__ uint32_t word_to_draw(uint32_t y, double n) {
-  y ^= y >> 11;
-  y ^= (y << 7) & 0x9d2c5680u;
-  y ^= (y << 15) & 0xefc60000u;
-  y ^= y >> 18;
-  const double i2_32m1 = 2.328306437080797e-10;
-  double u = (double)y * 2.3283064365386963e-10;
-  if (u <= 0.0) u = 0.5 * i2_32m1;
-  if (1.0 - u <= 0.0) u = 1.0 - 0.5 * i2_32m1;
-  return (uint32_t)floor(0.0 + (n - 0.0) * u);
 }
 
 }  // namespace
@@ -280,34 +268,74 @@ struct RngShards {
 // (64-bit integer divisions are software routines of ~100 instructions on this part, and this kernel runs on
 // whatever CUs are free between two gather launches, i.e. in front of the next one: position -> (run, shard) is a
 // multiplication with one correction step and a handful of compares.)
+// one position of the stream: the raw word -> the draw (virtual shards: of the shard that owns the position)
+__device__ __forceinline__ uint32_t convert_at(int64_t i, uint32_t word, int64_t count, double n, const RngShards& sh) {
+  if (sh.V > 1) {
+    int64_t r = 0, j = i;
+    if (sh.run < count) {
+      r = (int64_t)((double)i * sh.inv_run);
+      j = i - r * sh.run;
+      if (j < 0) {
+        --r;
+        j += sh.run;
+      } else if (j >= sh.run) {
+        ++r;
+        j -= sh.run;
+      }
+    }
+    const int64_t left = count - r * sh.run;
+    const int64_t dps = left >= sh.run ? sh.dps : left / sh.V;      // the division: in the last, shorter run only
+    if (dps > 0 && j < dps * sh.V) {
+      int v = 0;
+#pragma unroll
+      for (int q = 1; q < 8; ++q) v += (q < sh.V && j >= (int64_t)q * dps) ? 1 : 0;
+      return (uint32_t)sh.lo[v] + word_to_draw(word, sh.size[v]);
+    }
+  }
+  return word_to_draw(word, n);
+}
+
 __global__ __launch_bounds__(256) void r_mt_convert_kernel(uint32_t* out, int64_t count, uint32_t n_samples,
                                                            RngShards sh) {
   const double n = (double)n_samples;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256) {
-    if (sh.V > 1) {
-      int64_t r = 0, j = i;
-      if (sh.run < count) {
-        r = (int64_t)((double)i * sh.inv_run);
-        j = i - r * sh.run;
-        if (j < 0) {
-          --r;
-          j += sh.run;
-        } else if (j >= sh.run) {
-          ++r;
-          j -= sh.run;
-        }
-      }
-      const int64_t left = count - r * sh.run;
-      const int64_t dps = left >= sh.run ? sh.dps : left / sh.V;      // the division: in the last, shorter run only
-      if (dps > 0 && j < dps * sh.V) {
-        int v = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+    out[i] = convert_at(i, out[i], count, n, sh);
+}
+
+// The same on a FEW CUs (round 4): while the fused epoch kernel of the virtual shards holds every CU but the
+// generators' own for a whole epoch, 2048 small workgroups with one 4-byte load in flight per thread have nowhere to
+// run but those few CUs (0.8 ms per 10M draws there).  Here a launch is two 1024-thread workgroups per reserved CU
+// and a thread keeps four 16-byte loads in flight.
+constexpr int kConvU = 4;
+__global__ __launch_bounds__(1024) void r_mt_convert_narrow_kernel(uint32_t* out, int64_t count, uint32_t n_samples,
+                                                                   RngShards sh) {
+  const double n = (double)n_samples;
+  const int64_t n4 = count >> 2;
+  uint4* out4 = reinterpret_cast<uint4*>(out);
+  const int64_t stride = (int64_t)gridDim.x * 1024;
+  for (int64_t i0 = (int64_t)blockIdx.x * 1024 + threadIdx.x; i0 < n4; i0 += stride * kConvU) {
+    uint4 x[kConvU];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) v += (q < sh.V && j >= (int64_t)q * dps) ? 1 : 0;
-        out[i] = (uint32_t)sh.lo[v] + word_to_draw(out[i], sh.size[v]);
-        continue;
+    for (int u = 0; u < kConvU; ++u) {
+      const int64_t q = i0 + u * stride;
+      x[u] = q < n4 ? out4[q] : uint4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < kConvU; ++u) {
+      const int64_t q = i0 + u * stride;
+      if (q < n4) {
+        uint4 y;
+        y.x = convert_at(4 * q, x[u].x, count, n, sh);
+        y.y = convert_at(4 * q + 1, x[u].y, count, n, sh);
+        y.z = convert_at(4 * q + 2, x[u].z, count, n, sh);
+        y.w = convert_at(4 * q + 3, x[u].w, count, n, sh);
+        out4[q] = y;
       }
     }
-    out[i] = word_to_draw(out[i], n);
+  }
+  if (blockIdx.x == 0) {
+    const int64_t i = 4 * n4 + threadIdx.x;
+    if (i < count) out[i] = convert_at(i, out[i], count, n, sh);
   }
 }
 
@@ -342,9 +370,7 @@ int launch_rng_unif(const uint32_t* state_in, uint32_t* state_out, uint32_t* raw
   return SGDNET_OK;
 }
 
-// state_in -> state_out (may alias); raw words then draws into out[0, count)
-int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
-                    int64_t count, hipStream_t st, int n_shards, const double* shard_size, int gens, int64_t run_len) {
+static RngShards make_shards(int n_shards, const double* shard_size, int64_t count, int64_t run_len) {
   RngShards sh{};
   sh.V = n_shards;
   if (n_shards > 1) {
@@ -358,16 +384,40 @@ int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_sa
       lo += shard_size[v];
     }
   }
-  if (gens < 1) gens = 1;
-  const int64_t seg = (count + gens - 1) / gens;
-  hipLaunchKernelGGL(r_mt_state_kernel, dim3((gens + kGenPerWg - 1) / kGenPerWg), dim3(kRngBlock * kGenPerWg), 0, st,
-                     state_in, state_out, out, count, seg, gens);
+  return sh;
+}
+
+// raw words -> draws, in place (the second half of launch_rng_fill; also run on its own on a slot of the sample-order
+// pipeline that was left raw for the fused epoch kernel and is consumed by other kernels after all)
+int launch_rng_convert(uint32_t* out, int64_t count, uint32_t n_samples, hipStream_t st, int n_shards,
+                       const double* shard_size, int64_t run_len, int narrow_cus) {
+  const RngShards sh = make_shards(n_shards, shard_size, count, run_len);
+  if (narrow_cus > 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    hipLaunchKernelGGL(r_mt_convert_narrow_kernel, dim3(2 * narrow_cus), dim3(1024), 0, st, out, count, n_samples, sh);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
+  }
   int grid = (int)((count + 256 * 8 - 1) / (256 * 8));
   if (grid < 1) grid = 1;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(r_mt_convert_kernel, dim3(grid), dim3(256), 0, st, out, count, n_samples, sh);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
+}
+
+// state_in -> state_out (may alias); raw words then draws into out[0, count)
+// convert: 1 the wide conversion kernel, 2 the narrow one (narrow_cus CUs), 0 none: the slot keeps the raw words (the
+// fused epoch kernel of the virtual shards converts its own shares, saga_batched.hip)
+int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
+                    int64_t count, hipStream_t st, int n_shards, const double* shard_size, int gens, int64_t run_len,
+                    int convert, int narrow_cus) {
+  if (gens < 1) gens = 1;
+  const int64_t seg = (count + gens - 1) / gens;
+  hipLaunchKernelGGL(r_mt_state_kernel, dim3((gens + kGenPerWg - 1) / kGenPerWg), dim3(kRngBlock * kGenPerWg), 0, st,
+                     state_in, state_out, out, count, seg, gens);
+  SGD_HIP_TRY(hipGetLastError());
+  if (!convert) return SGDNET_OK;
+  return launch_rng_convert(out, count, n_samples, st, n_shards, shard_size, run_len, convert == 2 ? narrow_cus : 0);
 }
 
 }  // namespace sgdnet

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 
 #include "device_math.hpp"
+#include "r_rng_word.hpp"
 
 #ifndef SGDNET_BIN_BLOCK
 #define SGDNET_BIN_BLOCK 1024
@@ -1947,6 +1948,502 @@ __global__ void saga_epoch_end_kernel(LamParams* lamp, int batches) {
   if (threadIdx.x == 0 && blockIdx.x == 0) end_epoch(lamp, batches);
 }
 
+// --------------------------------------------------------------------------
+// Fused epoch of the virtual shards (round 4): ONE launch per epoch instead of
+// broadcast + 10 x (gather, sweep) + 5 merges.  Sparse x, one response, compact records.
+//
+// Between two merges the V shards are independent chains gather -> sweep -> gather ...
+// (src/saga-sparse.h:258-337 in batches, per replica), so nothing but a merge needs the whole
+// grid: the S workgroups of a shard synchronise among themselves (two counters per shard), and a
+// merge needs only the V workgroups that own the same feature slice (one counter per slice).  The
+// shards therefore drift apart in time: while one shard's workgroups publish slabs, wait, sweep
+// and restage w -- all latency -- the other shards' draw loops keep the memory system busy.  With
+// one launch per batch every workgroup of the chip went through those phases at the same moment
+// (26 % of a C4 epoch was outside the draw loops: VERDICT round 3).
+//
+// Round r of workgroup (v, i) -- shard v, slice i of S:
+//   stage    W (LDS) <- replica w_v ; b0 <- b_v [- c.w_v]                  (round 0: the solver's own state)
+//   draws    its share of the shard's batch against (W, b0): K1Compact, D_i in LDS   (saga-sparse.h:274-282, 306-335)
+//   publish  D_i -> slab (v, i), sum of gc -> vd0 ; arrive cnt1[v] ; wait for all S
+//   sweep    features [i F, (i+1) F): sum of the S slabs in a fixed order, w_j <- r^m w_j - gamma LS_m G_j
+//            - gamma D_j ; prox ; G_j += D_j / n_v (:316-325, 340-348 batched; penalties.h); (i == 0) intercept (:300-304)
+//   merge    (every `every` rounds and at the end) slice -> pub[parity][v] ; arrive col[i] ; wait for all V ;
+//            slice <- ref + sum_u (n_u / n) (pub_u - ref), the same expression in all V workgroups
+//   arrive cnt2[v] ; wait for all S (next round's staging reads every slice of w_v)
+//
+// Visibility follows the write-through form of the CDNA4 guide (inter-workgroup hand-off, form R1): EVERY byte
+// another workgroup reads is stored with sc1 (buffer_store ... sc1 / agent-scope atomic store), every storing wave
+// drains vmcnt before the workgroup's barrier, ONE lane then adds to the counter (agent-scope atomic), ONE lane polls
+// it with sc1 loads, the other waves wait at a workgroup barrier, and EVERY load of handed-off bytes is an sc1 load
+// (no L1 hit on a stale line).  Nothing depends on which XCD a workgroup runs on.
+//
+// Residency: the workgroups spin on each other, so all of them must be resident at once (one per CU: the LDS
+// tables fill it).  The kernel does not assume that: it opens with a start barrier that ONE arbiter word decides
+// (compare-and-swap 0 -> 1 "go" by workgroup 0 once everybody has arrived, 0 -> 2 "abort" by whoever waited too
+// long); before that decision nothing is modified, so an aborted launch (a GPU shared with another process, fewer
+// CUs than the grid) leaves the solver's state as it was, LamParams::fused_abort = 1 tells the host, and the epoch is
+// run again as separate launches.  Every later wait is bounded too (fused_abort = 2: a bug, the epoch is void).
+// The last workgroup to leave zeroes the counters for the next launch.
+// --------------------------------------------------------------------------
+constexpr int kSyncLine = 32;                  // unsigned words per 128-B line: every polled word has a line of its own
+constexpr int kSyncGo = 0, kSyncExit = 1, kSyncStart = 2, kSyncCnt1 = 3, kSyncCnt2 = kSyncCnt1 + 8,
+              kSyncCol = kSyncCnt2 + 8;
+constexpr int kFusedMaxBps = 128;              // workgroups per shard
+constexpr int kSyncLines = kSyncCol + kFusedMaxBps;
+constexpr int kSyncSticky = kSyncLines;        // abort code of any launch since the host last looked (never reset on the device)
+constexpr int kFusedChunks = 3;                // 64-lane chunks of 16-byte pairs in a workgroup's feature slice
+constexpr long long kFusedStartTicks = 2000000;      // 20 ms of the 100 MHz wall clock: the start barrier
+constexpr long long kFusedWaitTicks = 200000000;     // 2 s: every later wait (never reached unless there is a bug)
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef double f64x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fused_rsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// 16-byte write-through store / L1-bypassing load (aux 16 = sc1)
+__device__ __forceinline__ void st2_sc1(f64x2_t x, __amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), rs, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ f64x2_t ld2_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
+  return __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16));
+}
+__device__ __forceinline__ void st_sc1(double* q, double x) {
+  __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_sc1(const double* q) {
+  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned sync_load(unsigned* sync, int word) {
+  return __hip_atomic_load(sync + word * kSyncLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// every wave of the workgroup has drained its stores; ONE lane signals
+__device__ __forceinline__ void fused_arrive(unsigned* sync, int word) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add(sync + word * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one lane: counter >= target, or give up (returns false; *fail set on a timeout of this lane's own)
+__device__ __forceinline__ bool fused_poll(unsigned* sync, int word, unsigned target, LamParams* lamp) {
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 1;; ++spins) {
+    if (sync_load(sync, word) >= target) return true;
+    __builtin_amdgcn_s_sleep(4);
+    if ((spins & 63u) == 0) {
+      if (sync_load(sync, kSyncGo) != 1u) return false;          // somebody else gave up
+      if (wall_clock64() - t0 > kFusedWaitTicks) {
+        __hip_atomic_store(sync + kSyncGo * kSyncLine, 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&lamp->fused_abort, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sync + kSyncSticky * kSyncLine, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
+    }
+  }
+}
+
+// The start barrier (one lane per workgroup).  Returns true when the arbiter word says "go".
+__device__ __forceinline__ bool fused_start(unsigned* sync, LamParams* lamp) {
+  unsigned* go = sync + kSyncGo * kSyncLine;
+  const unsigned grid = gridDim.x;
+  const long long t0 = wall_clock64();
+  if (blockIdx.x == 0) {
+    unsigned expect = 0u;
+    for (;;) {
+      if (sync_load(sync, kSyncStart) >= grid) {
+        __hip_atomic_compare_exchange_strong(go, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      if (sync_load(sync, kSyncGo) != 0u) break;
+      if (wall_clock64() - t0 > kFusedStartTicks) {
+        __hip_atomic_compare_exchange_strong(go, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  } else {
+    for (;;) {
+      if (sync_load(sync, kSyncGo) != 0u) break;
+      if (wall_clock64() - t0 > 2 * kFusedStartTicks) {     // workgroup 0 itself is not running
+        unsigned expect = 0u;
+        __hip_atomic_compare_exchange_strong(go, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(4);
+    }
+  }
+  const unsigned decision = sync_load(sync, kSyncGo);
+  if (decision != 1u && decision != 3u) {
+    __hip_atomic_store(&lamp->fused_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(sync + kSyncSticky * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return decision == 1u;
+}
+
+// deterministic sum over the workgroup (every thread gets it); two barriers
+__device__ __forceinline__ double fused_block_sum(double a, double* red) {
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int wv = 0; wv < kLdsBlock / 64; ++wv) t += red[wv];
+  __syncthreads();
+  return t;
+}
+
+__global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, LamParams* lamp, int nb, int every) {
+  extern __shared__ __attribute__((aligned(16))) double Dl[];
+  __shared__ int ticket_counter;
+  __shared__ int sh_ok;
+  __shared__ double sh_red[kLdsBlock / 64];
+  __shared__ double sh_val[4];                  // [0] b0 of the round, [1] sum of gc of the shard's batch
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t p = d.p;                        // K == 1, p even
+  const int64_t P2 = p >> 1;
+  const int S = d.v_bps, V = d.V;
+  const int v = (int)blockIdx.x / S, wi = (int)blockIdx.x - v * S;
+  const int F = 2 * (int)((p + 2 * S - 1) / (2 * S));            // features of a workgroup's slice (even)
+  const int j0 = wi * F;
+  const int jn = p - j0 < F ? (p - j0 > 0 ? (int)(p - j0) : 0) : F;
+  double* Wl = Dl + p;
+  f64x2_t* D2 = reinterpret_cast<f64x2_t*>(Dl);
+  f64x2_t* W2 = reinterpret_cast<f64x2_t*>(Wl);
+  // per-lambda parameters: read once (the epoch's bookkeeping rewrites LamParams at the end)
+  const int penalty = lamp->penalty;
+  const double gamma = lamp->gamma, beta = lamp->beta;
+  const double r_full = lamp->r_full, ls_full = lamp->ls_full, r_tail = lamp->r_tail, ls_tail = lamp->ls_tail;
+  const int64_t m_full = lamp->m_full;
+  const int64_t sbase = lamp->stream_base;
+  const bool raw_words = lamp->stream_raw != 0;   // the stream holds the generators' raw words: every workgroup turns its own share into draws
+  const int64_t dps = d.v_dps;
+  const double n_d = d.v_size[v];
+  const bool std_x = d.standardize != 0;
+  const int64_t L = 2 * p + 2;                  // [g_sum | w | g_sum_intercept | intercept]
+  double* vwv = d.vw + (int64_t)v * p;
+  double* vGv = d.vG + (int64_t)v * p;
+  double* refv = d.vx + (int64_t)(2 * V + v) * L;
+  double* cwp = d.vx + (int64_t)3 * V * L;      // c . w of every workgroup's slice: V x kFusedMaxBps
+  unsigned* sync = d.vsync;
+  const __amdgpu_buffer_rsrc_t rs_slab = fused_rsrc(d.slab, (int64_t)V * S * p * 8);
+  const __amdgpu_buffer_rsrc_t rs_w = fused_rsrc(vwv, p * 8);
+  double tot_size = 0.0, lo_v = 0.0;
+  for (int u = 0; u < V; ++u) {
+    tot_size += d.v_size[u];
+    if (u < v) lo_v += d.v_size[u];
+  }
+  // this workgroup's share of a shard-batch of m draws (the ranges K1Compact::begin hands out): [lo, hi)
+  uint32_t* const stream_v = const_cast<uint32_t*>(d.stream) + sbase + (int64_t)v * dps;
+  auto convert_share = [&](int64_t t0, int m) {   // raw words -> draws from shard v's sample range, in place
+    const int share = ((m + S - 1) / S + kTicket - 1) / kTicket * kTicket;
+    const int lo = wi * share, hi = lo + share < m ? lo + share : m;
+    uint32_t* q = stream_v + t0;
+    for (int i = lo + tid; i < hi; i += kLdsBlock) q[i] = (uint32_t)lo_v + word_to_draw(q[i], n_d);
+  };
+
+#ifdef SGDNET_PHASE_TIMING
+  // thread 0's time per phase, summed over the rounds: dbg[workgroup * 16 + phase]; slots 14 / 15: first and last stamp
+  unsigned long long ph_t = 0;
+  if (d.dbg && tid == 0) d.dbg[(size_t)blockIdx.x * 16 + 14] = ph_t = phase_stamp();
+#define FPH(slot)                                                 \
+  do {                                                            \
+    if (d.dbg && tid == 0) {                                      \
+      const unsigned long long now = phase_stamp();               \
+      d.dbg[(size_t)blockIdx.x * 16 + (slot)] += now - ph_t;      \
+      d.dbg[(size_t)blockIdx.x * 16 + 15] = ph_t = now;           \
+    }                                                             \
+  } while (0)
+#else
+#define FPH(slot) ((void)0)
+#endif
+  // ---- start barrier: before "go" nothing is modified ---------------------------------------------
+  if (tid == 0) {
+    __hip_atomic_fetch_add(sync + kSyncStart * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    sh_ok = fused_start(sync, lamp) ? 1 : 0;
+  }
+  for (int64_t i = tid; i < P2; i += kLdsBlock) D2[i] = f64x2_t{0.0, 0.0};
+  __syncthreads();
+  bool done = false;
+  bool alive = sh_ok != 0;
+  int mi = 0;                                   // merges so far
+  K1Compact cg;
+  if (alive) {
+    const int m0 = (int)(dps < m_full ? dps : m_full);
+    if (raw_words) {
+      convert_share(0, m0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                          // the ids below are read by other waves than the ones that wrote them
+    }
+    if (tid == 0) ticket_counter = K1Compact::static_tickets();
+    cg.begin(d, stream_v, m0, wi, S, &ticket_counter);
+  }
+  for (int r = 0; alive && r < nb; ++r) {
+    const int64_t t0 = (int64_t)r * m_full;
+    const int m = (int)(dps - t0 < m_full ? dps - t0 : m_full);
+    const bool tail = m != m_full;
+    const double r_m = tail ? r_tail : r_full, ls_m = tail ? ls_tail : ls_full;
+    const bool last = r + 1 == nb;
+    const bool merge_due = last || (r + 1) % every == 0;
+
+    // ---- stage: long-row bits of the first draws (their ids were requested a phase ago), w, intercept --------
+    cg.tag_first();
+    {
+      constexpr int kStage = 8;                 // one round of loads for up to 16 384 coefficients
+      for (int64_t i0 = tid; i0 < P2; i0 += (int64_t)kLdsBlock * kStage) {
+        f64x2_t t[kStage];
+#pragma unroll
+        for (int q = 0; q < kStage; ++q) {
+          const int64_t i = i0 + (int64_t)q * kLdsBlock;
+          t[q] = f64x2_t{0.0, 0.0};
+          if (i < P2) t[q] = r == 0 ? reinterpret_cast<const f64x2_t*>(d.w)[i] : ld2_sc1(rs_w, (uint32_t)(i * 16));
+        }
+#pragma unroll
+        for (int q = 0; q < kStage; ++q) {
+          const int64_t i = i0 + (int64_t)q * kLdsBlock;
+          if (i < P2) W2[i] = t[q];
+        }
+      }
+    }
+    if (wave == 0) {                            // b0 = b_v - c . w_v
+      double cw = 0.0;
+      if (std_x && r > 0) {
+        for (int k = lane; k < S; k += 64) cw += ld_sc1(cwp + v * kFusedMaxBps + k);
+        cw = wave_sum(cw);
+      }
+      if (lane == 0) sh_val[0] = (r == 0 ? d.b[0] : ld_sc1(d.vb + v)) - cw;
+    }
+    __syncthreads();
+    if (r == 0 && std_x) {                      // c . w of the state the epoch starts from
+      double a = 0.0;
+      for (int64_t j = tid; j < p; j += kLdsBlock) a += d.c[j] * Wl[j];
+      a = fused_block_sum(a, sh_red);
+      if (tid == 0) sh_val[0] -= a;
+      __syncthreads();
+    }
+    const double b0 = sh_val[0];
+    FPH(0);
+
+    // ---- draws ------------------------------------------------------------------------------
+    const double gct = cg.run(d, b0, Wl, Dl);
+    __syncthreads();
+    FPH(1);
+
+    // ---- publish the slab (write-through) and the sum of the gradient changes -----------------------
+    {
+      const uint32_t base = (uint32_t)(((int64_t)blockIdx.x * p) * 8);
+      for (int64_t i = tid; i < P2; i += kLdsBlock) {
+        st2_sc1(D2[i], rs_slab, base + (uint32_t)(i * 16));
+        D2[i] = f64x2_t{0.0, 0.0};
+      }
+      const double t = wave_sum(gct);
+      if (lane == 0) sh_red[wave] = t;
+      __syncthreads();
+      if (tid == 0) {
+        double tot = 0.0;
+        for (int wv = 0; wv < kLdsBlock / 64; ++wv) tot += sh_red[wv];
+        st_sc1(d.vd0 + blockIdx.x, tot);
+      }
+    }
+    fused_arrive(sync, kSyncCnt1 + v);
+    FPH(2);
+    // behind the arrival, while the rest of the shard finishes: this workgroup's own coefficients (nobody else
+    // writes them), and the next round's share of the sample order
+    const int64_t j = j0 + tid;
+    const bool upd = tid < jn;
+    const bool icpt = wi == 0 && tid == 0;
+    double w_old = 0.0, g_old = 0.0, c_own = 0.0, rg = 0.0, rw = 0.0, b_new = 0.0, gb_new = 0.0, rgb = 0.0, rb = 0.0;
+    if (upd) {
+      w_old = r == 0 ? d.w[j] : ld_sc1(vwv + j);
+      g_old = r == 0 ? d.G[j] : ld_sc1(vGv + j);
+      if (std_x) c_own = d.c[j];
+      if (merge_due) {
+        rg = mi == 0 ? d.G[j] : ld_sc1(refv + j);
+        rw = mi == 0 ? d.w[j] : ld_sc1(refv + p + j);
+      }
+    }
+    if (icpt) {
+      b_new = r == 0 ? d.b[0] : ld_sc1(d.vb + v);
+      gb_new = r == 0 ? d.gb[0] : ld_sc1(d.vgb + v);
+      if (merge_due) {
+        rgb = mi == 0 ? d.gb[0] : ld_sc1(refv + 2 * p);
+        rb = mi == 0 ? d.b[0] : ld_sc1(refv + 2 * p + 1);
+      }
+    }
+    const int64_t t0n = t0 + m_full;
+    const int mn = (int)(dps - t0n < m_full ? dps - t0n : m_full);
+    if (!last && raw_words) convert_share(t0n, mn);
+    if (tid == 0) sh_ok = fused_poll(sync, kSyncCnt1 + v, (unsigned)S * (unsigned)(r + 1), lamp) ? 1 : 0;
+    __syncthreads();
+    if (!sh_ok) break;
+    FPH(3);
+
+    // ---- sweep of this workgroup's feature slice ------------------------------------------------
+    {
+      f64x2_t acc[kFusedChunks];
+#pragma unroll
+      for (int c = 0; c < kFusedChunks; ++c) acc[c] = f64x2_t{0.0, 0.0};
+      for (int k = wave; k < S; k += 2 * (kLdsBlock / 64)) {
+        const bool two = k + kLdsBlock / 64 < S;
+        const uint32_t o0 = (uint32_t)((((int64_t)(v * S + k)) * p + j0) * 8);
+        const uint32_t o1 = (uint32_t)((((int64_t)(v * S + k + kLdsBlock / 64)) * p + j0) * 8);
+        f64x2_t a0[kFusedChunks], a1[kFusedChunks];
+#pragma unroll
+        for (int c = 0; c < kFusedChunks; ++c) {
+          const int pi = c * 64 + lane;
+          a0[c] = a1[c] = f64x2_t{0.0, 0.0};
+          if (2 * pi < jn) {
+            a0[c] = ld2_sc1(rs_slab, o0 + (uint32_t)(pi * 16));
+            if (two) a1[c] = ld2_sc1(rs_slab, o1 + (uint32_t)(pi * 16));
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < kFusedChunks; ++c) {
+          acc[c] += a0[c];
+          acc[c] += a1[c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < kFusedChunks; ++c) {
+        const int pi = c * 64 + lane;
+        if (2 * pi < F) reinterpret_cast<f64x2_t*>(Wl + (int64_t)wave * F)[pi] = acc[c];
+      }
+      if (wave == kLdsBlock / 64 - 1) {         // the shard's sum of gc (intercept accumulator; implicit centring)
+        double a = 0.0;
+        for (int k = lane; k < S; k += 64) a += ld_sc1(d.vd0 + v * S + k);
+        a = wave_sum(a);
+        if (lane == 0) sh_val[1] = a;
+      }
+    }
+    __syncthreads();
+    const double d0 = sh_val[1];
+    double w_new = 0.0, g_new = 0.0;
+    if (upd) {
+      double dj = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < kLdsBlock / 64; ++wv) dj += Wl[(int64_t)wv * F + tid];
+      if (std_x) dj -= c_own * d0;              // implicit centring: D_j -= c_j * sum(gc)
+      const double val = r_m * w_old - (gamma * ls_m) * g_old - gamma * dj;
+      const double tau = beta * gamma * ls_m;
+      w_new = val;
+      if (penalty == SGDNET_ELASTICNET) {
+        w_new = soft_threshold(val, tau);
+      } else if (penalty == SGDNET_GROUPLASSO) {          // penalties.h:61-79 with one response
+        const double factor = tau / sqrt(val * val);
+        w_new = factor < 1.0 ? val * (1.0 - factor) : 0.0;
+      }
+      g_new = (dj != 0.0 || penalty == SGDNET_GROUPLASSO) ? g_old + dj / n_d : g_old;
+    }
+    if (icpt && d.fit_intercept) {              // saga-sparse.h:300-304 in batches
+      const double dk = d0 / n_d;
+      gb_new += dk;
+      b_new -= gamma * (gb_new * (d.xd ? 1.0 : 0.01) * (double)m + dk);
+    }
+    FPH(4);
+    if (merge_due) {
+      // ---- periodic average of the replicas, slice by slice ------------------------------------------
+      double* pubv = d.vx + (int64_t)((mi & 1) * V + v) * L;
+      if (upd) {
+        st_sc1(pubv + j, g_new);
+        st_sc1(pubv + p + j, w_new);
+      }
+      if (icpt) {
+        st_sc1(pubv + 2 * p, gb_new);
+        st_sc1(pubv + 2 * p + 1, b_new);
+      }
+      fused_arrive(sync, kSyncCol + wi);
+      if (tid == 0) sh_ok = fused_poll(sync, kSyncCol + wi, (unsigned)V * (unsigned)(mi + 1), lamp) ? 1 : 0;
+      __syncthreads();
+      if (!sh_ok) break;
+      const double* pub0 = d.vx + (int64_t)((mi & 1) * V) * L;
+      if (upd) {
+        double xg[8], xw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          xg[u] = xw[u] = 0.0;
+          if (u < V) {
+            xg[u] = ld_sc1(pub0 + (int64_t)u * L + j);
+            xw[u] = ld_sc1(pub0 + (int64_t)u * L + p + j);
+          }
+        }
+        double mg = rg, mw = rw;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u < V) {
+            const double wt = d.v_size[u] / tot_size;
+            mg += wt * (xg[u] - rg);
+            mw += wt * (xw[u] - rw);
+          }
+        }
+        g_new = mg;
+        w_new = mw;
+        st_sc1(refv + j, mg);
+        st_sc1(refv + p + j, mw);
+        if (last && v == 0) {
+          d.G[j] = mg;
+          d.w[j] = mw;
+        }
+      }
+      if (icpt) {
+        double mgb = rgb, mb = rb;
+        for (int u = 0; u < V; ++u) {
+          const double wt = d.v_size[u] / tot_size;
+          mgb += wt * (ld_sc1(pub0 + (int64_t)u * L + 2 * p) - rgb);
+          mb += wt * (ld_sc1(pub0 + (int64_t)u * L + 2 * p + 1) - rb);
+        }
+        gb_new = mgb;
+        b_new = mb;
+        st_sc1(refv + 2 * p, mgb);
+        st_sc1(refv + 2 * p + 1, mb);
+        if (last && v == 0) {
+          d.gb[0] = mgb;
+          d.b[0] = mb;
+        }
+      }
+      ++mi;
+      FPH(5);
+    }
+    if (upd) {
+      st_sc1(vwv + j, w_new);
+      st_sc1(vGv + j, g_new);
+    }
+    if (icpt) {
+      st_sc1(d.vb + v, b_new);
+      st_sc1(d.vgb + v, gb_new);
+    }
+    if (std_x) {                                // c . w of the slice, for the next round's linear predictors
+      const double a = fused_block_sum(upd ? c_own * w_new : 0.0, sh_red);
+      if (tid == 0) st_sc1(cwp + v * kFusedMaxBps + wi, a);
+    }
+    if (last) {
+      done = true;
+      break;
+    }
+    fused_arrive(sync, kSyncCnt2 + v);
+    FPH(6);
+    // the next round's first sample ids, requested before the wait (converted by this workgroup a phase ago)
+    if (tid == 0) ticket_counter = K1Compact::static_tickets();
+    cg.begin(d, stream_v + t0n, mn, wi, S, &ticket_counter);
+    if (tid == 0) sh_ok = fused_poll(sync, kSyncCnt2 + v, (unsigned)S * (unsigned)(r + 1), lamp) ? 1 : 0;
+    __syncthreads();
+    if (!sh_ok) break;
+    FPH(7);
+  }
+
+  // ---- leave: the epoch's bookkeeping, and the last workgroup out resets the counters ------------------
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    if (done && blockIdx.x == 0) end_epoch(lamp, nb);
+    const unsigned prev = __hip_atomic_fetch_add(sync + kSyncExit * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == gridDim.x) {
+      for (int wd = 0; wd < kSyncLines; ++wd)
+        __hip_atomic_store(sync + wd * kSyncLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ConvergenceCheck (src/utils.h:240-262): max |w - w_prev| and max |w|, then w_prev = w.
 __global__ __launch_bounds__(kBlock) void saga_convergence_kernel(SagaDev d, LamParams* lamp) {
   const int64_t len = (int64_t)d.K * d.p;
@@ -3004,6 +3501,42 @@ int launch_vs_sweep(const SagaDev& d, LamParams* lam, int tail, int m, hipStream
     hipExtLaunchKernelGGL(saga_vs_sweep_kernel<4>, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
   else
     hipExtLaunchKernelGGL(saga_vs_sweep_kernel<16>, dim3(nfb * d.V), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam, tail, nfb);
+  SGD_HIP_TRY(hipGetLastError());
+  return SGDNET_OK;
+}
+
+// ---- the fused epoch of the virtual shards (saga_vs_epoch_kernel) ----
+static int64_t fused_slice(const SagaDev& d) { return 2 * ((d.p + 2 * (int64_t)d.v_bps - 1) / (2 * (int64_t)d.v_bps)); }
+static size_t fused_lds_bytes(const SagaDev& d) {
+  const int64_t part = (int64_t)(kLdsBlock / 64) * fused_slice(d);     // the slice sweep's per-wavefront partial sums
+  return sizeof(double) * (size_t)(d.p + (part > d.p ? part : d.p)) + 16;
+}
+size_t vs_fused_sync_words() { return (size_t)(kSyncLines + 1) * kSyncLine; }
+size_t vs_fused_exchange_doubles(const SagaDev& d, int n_shards) {
+  return (size_t)3 * n_shards * (size_t)(2 * d.p + 2) + (size_t)n_shards * kFusedMaxBps;
+}
+
+// sparse x, one response, compact records, an even number of features, slices of at most 384 features
+bool vs_fused_eligible(const SagaDev& d) {
+  if (!vs_eligible(d, 0) || d.K != 1 || d.xd || !d.cP || !lanes8_ok(d) || (d.p & 1) || !d.vsync || !d.vx) return false;
+  if (d.v_bps < 1 || d.v_bps > kFusedMaxBps || d.V * d.v_bps > 1024) return false;
+  if (fused_slice(d) > 2 * 64 * kFusedChunks) return false;
+  if ((int64_t)d.V * d.v_bps * d.p * 8 >= (1ll << 31)) return false;
+  return fused_lds_bytes(d) + kLdsStaticReserve <= kLdsPerCu;
+}
+
+int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
+  static bool attr_done_dev[64] = {};
+  int cur_dev = 0;
+  (void)hipGetDevice(&cur_dev);
+  if (!attr_done_dev[cur_dev & 63]) {
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_vs_epoch_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
+    attr_done_dev[cur_dev & 63] = true;
+  }
+  if (nb < 1 || every < 1) return SGDNET_EINVAL;
+  hipExtLaunchKernelGGL(saga_vs_epoch_kernel, dim3(vs_grid(d)), dim3(kLdsBlock), fused_lds_bytes(d), st, ev0, ev1, 0, d,
+                        lam, nb, every);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

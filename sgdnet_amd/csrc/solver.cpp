@@ -84,6 +84,8 @@ struct sgdnet_solver {
     uint32_t* poly_n = nullptr;
     uint32_t* ends = nullptr;
     int64_t run_len = 0;   // virtual shards: draws per run of the layout (0: one run = the epoch)
+    // the slot holds the generators' raw words (left to the fused epoch kernel, which converts its own shares)
+    bool raw[2] = {false, false};
   } pipe;
   int64_t nnz = 0;
   bool penalty_set = false;
@@ -93,6 +95,7 @@ struct sgdnet_solver {
     int64_t batch, draws;
     hipGraph_t graph;
     hipGraphExec_t exec;
+    bool fused;                 // the epoch is ONE launch of saga_vs_epoch_kernel
   };
   std::vector<GraphEntry> graphs;
   hipGraphExec_t gexec = nullptr;
@@ -115,6 +118,11 @@ struct sgdnet_solver {
   // one-response sparse fits with compact records: the batched kernels keep the gradient memory inside the
   // records (saga_batched.hip "Compact records"), everything else (exact mode, the host) sees the K x n array
   bool m_in_rec = false;
+  // fused epoch of the virtual shards (saga_vs_epoch_kernel): switched off for this solver once a launch could not
+  // become resident (a GPU shared with another process); the separate launches take over
+  bool fused_off = false;
+  bool fused_in_graph = false;   // the captured epochs use it
+  int fused_abort_seen = 0;      // LamParams::fused_abort as the last ConvergenceCheck read it
 };
 
 namespace {
@@ -154,7 +162,7 @@ bool lam_on_device(const sgdnet_solver* s) {
   return a.penalty == b.penalty && a.gamma == b.gamma && a.alpha == b.alpha && a.beta == b.beta && a.r_full == b.r_full &&
          a.ls_full == b.ls_full && a.r_tail == b.r_tail && a.ls_tail == b.ls_tail && a.m_full == b.m_full &&
          a.m_tail == b.m_tail && a.stream_base == b.stream_base && a.stream_wrap == b.stream_wrap &&
-         a.draws_per_epoch == b.draws_per_epoch && a.batch_seq == b.batch_seq;
+         a.draws_per_epoch == b.draws_per_epoch && a.batch_seq == b.batch_seq && a.stream_raw == b.stream_raw;
 }
 
 // host mirror of end_epoch (saga_batched.hip)
@@ -453,6 +461,35 @@ int set_batch_shape(sgdnet_solver* s, int64_t batch, int64_t draws) {
   return SGDNET_OK;
 }
 
+bool vs_active(const sgdnet_solver* s, int64_t batch);
+bool vs_fused_active(const sgdnet_solver* s);
+
+// The epoch(s) about to be enqueued read the stream at `stream_offset`.  A slot of the sample-order pipeline that was
+// left raw goes to the fused epoch kernel as it is (LamParams::stream_raw; the kernel converts it, so the slot counts
+// as converted from here on); for any other consumer it is converted now, on the solver's stream (which has waited
+// for the generators: solver_rng_acquire).
+int prepare_stream_slot(sgdnet_solver* s, int64_t batch, int64_t stream_offset, int64_t draws, int n_epochs) {
+  auto& P = s->pipe;
+  s->lam.stream_raw = 0;
+  if (!P.open || !(P.raw[0] || P.raw[1])) return SGDNET_OK;
+  const bool one_slot = n_epochs == 1 && draws == P.n && (stream_offset == 0 || stream_offset == P.n);
+  const int slot = stream_offset == 0 ? 0 : 1;
+  if (one_slot && P.raw[slot] && vs_active(s, batch) && vs_fused_active(s)) {
+    s->lam.stream_raw = 1;
+    P.raw[slot] = false;
+    return SGDNET_OK;
+  }
+  for (int q = 0; q < 2; ++q) {
+    if (!P.raw[q] || (one_slot && q != slot)) continue;
+    if (!one_slot) SGD_HIP_TRY(hipStreamSynchronize(P.st));      // a slot that may still be generated
+    int rc = launch_rng_convert(s->stream_dev + (int64_t)q * P.n, P.n, (uint32_t)s->d.n, s->st, s->d.V, s->d.v_size,
+                                P.run_len);
+    if (rc) return rc;
+    P.raw[q] = false;
+  }
+  return SGDNET_OK;
+}
+
 int n_batches(int64_t batch, int64_t draws) {
   if (batch < 1) batch = 1;
   if (batch > draws) batch = draws;
@@ -472,12 +509,40 @@ int vs_merge_batches(const sgdnet_solver* s, int64_t batch) {
   return (int)(b < 1 ? 1 : b);
 }
 
+// The whole epoch in one launch (saga_batched.hip "Fused epoch"): option fused_epoch, the kernel's own limits, a
+// device with at least as many CUs as the launch has workgroups, and no earlier launch of this solver that failed
+// to become resident.
+bool vs_fused_active(const sgdnet_solver* s) {
+  if (s->fused_off || !option(kOptFusedEpoch) || !vs_fused_eligible(s->d)) return false;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess) return false;
+  return s->d.V * s->d.v_bps <= cus;
+}
+
 int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std::vector<hipEvent_t>* ev) {
   const SagaDev& d = s->d;
   const int64_t dps = draws / d.V;
   if (batch > dps) batch = dps;
   const int nb = n_batches(batch, dps);
   const int every = vs_merge_batches(s, batch);
+  if (vs_fused_active(s)) {
+    if (ev) {
+      hipEvent_t e[2];
+      for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
+      int rcf = launch_vs_epoch(d, s->lam_dev, nb, every, s->st, e[0], e[1]);
+      if (rcf) return rcf;
+      hipEvent_t z[2];                          // no separate sweep launches: an empty interval
+      for (auto& x : z) SGD_HIP_TRY(hipEventCreate(&x));
+      SGD_HIP_TRY(hipEventRecord(z[0], s->st));
+      SGD_HIP_TRY(hipEventRecord(z[1], s->st));
+      ev->push_back(e[0]);
+      ev->push_back(e[1]);
+      ev->push_back(z[0]);
+      ev->push_back(z[1]);
+      return SGDNET_OK;
+    }
+    return launch_vs_epoch(d, s->lam_dev, nb, every, s->st);
+  }
   int rc = launch_vs_broadcast(d, s->st);
   if (rc) return rc;
   rc = launch_vs_cw(d, s->st);
@@ -553,9 +618,11 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
 }
 
 int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
+  const bool fused = vs_active(s, batch) && vs_fused_active(s);
   for (auto& g : s->graphs)
-    if (g.batch == batch && g.draws == draws) {
+    if (g.batch == batch && g.draws == draws && g.fused == fused) {
       s->gexec = g.exec;
+      s->fused_in_graph = fused;
       return SGDNET_OK;
     }
   if (s->graphs.size() >= 4) {   // a sharded epoch uses at most two shapes (segments + remainder)
@@ -565,6 +632,7 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
     (void)hipGraphDestroy(old.graph);
     s->graphs.erase(s->graphs.begin());
   }
+  s->fused_in_graph = fused;
   SGD_HIP_TRY(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
   int rc = enqueue_epoch_kernels(s, batch, draws, nullptr);
   hipGraph_t g = nullptr;
@@ -584,7 +652,7 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
     set_error("hipGraphInstantiate failed: %s", hipGetErrorString(e));
     return SGDNET_EHIP;
   }
-  s->graphs.push_back({batch, draws, g, ex});
+  s->graphs.push_back({batch, draws, g, ex, fused});
   s->gexec = ex;
   return SGDNET_OK;
 }
@@ -632,6 +700,39 @@ int read_convergence(sgdnet_solver* s, double tol, int* converged) {
   *converged = (all_zero || no_change) ? 1 : 0;
   s->last_change = max_change;
   s->last_size = max_size;
+  s->fused_abort_seen = back.fused_abort;
+  return SGDNET_OK;
+}
+
+// A fused epoch launch that gave up (saga_batched.hip "Fused epoch").  *rerun: the launch changed nothing, the
+// caller runs the epoch again (the solver has switched to separate launches).
+int fused_recover(sgdnet_solver* s, int code, int64_t draws, int batches, bool* rerun) {
+  *rerun = false;
+  if (!code) return SGDNET_OK;
+  s->fused_off = true;
+  s->fused_abort_seen = 0;
+  SGD_HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(s->lam_dev) + offsetof(LamParams, fused_abort), 0, sizeof(int), s->st));
+  SGD_HIP_TRY(hipMemsetAsync(s->d.vsync + vs_fused_sync_words() - 32, 0, sizeof(unsigned), s->st));
+  if (code != 1) {
+    set_error("batched mode: a wait inside the fused epoch kernel timed out (internal error; the epoch is void)");
+    return SGDNET_EHIP;
+  }
+  if (getenv("SGDNET_TRACE"))
+    fprintf(stderr, "[sgdnet]   the fused epoch launch could not become resident (GPU shared?): separate launches from now on\n");
+  // the device did not advance the epoch's bookkeeping: take the host mirror back
+  for (LamParams* q : {&s->lam, &s->lam_dev_mirror}) {
+    int64_t sb = q->stream_base - draws;
+    if (sb < 0 && q->stream_wrap > 0) sb += q->stream_wrap;
+    q->stream_base = sb;
+    q->batch_seq -= batches;
+  }
+  if (s->lam.stream_raw) {                      // the launch was to convert its slot of the sample order and did not
+    const int64_t sb = s->lam.stream_base;
+    int rc = launch_rng_convert(s->stream_dev + sb, s->pipe.n, (uint32_t)s->d.n, s->st, s->d.V, s->d.v_size, s->pipe.run_len);
+    if (rc) return rc;
+    s->lam.stream_raw = 0;
+  }
+  *rerun = true;
   return SGDNET_OK;
 }
 
@@ -779,8 +880,9 @@ struct OptionDef {
 const OptionDef kOptionDefs[sgdnet::kOptCount] = {
     {"virtual_shards", -1, -1, 8}, {"rng_generators", 0, 0, 64},     {"window_eigenvalue", 1, 0, 1},
     {"host_setup", 0, 0, 1},       {"exact_epoch_blocks", 1, 0, 1}, {"exact_row_registers", 1, 0, 4},
+    {"fused_epoch", 1, 0, 1},
 };
-std::atomic<int> g_options[sgdnet::kOptCount] = {{-1}, {0}, {1}, {0}, {1}, {1}};
+std::atomic<int> g_options[sgdnet::kOptCount] = {{-1}, {0}, {1}, {0}, {1}, {1}, {1}};
 int find_option(const char* name) {
   if (name)
     for (int i = 0; i < sgdnet::kOptCount; ++i)
@@ -1347,16 +1449,22 @@ int solver_rng_prefetch(sgdnet_solver* s) {
   const int slot = (int)(P.gens & 1);
   SGD_HIP_TRY(hipStreamWaitEvent(P.st, P.freed[slot], 0));
   int rc;
+  // virtual shards with the fused epoch kernel: that kernel holds every CU but the generators' own for the whole
+  // epoch, where the conversion (tempering, unif_rand scaling, floor(n_v u): compute-bound) would take longer than
+  // the epoch; the slot keeps the raw words and every workgroup of the epoch kernel converts its own share
+  const bool keep_raw = s->d.V > 1 && P.run_len == 0 && vs_fused_active(s);
+  P.raw[slot] = keep_raw;
   if (P.G > 1) {
     rc = launch_rng_fill(P.state[P.gens & 1], P.ends, (uint32_t)s->d.n, s->stream_dev + (int64_t)slot * P.n, P.n,
-                         P.st, s->d.V, s->d.v_size, P.G, P.run_len);
+                         P.st, s->d.V, s->d.v_size, P.G, P.run_len, keep_raw ? 0 : 1);
     // the jump's workgroups take their generators in turn: the side stream never holds more CUs than
     // the generators' own (a wider launch would push gather workgroups into a second round)
     if (!rc) rc = launch_rng_jump(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], P.poly_n, P.G, P.st,
                                   std::max(1, s->d.cu_reserve));
   } else {
     rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
-                         s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G, P.run_len);
+                         s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G, P.run_len,
+                         keep_raw ? 0 : 1);
   }
   if (rc) return rc;
   SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
@@ -1573,6 +1681,8 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
     if (rc) return rc;
     s->lam.stream_base = stream_offset;
     s->lam.stream_wrap = stream_wrap_for(s, stream_offset, draws_per_epoch);
+    rc = prepare_stream_slot(s, batch, stream_offset, draws_per_epoch, (int)max_epochs);
+    if (rc) return rc;
     rc = push_lam(s);
     if (rc) return rc;
     if (s->d.standardize) {
@@ -1608,6 +1718,17 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
       const auto tc0 = std::chrono::steady_clock::now();
       rc = device_convergence(s, tol, &converged);
       if (rc) return rc;
+      if (s->fused_in_graph && s->fused_abort_seen) {
+        bool rerun = false;
+        rc = fused_recover(s, s->fused_abort_seen, draws_per_epoch, nb, &rerun);
+        if (rc) return rc;
+        if (rerun) {                            // nothing was modified: the same epoch as separate launches
+          converged = 0;
+          rc = ensure_graph(s, batch, draws_per_epoch);
+          if (rc) return rc;
+          continue;
+        }
+      }
       rc = check_bins(s);
       if (rc) return rc;
       g_trace_conv += std::chrono::duration<double>(std::chrono::steady_clock::now() - tc0).count();
@@ -1645,6 +1766,8 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
   s->lam.stream_wrap = stream_wrap_for(s, stream_offset, draws_per_epoch);
+  rc = prepare_stream_slot(s, batch, stream_offset, draws_per_epoch, n_epochs);
+  if (rc) return rc;
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1680,6 +1803,21 @@ static int check_bins(sgdnet_solver* s) {
 int sgdnet_solver_sync(sgdnet_solver* s) {
   if (!s) return SGDNET_EINVAL;
   SGD_HIP_TRY(hipSetDevice(s->device));
+  if (s->fused_in_graph && s->d.vsync) {        // epochs enqueued without a check of their own: did a fused launch give up?
+    unsigned code = 0;
+    SGD_HIP_TRY(hipMemcpyAsync(&code, s->d.vsync + vs_fused_sync_words() - 32, sizeof(unsigned), hipMemcpyDeviceToHost, s->st));
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    if (code) {
+      bool rerun = false;
+      (void)fused_recover(s, 2, 0, 0, &rerun);
+      drop_graph(s);
+      set_error("batched mode: a fused epoch launch %s; the epochs enqueued since the last synchronisation are void "
+                "(sgdnet_set_option(\"fused_epoch\", 0) keeps the separate launches)",
+                code == 1 ? "could not become resident on the GPU (is it shared with another process?)"
+                          : "timed out inside the epoch");
+      return SGDNET_EHIP;
+    }
+  }
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   return check_bins(s);
 }
@@ -1702,6 +1840,8 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   if (rc) return rc;
   s->lam.stream_base = stream_offset;
   s->lam.stream_wrap = stream_wrap_for(s, stream_offset, draws_per_epoch);
+  rc = prepare_stream_slot(s, batch, stream_offset, draws_per_epoch, 1);
+  if (rc) return rc;
   rc = push_lam(s);
   if (rc) return rc;
   if (s->d.standardize) {
@@ -1709,6 +1849,10 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
     if (rc) return rc;
   }
   std::vector<hipEvent_t> ev;
+#ifdef SGDNET_PHASE_TIMING
+  const bool fused_prof = vs_active(s, batch) && vs_fused_active(s);
+  if (fused_prof && s->d.dbg) SGD_HIP_TRY(hipMemsetAsync(s->d.dbg, 0, sizeof(unsigned long long) * 16 * 1024, s->st));
+#endif
   rc = enqueue_epoch_kernels(s, batch, draws_per_epoch, &ev);
   if (rc) return rc;
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
@@ -1725,6 +1869,38 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
   }
   for (hipEvent_t e : ev) (void)hipEventDestroy(e);
 #ifdef SGDNET_PHASE_TIMING
+  if (s->d.dbg && fused_prof) {   // fused epoch kernel: thread 0's time per phase, summed over the rounds
+    const int grid = s->d.V * s->d.v_bps;
+    std::vector<unsigned long long> t(16 * 1024);
+    SGD_HIP_TRY(hipMemcpy(t.data(), s->d.dbg, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
+    static const char* nm[8] = {"stage w + ids", "draw loop", "publish slab", "wait shard (1)", "slice sweep", "merge",
+                                "store + arrive", "wait shard (2)"};
+    unsigned long long first = ~0ull, last = 0;
+    for (int b = 0; b < grid; ++b) {
+      first = std::min(first, t[b * 16 + 14]);
+      last = std::max(last, t[b * 16 + 15]);
+    }
+    fprintf(stderr, "[phase] fused epoch kernel: span seen by the workgroups %.1f us (%d workgroups)\n", (double)(last - first) / 100.0, grid);
+    double tot_mean = 0;
+    for (int ph = 0; ph < 8; ++ph) {
+      double sum = 0, mx = 0, mn = 1e30;
+      for (int b = 0; b < grid; ++b) {
+        const double dt = (double)t[b * 16 + ph] / 100.0;
+        sum += dt; mx = std::max(mx, dt); mn = std::min(mn, dt);
+      }
+      tot_mean += sum / grid;
+      fprintf(stderr, "[phase] %-16s per epoch: mean %7.1f us  min %7.1f  max %7.1f\n", nm[ph], sum / grid, mn, mx);
+    }
+    fprintf(stderr, "[phase] sum of the means %.1f us\n", tot_mean);
+    for (int v = 0; v < s->d.V; ++v) {
+      double a0 = 0, a1 = 0;
+      for (int b = v * s->d.v_bps; b < (v + 1) * s->d.v_bps; ++b) {
+        a0 += (double)(t[b * 16 + 14] - first) / 100.0;
+        a1 += (double)(t[b * 16 + 15] - first) / 100.0;
+      }
+      fprintf(stderr, "[phase]   shard %d: mean start %.1f us, mean end %.1f us\n", v, a0 / s->d.v_bps, a1 / s->d.v_bps);
+    }
+  } else
   if (s->d.dbg && binned_active(s->d, (int)batch)) {   // binned form: slots 0-5 gather, 6-10 range sweep
     std::vector<unsigned long long> t(16 * 1024);
     SGD_HIP_TRY(hipMemcpy(t.data(), s->d.dbg, sizeof(unsigned long long) * t.size(), hipMemcpyDeviceToHost));
@@ -1809,6 +1985,7 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
 
 int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch) {
   if (!s || batch < 1) return 0;
+  if (vs_active(s, batch) && vs_fused_active(s)) return 3;
   if (binned_active(s->d, (int)batch)) return 2;
   return batch_gather_slab_doubles(s->d, (int)batch) > 0 ? 1 : 0;
 }
@@ -1975,7 +2152,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   s->vs_owned.clear();
   SagaDev& d = s->d;
   d.V = 0;
-  d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = nullptr;
+  d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = d.vx = nullptr;
+  d.vsync = nullptr;
   if (n_shards < 2) return SGDNET_OK;
   if (d.K > 16 || (d.K > 1 && !s->sparse)) {
     set_error("virtual shards: one response, or up to 16 classes of sparse x");
@@ -1997,6 +2175,12 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   if (!rc) rc = alloc(&d.vcw, 8 * (size_t)d.K);
   if (!rc) rc = alloc(&d.vd0, 256 * (size_t)d.K);
   if (!rc) rc = alloc(&d.vref, (size_t)(2 * KP + 2 * d.K));
+  if (!rc && d.K == 1) {                        // the fused epoch kernel's barrier counters and exchange buffer
+    double* words = nullptr;
+    rc = alloc(&words, (vs_fused_sync_words() * sizeof(unsigned) + sizeof(double) - 1) / sizeof(double));
+    d.vsync = reinterpret_cast<unsigned*>(words);
+    if (!rc) rc = alloc(&d.vx, vs_fused_exchange_doubles(d, n_shards));
+  }
   if (rc) {
     set_error("virtual shards: out of device memory");
     return rc;
@@ -2010,7 +2194,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
     for (void* q : s->vs_owned) (void)hipFree(q);
     s->vs_owned.clear();
     d.V = 0;
-    d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = nullptr;
+    d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = d.vx = nullptr;
+    d.vsync = nullptr;
     set_error("virtual shards: n_features too large for the LDS-resident gather");
     return SGDNET_EUNSUPPORTED;
   }

@@ -252,7 +252,8 @@ class SagaSolver:
         form = self._L.sgdnet_solver_gather_form(self._h, min(batch, draws))
         return dict(gather_ms=g.value, gather_launches=ng.value, sweep_ms=w.value,
                     sweep_launches=nw.value,
-                    gather_kernel={1: "saga_batch_gather_lds_kernel", 2: "saga_binned_gather_kernel"}.get(
+                    gather_kernel={1: "saga_batch_gather_lds_kernel", 2: "saga_binned_gather_kernel",
+                                   3: "saga_vs_epoch_kernel"}.get(
                         form, "saga_batch_gather_kernel"))
 
     def deviance(self):
