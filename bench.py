@@ -80,9 +80,10 @@ def main():
     ap.add_argument("--conv-max-epochs", type=int, default=400)
     ap.add_argument("--vshards", type=int, default=-1,
                     help="virtual shards per GPU (DESIGN.md 8); -1 = the library's rule, 0/1 = off")
-    ap.add_argument("--fused-epoch", type=int, default=1, choices=[0, 1],
-                    help="1 (default): the library's option fused_epoch -- an epoch on virtual shards is ONE launch; "
-                         "0: one gather and one sweep launch per batch (round 3's structure, for A/B runs)")
+    ap.add_argument("--fused-epoch", type=int, default=1, choices=[0, 1, 2],
+                    help="the library's option fused_epoch -- 1 (default): an epoch on virtual shards is ONE launch; "
+                         "2: the same with write-through hand-offs always; 0: one gather and one sweep launch per "
+                         "batch (round 3's structure, for A/B runs)")
     ap.add_argument("--alt-merge", action="store_true",
                     help="N > 1: also measure the exchange scheme that --merge did not select")
     ap.add_argument("--no-alt-merge", action="store_true", help="(default; kept for old command lines)")

@@ -179,7 +179,9 @@ int sgdnet_device_count(void);
 /*                        consumer always                                    */
 /*   "fused_epoch"        1 (default): a batched epoch on virtual shards      */
 /*                        (sparse x, one response) is ONE launch whose        */
-/*                        workgroups synchronise shard by shard; 0: one       */
+/*                        workgroups synchronise shard by shard (a shard whose */
+/*                        workgroups share an XCD hands off through its L2);  */
+/*                        2: the same with write-through hand-offs always; 0: one */
 /*                        gather and one sweep launch per batch (what the     */
 /*                        library falls back to by itself when the GPU is     */
 /*                        shared and the launch cannot become resident)       */

@@ -55,6 +55,20 @@ int option(Option o);
 // src/constants.h:22 of the reference: 100 * DBL_EPSILON
 constexpr double kSmall = 100.0 * 2.220446049250313e-16;
 
+// The sample-order generators as the fused epoch kernel of the virtual shards runs them (saga_batched.hip): its
+// spare workgroups produce the NEXT epoch's raw words and jump the generators' start states while the epoch runs.
+// Lives in device memory (the captured launch reads it; `gen` is advanced by the kernel itself).
+struct RngDev {
+  uint32_t* state[2];     // start states of the generators: generation g reads state[g & 1], its jump writes state[(g + 1) & 1]
+  uint32_t* ends;         // where the state step leaves the generators (not used)
+  uint32_t* stream;       // two slots of n words: generation g fills slot g & 1
+  const uint32_t* poly;   // x^n mod phi(x): the jump of one epoch
+  int64_t n;              // draws per epoch
+  int64_t seg;            // words per generator
+  int gens;
+  unsigned gen;           // the generation the next producing launch makes
+};
+
 // Device view of one problem + its solver state.  Passed to kernels by value.
 struct SagaDev {
   int family;
@@ -83,6 +97,8 @@ struct SagaDev {
   // exchange buffer [2 parities x V published slices | V reference copies | c.w partials]
   unsigned* vsync;
   double* vx;
+  int vs_xcd_local;      // fused epoch kernel: shards whose workgroups share an XCD hand off through its L2 (plain stores)
+  RngDev* rngdev;        // sample-order generators inside the fused epoch kernel (cu_reserve workgroups), or nullptr
   unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
   int cu_reserve;    // CUs left to the sample-order generators that run beside the epoch (LDS gather grids shrink by it)
   int force_global;  // synchronous sharded mode: always the global-atomic gather (D must be one array)
@@ -155,6 +171,7 @@ struct LamParams {
   int64_t stream_wrap;   // > 0: the epoch's end wraps stream_base at this length (the two-epoch buffer of the sample-order pipeline)
   int64_t draws_per_epoch;
   int batch_seq;         // running batch id (claims)
+  int rng_generate;      // fused epoch kernel: this launch also produces the next generation of the sample order (SagaDev::rngdev)
   int stream_raw;        // the epoch's slot of the sample-order pipeline holds the generators' raw words: the fused epoch
                          // kernel turns them into draws itself (round 4; every other consumer gets a converted slot)
   // ConvergenceCheck scratch: bit patterns of max|dw| and max|w|
@@ -229,6 +246,7 @@ size_t vs_fused_sync_words();
 size_t vs_fused_exchange_doubles(const SagaDev& d, int n_shards);
 int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);
+int vs_fused_rng_workgroups(const SagaDev& d);
 bool compact_eligible(const SagaDev& d);
 int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* meta, hipStream_t st);
 int compact_entries(const SagaDev& d);

@@ -29,6 +29,7 @@
 
 #include "device_math.hpp"
 #include "r_rng_word.hpp"
+#include "r_rng_bodies.hpp"
 
 #ifndef SGDNET_BIN_BLOCK
 #define SGDNET_BIN_BLOCK 1024
@@ -680,8 +681,9 @@ struct K1Compact {
   // tickets handed out before the LDS counter exists: two per wavefront (the counter starts behind them)
   static __device__ __forceinline__ int static_tickets() { return 2 * (kLdsBlock / 64) * kTicket; }
 
-  __device__ __forceinline__ void begin(const SagaDev& d, const uint32_t* sp_, int m_, int blk, int nblk,
-                                        int* ticket_counter) {
+  // lane geometry, this wavefront's first two (static) tickets: no memory access
+  __device__ __forceinline__ void init(const SagaDev& d, const uint32_t* sp_, int m_, int blk, int nblk,
+                                       int* ticket_counter) {
     E = d.cE;                                     // entries in plane P: 12 (response in cmeta) or 11
     in_reg = E + 4;                               // entries of a row held in registers
     y_in_meta = E == 12;
@@ -711,8 +713,16 @@ struct K1Compact {
     b_nxt = tk.lo + ((kLdsBlock / 64) + wave) * kTicket;
     if (b_cur >= tk.hi) b_cur = m;
     if (b_nxt >= tk.hi) b_nxt = m;
+  }
+  // the sample ids of those two tickets (requested, not waited for)
+  __device__ __forceinline__ void request_first() {
     s_cur = b_cur < m ? sp[own_pos(b_cur)] : 0u;
     s_nxt = b_nxt < m ? sp[own_pos(b_nxt)] : 0u;
+  }
+  __device__ __forceinline__ void begin(const SagaDev& d, const uint32_t* sp_, int m_, int blk, int nblk,
+                                        int* ticket_counter) {
+    init(d, sp_, m_, blk, nblk, ticket_counter);
+    request_first();
   }
 
   __device__ __forceinline__ void tag_first() {
@@ -1987,7 +1997,7 @@ __global__ void saga_epoch_end_kernel(LamParams* lamp, int batches) {
 // --------------------------------------------------------------------------
 constexpr int kSyncLine = 32;                  // unsigned words per 128-B line: every polled word has a line of its own
 constexpr int kSyncGo = 0, kSyncExit = 1, kSyncStart = 2, kSyncCnt1 = 3, kSyncCnt2 = kSyncCnt1 + 8,
-              kSyncCol = kSyncCnt2 + 8;
+              kSyncXcd = kSyncCnt2 + 8, kSyncCol = kSyncXcd + 8;
 constexpr int kFusedMaxBps = 128;              // workgroups per shard
 constexpr int kSyncLines = kSyncCol + kFusedMaxBps;
 constexpr int kSyncSticky = kSyncLines;        // abort code of any launch since the host last looked (never reset on the device)
@@ -2007,6 +2017,21 @@ __device__ __forceinline__ void st2_sc1(f64x2_t x, __amdgpu_buffer_rsrc_t rs, ui
 }
 __device__ __forceinline__ f64x2_t ld2_sc1(__amdgpu_buffer_rsrc_t rs, uint32_t byte_off) {
   return __builtin_bit_cast(f64x2_t, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16));
+}
+// intra-shard hand-offs.  local: every workgroup of the shard runs on ONE XCD (verified at the start barrier from
+// XCC_ID), whose L2 is the coherence point of its CUs: a plain store lands there and stays, and the consumers'
+// L1-bypassing (sc1) loads are served from it -- nothing crosses the fabric.  Otherwise the write-through forms.
+__device__ __forceinline__ void st2_shard(f64x2_t x, __amdgpu_buffer_rsrc_t rs, uint32_t byte_off, bool local) {
+  if (local)
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), rs, (int)byte_off, 0, 0);
+  else
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, x), rs, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ void st_shard(double* q, double x, bool local) {
+  if (local)
+    *q = x;
+  else
+    __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void st_sc1(double* q, double x) {
   __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2045,9 +2070,8 @@ __device__ __forceinline__ bool fused_poll(unsigned* sync, int word, unsigned ta
 }
 
 // The start barrier (one lane per workgroup).  Returns true when the arbiter word says "go".
-__device__ __forceinline__ bool fused_start(unsigned* sync, LamParams* lamp) {
+__device__ __forceinline__ bool fused_start(unsigned* sync, LamParams* lamp, unsigned grid) {
   unsigned* go = sync + kSyncGo * kSyncLine;
-  const unsigned grid = gridDim.x;
   const long long t0 = wall_clock64();
   if (blockIdx.x == 0) {
     unsigned expect = 0u;
@@ -2094,17 +2118,52 @@ __device__ __forceinline__ double fused_block_sum(double a, double* red) {
   return t;
 }
 
+// every workgroup leaves through here: the last one out resets the counters for the next launch (and moves the
+// generators on when this launch produced a generation of the sample order)
+__device__ __forceinline__ void fused_leave(const SagaDev& d, LamParams* lamp, int nb, bool epoch_done) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned* sync = d.vsync;
+    if (epoch_done && blockIdx.x == 0) end_epoch(lamp, nb);
+    const unsigned prev = __hip_atomic_fetch_add(sync + kSyncExit * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev + 1u == gridDim.x) {
+      for (int wd = 0; wd < kSyncLines; ++wd)
+        __hip_atomic_store(sync + wd * kSyncLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (d.rngdev && lamp->rng_generate) d.rngdev->gen += 1u;
+    }
+  }
+}
+
 __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, LamParams* lamp, int nb, int every) {
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   __shared__ int ticket_counter;
   __shared__ int sh_ok;
   __shared__ double sh_red[kLdsBlock / 64];
   __shared__ double sh_val[4];                  // [0] b0 of the round, [1] sum of gc of the shard's batch
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x;
   const int64_t p = d.p;                        // K == 1, p even
   const int64_t P2 = p >> 1;
   const int S = d.v_bps, V = d.V;
-  const int v = (int)blockIdx.x / S, wi = (int)blockIdx.x - v * S;
+  if ((int)blockIdx.x >= V * S) {
+    // ---- the generators' workgroups: the NEXT epoch's raw words, then the generators' start states one epoch on ----
+    // (r_rng_bodies.hpp; nothing here waits for the epoch's workgroups, nor they for this)
+    if (d.rngdev && lamp->rng_generate) {
+      const RngDev* R = d.rngdev;
+      const unsigned gen = R->gen;
+      uint32_t* lds = reinterpret_cast<uint32_t*>(Dl);
+      const int rb = (int)blockIdx.x - V * S, nrb = (int)gridDim.x - V * S;
+      mt_state_body(rb, reinterpret_cast<uint32_t(*)[2][kMtN + 1]>(lds), R->state[gen & 1u], R->ends,
+                    R->stream + (int64_t)(gen & 1u) * R->n, R->n, R->seg, R->gens);
+      __syncthreads();
+      mt_jump_body(rb, nrb, lds, R->state[gen & 1u], R->state[(gen + 1u) & 1u], R->poly, R->gens);
+    }
+    fused_leave(d, lamp, nb, false);
+    return;
+  }
+  // workgroups are dealt round-robin over the XCDs: shard = index modulo V puts a shard's workgroups on one XCD when
+  // V == 8 (speed only; what the hardware really did is checked at the start barrier)
+  const int v = (int)blockIdx.x % V, wi = (int)blockIdx.x / V;
   const int F = 2 * (int)((p + 2 * S - 1) / (2 * S));            // features of a workgroup's slice (even)
   const int j0 = wi * F;
   const int jn = p - j0 < F ? (p - j0 > 0 ? (int)(p - j0) : 0) : F;
@@ -2136,11 +2195,35 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
   }
   // this workgroup's share of a shard-batch of m draws (the ranges K1Compact::begin hands out): [lo, hi)
   uint32_t* const stream_v = const_cast<uint32_t*>(d.stream) + sbase + (int64_t)v * dps;
-  auto convert_share = [&](int64_t t0, int m) {   // raw words -> draws from shard v's sample range, in place
+  // raw words -> draws from shard v's sample range, in place, in two steps: the words of this workgroup's share
+  // are requested early (conv_load), converted and stored a phase later (conv_store) -- no round trip is waited for
+  constexpr int kC = 8;                         // words per thread: shares of up to 8192 draws
+  auto conv_range = [&](int m, int& lo, int& hi) {
     const int share = ((m + S - 1) / S + kTicket - 1) / kTicket * kTicket;
-    const int lo = wi * share, hi = lo + share < m ? lo + share : m;
+    lo = wi * share;
+    hi = lo + share < m ? lo + share : m;
+  };
+  auto conv_load = [&](int64_t t0, int m, uint32_t (&x)[kC]) {
+    int lo, hi;
+    conv_range(m, lo, hi);
+    const uint32_t* q = stream_v + t0;
+#pragma unroll
+    for (int c = 0; c < kC; ++c) {
+      const int i = lo + (int)threadIdx.x + c * kLdsBlock;
+      x[c] = i < hi ? q[i] : 0u;
+    }
+  };
+  auto conv_store = [&](int64_t t0, int m, const uint32_t (&x)[kC]) {
+    int lo, hi;
+    conv_range(m, lo, hi);
     uint32_t* q = stream_v + t0;
-    for (int i = lo + tid; i < hi; i += kLdsBlock) q[i] = (uint32_t)lo_v + word_to_draw(q[i], n_d);
+#pragma unroll
+    for (int c = 0; c < kC; ++c) {
+      const int i = lo + (int)threadIdx.x + c * kLdsBlock;
+      if (i < hi) q[i] = (uint32_t)lo_v + word_to_draw(x[c], n_d);
+    }
+    for (int i = lo + (int)threadIdx.x + kC * kLdsBlock; i < hi; i += kLdsBlock)   // longer shares: one word at a time
+      q[i] = (uint32_t)lo_v + word_to_draw(q[i], n_d);
   };
 
 #ifdef SGDNET_PHASE_TIMING
@@ -2160,24 +2243,39 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
 #endif
   // ---- start barrier: before "go" nothing is modified ---------------------------------------------
   if (tid == 0) {
+    // which XCD runs this workgroup: the shard's workgroups OR their bits together before they arrive
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 15u;        // HW_REG_XCC_ID
+    __hip_atomic_fetch_or(sync + (kSyncXcd + v) * kSyncLine, 1u << xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_fetch_add(sync + kSyncStart * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    sh_ok = fused_start(sync, lamp) ? 1 : 0;
+    sh_ok = fused_start(sync, lamp, (unsigned)(V * S)) ? 1 : 0;
+    if (sh_ok) {
+      const unsigned mask = sync_load(sync, kSyncXcd + v);
+      sh_ok = (mask & (mask - 1u)) == 0u ? 3 : 1;        // bit 1: the whole shard on one XCD
+    }
   }
   for (int64_t i = tid; i < P2; i += kLdsBlock) D2[i] = f64x2_t{0.0, 0.0};
   __syncthreads();
   bool done = false;
   bool alive = sh_ok != 0;
+  const bool local = (sh_ok & 2) != 0 && d.vs_xcd_local != 0;
   int mi = 0;                                   // merges so far
-  K1Compact cg;
+  // the sample ids of a round's first two passes are requested a phase ahead; only they are carried over (the
+  // rest of K1Compact is lane geometry, set up again at the top of the round: fewer registers live across the phases)
+  uint32_t s_first = 0u, s_second = 0u;
   if (alive) {
     const int m0 = (int)(dps < m_full ? dps : m_full);
     if (raw_words) {
-      convert_share(0, m0);
+      uint32_t x0[kC];
+      conv_load(0, m0, x0);
+      conv_store(0, m0, x0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                          // the ids below are read by other waves than the ones that wrote them
     }
-    if (tid == 0) ticket_counter = K1Compact::static_tickets();
-    cg.begin(d, stream_v, m0, wi, S, &ticket_counter);
+    K1Compact nx;
+    nx.begin(d, stream_v, m0, wi, S, &ticket_counter);
+    s_first = nx.s_cur;
+    s_second = nx.s_nxt;
   }
   for (int r = 0; alive && r < nb; ++r) {
     const int64_t t0 = (int64_t)r * m_full;
@@ -2188,10 +2286,23 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     const bool merge_due = last || (r + 1) % every == 0;
 
     // ---- stage: long-row bits of the first draws (their ids were requested a phase ago), w, intercept --------
+    if (tid == 0) ticket_counter = K1Compact::static_tickets();
+    K1Compact cg;
+    cg.init(d, stream_v + t0, m, wi, S, &ticket_counter);
+    cg.s_cur = s_first;
+    cg.s_nxt = s_second;
     cg.tag_first();
+    int ts = threadIdx.x;                       // (opaque, as tq below)
+    asm volatile("" : "+v"(ts));
+    double cw = 0.0, bv = 0.0;                  // wave 0: requested in front of the staging loads (one round trip for all)
+    if ((ts >> 6) == 0) {
+      if (std_x && r > 0)
+        for (int k = ts & 63; k < S; k += 64) cw += ld_sc1(cwp + v * kFusedMaxBps + k);
+      bv = r == 0 ? d.b[0] : ld_sc1(d.vb + v);
+    }
     {
       constexpr int kStage = 8;                 // one round of loads for up to 16 384 coefficients
-      for (int64_t i0 = tid; i0 < P2; i0 += (int64_t)kLdsBlock * kStage) {
+      for (int64_t i0 = ts; i0 < P2; i0 += (int64_t)kLdsBlock * kStage) {
         f64x2_t t[kStage];
 #pragma unroll
         for (int q = 0; q < kStage; ++q) {
@@ -2206,20 +2317,16 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
         }
       }
     }
-    if (wave == 0) {                            // b0 = b_v - c . w_v
-      double cw = 0.0;
-      if (std_x && r > 0) {
-        for (int k = lane; k < S; k += 64) cw += ld_sc1(cwp + v * kFusedMaxBps + k);
-        cw = wave_sum(cw);
-      }
-      if (lane == 0) sh_val[0] = (r == 0 ? d.b[0] : ld_sc1(d.vb + v)) - cw;
+    if ((ts >> 6) == 0) {                       // b0 = b_v - c . w_v
+      cw = wave_sum(cw);
+      if ((ts & 63) == 0) sh_val[0] = bv - cw;
     }
     __syncthreads();
     if (r == 0 && std_x) {                      // c . w of the state the epoch starts from
       double a = 0.0;
-      for (int64_t j = tid; j < p; j += kLdsBlock) a += d.c[j] * Wl[j];
+      for (int64_t j = ts; j < p; j += kLdsBlock) a += d.c[j] * Wl[j];
       a = fused_block_sum(a, sh_red);
-      if (tid == 0) sh_val[0] -= a;
+      if (ts == 0) sh_val[0] -= a;
       __syncthreads();
     }
     const double b0 = sh_val[0];
@@ -2229,30 +2336,40 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     const double gct = cg.run(d, b0, Wl, Dl);
     __syncthreads();
     FPH(1);
+    // (an opaque copy of the thread id: nothing computed from it below can be hoisted out of the round and kept in
+    //  registers across the draw loop, which has none to spare)
+    int tq = threadIdx.x;
+    asm volatile("" : "+v"(tq));
+    const int lane = tq & 63, wave = tq >> 6;
+    const int64_t t0n = t0 + m_full;
+    const int mn = (int)(dps - t0n < m_full ? dps - t0n : m_full);
+    uint32_t xraw[kC];
+    const bool conv_next = !last && raw_words;
+    if (conv_next) conv_load(t0n, mn, xraw);    // the next round's share of the sample order: requested now
 
     // ---- publish the slab (write-through) and the sum of the gradient changes -----------------------
     {
       const uint32_t base = (uint32_t)(((int64_t)blockIdx.x * p) * 8);
-      for (int64_t i = tid; i < P2; i += kLdsBlock) {
-        st2_sc1(D2[i], rs_slab, base + (uint32_t)(i * 16));
+      for (int64_t i = tq; i < P2; i += kLdsBlock) {
+        st2_shard(D2[i], rs_slab, base + (uint32_t)(i * 16), local);
         D2[i] = f64x2_t{0.0, 0.0};
       }
       const double t = wave_sum(gct);
       if (lane == 0) sh_red[wave] = t;
       __syncthreads();
-      if (tid == 0) {
+      if (tq == 0) {
         double tot = 0.0;
         for (int wv = 0; wv < kLdsBlock / 64; ++wv) tot += sh_red[wv];
-        st_sc1(d.vd0 + blockIdx.x, tot);
+        st_shard(d.vd0 + blockIdx.x, tot, local);
       }
     }
     fused_arrive(sync, kSyncCnt1 + v);
     FPH(2);
     // behind the arrival, while the rest of the shard finishes: this workgroup's own coefficients (nobody else
     // writes them), and the next round's share of the sample order
-    const int64_t j = j0 + tid;
-    const bool upd = tid < jn;
-    const bool icpt = wi == 0 && tid == 0;
+    const int64_t j = j0 + tq;
+    const bool upd = tq < jn;
+    const bool icpt = wi == 0 && tq == 0;
     double w_old = 0.0, g_old = 0.0, c_own = 0.0, rg = 0.0, rw = 0.0, b_new = 0.0, gb_new = 0.0, rgb = 0.0, rb = 0.0;
     if (upd) {
       w_old = r == 0 ? d.w[j] : ld_sc1(vwv + j);
@@ -2271,23 +2388,24 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
         rb = mi == 0 ? d.b[0] : ld_sc1(refv + 2 * p + 1);
       }
     }
-    const int64_t t0n = t0 + m_full;
-    const int mn = (int)(dps - t0n < m_full ? dps - t0n : m_full);
-    if (!last && raw_words) convert_share(t0n, mn);
-    if (tid == 0) sh_ok = fused_poll(sync, kSyncCnt1 + v, (unsigned)S * (unsigned)(r + 1), lamp) ? 1 : 0;
+    if (conv_next) conv_store(t0n, mn, xraw);
+    if (tq == 0) sh_ok = fused_poll(sync, kSyncCnt1 + v, (unsigned)S * (unsigned)(r + 1), lamp) ? 1 : 0;
     __syncthreads();
     if (!sh_ok) break;
     FPH(3);
 
     // ---- sweep of this workgroup's feature slice ------------------------------------------------
     {
+      double gsum = 0.0;                        // requested in front of the slab loads
+      if (wave == kLdsBlock / 64 - 1)
+        for (int k = lane; k < S; k += 64) gsum += ld_sc1(d.vd0 + k * V + v);
       f64x2_t acc[kFusedChunks];
 #pragma unroll
       for (int c = 0; c < kFusedChunks; ++c) acc[c] = f64x2_t{0.0, 0.0};
       for (int k = wave; k < S; k += 2 * (kLdsBlock / 64)) {
         const bool two = k + kLdsBlock / 64 < S;
-        const uint32_t o0 = (uint32_t)((((int64_t)(v * S + k)) * p + j0) * 8);
-        const uint32_t o1 = (uint32_t)((((int64_t)(v * S + k + kLdsBlock / 64)) * p + j0) * 8);
+        const uint32_t o0 = (uint32_t)((((int64_t)(k * V + v)) * p + j0) * 8);
+        const uint32_t o1 = (uint32_t)((((int64_t)((k + kLdsBlock / 64) * V + v)) * p + j0) * 8);
         f64x2_t a0[kFusedChunks], a1[kFusedChunks];
 #pragma unroll
         for (int c = 0; c < kFusedChunks; ++c) {
@@ -2310,10 +2428,8 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
         if (2 * pi < F) reinterpret_cast<f64x2_t*>(Wl + (int64_t)wave * F)[pi] = acc[c];
       }
       if (wave == kLdsBlock / 64 - 1) {         // the shard's sum of gc (intercept accumulator; implicit centring)
-        double a = 0.0;
-        for (int k = lane; k < S; k += 64) a += ld_sc1(d.vd0 + v * S + k);
-        a = wave_sum(a);
-        if (lane == 0) sh_val[1] = a;
+        gsum = wave_sum(gsum);
+        if (lane == 0) sh_val[1] = gsum;
       }
     }
     __syncthreads();
@@ -2322,7 +2438,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     if (upd) {
       double dj = 0.0;
 #pragma unroll
-      for (int wv = 0; wv < kLdsBlock / 64; ++wv) dj += Wl[(int64_t)wv * F + tid];
+      for (int wv = 0; wv < kLdsBlock / 64; ++wv) dj += Wl[(int64_t)wv * F + tq];
       if (std_x) dj -= c_own * d0;              // implicit centring: D_j -= c_j * sum(gc)
       const double val = r_m * w_old - (gamma * ls_m) * g_old - gamma * dj;
       const double tau = beta * gamma * ls_m;
@@ -2353,20 +2469,24 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
         st_sc1(pubv + 2 * p + 1, b_new);
       }
       fused_arrive(sync, kSyncCol + wi);
-      if (tid == 0) sh_ok = fused_poll(sync, kSyncCol + wi, (unsigned)V * (unsigned)(mi + 1), lamp) ? 1 : 0;
+      if (tq == 0) sh_ok = fused_poll(sync, kSyncCol + wi, (unsigned)V * (unsigned)(mi + 1), lamp) ? 1 : 0;
       __syncthreads();
       if (!sh_ok) break;
       const double* pub0 = d.vx + (int64_t)((mi & 1) * V) * L;
-      if (upd) {
-        double xg[8], xw[8];
+      double xg[8], xw[8], xgb[8], xb[8];       // every load of the exchange first: one round trip
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          xg[u] = xw[u] = 0.0;
-          if (u < V) {
-            xg[u] = ld_sc1(pub0 + (int64_t)u * L + j);
-            xw[u] = ld_sc1(pub0 + (int64_t)u * L + p + j);
-          }
+      for (int u = 0; u < 8; ++u) {
+        xg[u] = xw[u] = xgb[u] = xb[u] = 0.0;
+        if (u < V && upd) {
+          xg[u] = ld_sc1(pub0 + (int64_t)u * L + j);
+          xw[u] = ld_sc1(pub0 + (int64_t)u * L + p + j);
         }
+        if (u < V && icpt) {
+          xgb[u] = ld_sc1(pub0 + (int64_t)u * L + 2 * p);
+          xb[u] = ld_sc1(pub0 + (int64_t)u * L + 2 * p + 1);
+        }
+      }
+      if (upd) {
         double mg = rg, mw = rw;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -2387,10 +2507,13 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
       }
       if (icpt) {
         double mgb = rgb, mb = rb;
-        for (int u = 0; u < V; ++u) {
-          const double wt = d.v_size[u] / tot_size;
-          mgb += wt * (ld_sc1(pub0 + (int64_t)u * L + 2 * p) - rgb);
-          mb += wt * (ld_sc1(pub0 + (int64_t)u * L + 2 * p + 1) - rb);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u < V) {
+            const double wt = d.v_size[u] / tot_size;
+            mgb += wt * (xgb[u] - rgb);
+            mb += wt * (xb[u] - rb);
+          }
         }
         gb_new = mgb;
         b_new = mb;
@@ -2405,16 +2528,16 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
       FPH(5);
     }
     if (upd) {
-      st_sc1(vwv + j, w_new);
-      st_sc1(vGv + j, g_new);
+      st_shard(vwv + j, w_new, local);
+      st_shard(vGv + j, g_new, local);
     }
     if (icpt) {
-      st_sc1(d.vb + v, b_new);
-      st_sc1(d.vgb + v, gb_new);
+      st_shard(d.vb + v, b_new, local);
+      st_shard(d.vgb + v, gb_new, local);
     }
     if (std_x) {                                // c . w of the slice, for the next round's linear predictors
       const double a = fused_block_sum(upd ? c_own * w_new : 0.0, sh_red);
-      if (tid == 0) st_sc1(cwp + v * kFusedMaxBps + wi, a);
+      if (tq == 0) st_shard(cwp + v * kFusedMaxBps + wi, a, local);
     }
     if (last) {
       done = true;
@@ -2423,25 +2546,19 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     fused_arrive(sync, kSyncCnt2 + v);
     FPH(6);
     // the next round's first sample ids, requested before the wait (converted by this workgroup a phase ago)
-    if (tid == 0) ticket_counter = K1Compact::static_tickets();
-    cg.begin(d, stream_v + t0n, mn, wi, S, &ticket_counter);
-    if (tid == 0) sh_ok = fused_poll(sync, kSyncCnt2 + v, (unsigned)S * (unsigned)(r + 1), lamp) ? 1 : 0;
+    {
+      K1Compact nx;
+      nx.begin(d, stream_v + t0n, mn, wi, S, &ticket_counter);
+      s_first = nx.s_cur;
+      s_second = nx.s_nxt;
+    }
+    if (tq == 0) sh_ok = fused_poll(sync, kSyncCnt2 + v, (unsigned)S * (unsigned)(r + 1), lamp) ? 1 : 0;
     __syncthreads();
     if (!sh_ok) break;
     FPH(7);
   }
 
-  // ---- leave: the epoch's bookkeeping, and the last workgroup out resets the counters ------------------
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    if (done && blockIdx.x == 0) end_epoch(lamp, nb);
-    const unsigned prev = __hip_atomic_fetch_add(sync + kSyncExit * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (prev + 1u == gridDim.x) {
-      for (int wd = 0; wd < kSyncLines; ++wd)
-        __hip_atomic_store(sync + wd * kSyncLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
+  fused_leave(d, lamp, nb, done);
 }
 
 // ConvergenceCheck (src/utils.h:240-262): max |w - w_prev| and max |w|, then w_prev = w.
@@ -3525,6 +3642,9 @@ bool vs_fused_eligible(const SagaDev& d) {
   return fused_lds_bytes(d) + kLdsStaticReserve <= kLdsPerCu;
 }
 
+// workgroups added to the launch for the sample-order generators (one per reserved CU)
+int vs_fused_rng_workgroups(const SagaDev& d) { return d.rngdev ? d.cu_reserve : 0; }
+
 int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   static bool attr_done_dev[64] = {};
   int cur_dev = 0;
@@ -3535,7 +3655,10 @@ int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStre
     attr_done_dev[cur_dev & 63] = true;
   }
   if (nb < 1 || every < 1) return SGDNET_EINVAL;
-  hipExtLaunchKernelGGL(saga_vs_epoch_kernel, dim3(vs_grid(d)), dim3(kLdsBlock), fused_lds_bytes(d), st, ev0, ev1, 0, d,
+  const int rng_wgs = vs_fused_rng_workgroups(d);
+  size_t lds = fused_lds_bytes(d);
+  if (rng_wgs > 0 && lds < kJumpLds) lds = kJumpLds;
+  hipExtLaunchKernelGGL(saga_vs_epoch_kernel, dim3(vs_grid(d) + rng_wgs), dim3(kLdsBlock), lds, st, ev0, ev1, 0, d,
                         lam, nb, every);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;

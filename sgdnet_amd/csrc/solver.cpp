@@ -86,6 +86,10 @@ struct sgdnet_solver {
     int64_t run_len = 0;   // virtual shards: draws per run of the layout (0: one run = the epoch)
     // the slot holds the generators' raw words (left to the fused epoch kernel, which converts its own shares)
     bool raw[2] = {false, false};
+    // generators inside the fused epoch kernel (SagaDev::rngdev): the generation that the next fused launch is to
+    // produce, or -1; a generation still pending when its draws are asked for is produced on the side stream after all
+    RngDev* dev = nullptr;
+    int64_t pending_gen = -1;
   } pipe;
   int64_t nnz = 0;
   bool penalty_set = false;
@@ -95,7 +99,7 @@ struct sgdnet_solver {
     int64_t batch, draws;
     hipGraph_t graph;
     hipGraphExec_t exec;
-    bool fused;                 // the epoch is ONE launch of saga_vs_epoch_kernel
+    int fused;                  // > 0: the epoch is ONE launch of saga_vs_epoch_kernel (the value of option fused_epoch)
   };
   std::vector<GraphEntry> graphs;
   hipGraphExec_t gexec = nullptr;
@@ -162,7 +166,8 @@ bool lam_on_device(const sgdnet_solver* s) {
   return a.penalty == b.penalty && a.gamma == b.gamma && a.alpha == b.alpha && a.beta == b.beta && a.r_full == b.r_full &&
          a.ls_full == b.ls_full && a.r_tail == b.r_tail && a.ls_tail == b.ls_tail && a.m_full == b.m_full &&
          a.m_tail == b.m_tail && a.stream_base == b.stream_base && a.stream_wrap == b.stream_wrap &&
-         a.draws_per_epoch == b.draws_per_epoch && a.batch_seq == b.batch_seq && a.stream_raw == b.stream_raw;
+         a.draws_per_epoch == b.draws_per_epoch && a.batch_seq == b.batch_seq && a.stream_raw == b.stream_raw &&
+         a.rng_generate == b.rng_generate;
 }
 
 // host mirror of end_epoch (saga_batched.hip)
@@ -471,16 +476,25 @@ bool vs_fused_active(const sgdnet_solver* s);
 int prepare_stream_slot(sgdnet_solver* s, int64_t batch, int64_t stream_offset, int64_t draws, int n_epochs) {
   auto& P = s->pipe;
   s->lam.stream_raw = 0;
-  if (!P.open || !(P.raw[0] || P.raw[1])) return SGDNET_OK;
+  s->lam.rng_generate = 0;
+  if (!P.open) return SGDNET_OK;
   const bool one_slot = n_epochs == 1 && draws == P.n && (stream_offset == 0 || stream_offset == P.n);
   const int slot = stream_offset == 0 ? 0 : 1;
-  if (one_slot && P.raw[slot] && vs_active(s, batch) && vs_fused_active(s)) {
+  const bool fused = one_slot && vs_active(s, batch) && vs_fused_active(s);
+  // the launch that consumes generation `used` also produces the pending generation used + 1 (its spare workgroups)
+  if (fused && s->d.rngdev && P.pending_gen >= 0 && P.pending_gen == P.used + 1 && slot == (int)(P.used & 1)) {
+    s->lam.rng_generate = 1;
+    P.pending_gen = -1;
+  }
+  if (!(P.raw[0] || P.raw[1])) return SGDNET_OK;
+  if (fused && P.raw[slot]) {
     s->lam.stream_raw = 1;
     P.raw[slot] = false;
     return SGDNET_OK;
   }
   for (int q = 0; q < 2; ++q) {
     if (!P.raw[q] || (one_slot && q != slot)) continue;
+    if (P.pending_gen >= 0 && (int)(P.pending_gen & 1) == q) continue;   // not produced yet (solver_rng_acquire will)
     if (!one_slot) SGD_HIP_TRY(hipStreamSynchronize(P.st));      // a slot that may still be generated
     int rc = launch_rng_convert(s->stream_dev + (int64_t)q * P.n, P.n, (uint32_t)s->d.n, s->st, s->d.V, s->d.v_size,
                                 P.run_len);
@@ -516,16 +530,17 @@ bool vs_fused_active(const sgdnet_solver* s) {
   if (s->fused_off || !option(kOptFusedEpoch) || !vs_fused_eligible(s->d)) return false;
   int cus = 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device) != hipSuccess) return false;
-  return s->d.V * s->d.v_bps <= cus;
+  return s->d.V * s->d.v_bps + vs_fused_rng_workgroups(s->d) <= cus;
 }
 
 int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std::vector<hipEvent_t>* ev) {
-  const SagaDev& d = s->d;
+  SagaDev& d = s->d;
   const int64_t dps = draws / d.V;
   if (batch > dps) batch = dps;
   const int nb = n_batches(batch, dps);
   const int every = vs_merge_batches(s, batch);
   if (vs_fused_active(s)) {
+    s->d.vs_xcd_local = option(kOptFusedEpoch) == 1 ? 1 : 0;
     if (ev) {
       hipEvent_t e[2];
       for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
@@ -618,11 +633,11 @@ int enqueue_epoch_kernels(sgdnet_solver* s, int64_t batch, int64_t draws, std::v
 }
 
 int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
-  const bool fused = vs_active(s, batch) && vs_fused_active(s);
+  const int fused = (vs_active(s, batch) && vs_fused_active(s)) ? option(kOptFusedEpoch) : 0;
   for (auto& g : s->graphs)
     if (g.batch == batch && g.draws == draws && g.fused == fused) {
       s->gexec = g.exec;
-      s->fused_in_graph = fused;
+      s->fused_in_graph = fused != 0;
       return SGDNET_OK;
     }
   if (s->graphs.size() >= 4) {   // a sharded epoch uses at most two shapes (segments + remainder)
@@ -632,7 +647,7 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
     (void)hipGraphDestroy(old.graph);
     s->graphs.erase(s->graphs.begin());
   }
-  s->fused_in_graph = fused;
+  s->fused_in_graph = fused != 0;
   SGD_HIP_TRY(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
   int rc = enqueue_epoch_kernels(s, batch, draws, nullptr);
   hipGraph_t g = nullptr;
@@ -654,6 +669,14 @@ int ensure_graph(sgdnet_solver* s, int64_t batch, int64_t draws) {
   }
   s->graphs.push_back({batch, draws, g, ex, fused});
   s->gexec = ex;
+  return SGDNET_OK;
+}
+
+// One epoch on the solver's stream: the captured graph -- or, where the epoch is ONE kernel anyway (fused epoch of the
+// virtual shards), that launch itself: a one-node graph replay left ~14 us between two epochs, a plain launch ~2.
+int launch_epoch(sgdnet_solver* s, int64_t batch, int64_t draws) {
+  if (s->fused_in_graph) return enqueue_epoch_kernels(s, batch, draws, nullptr);
+  SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
   return SGDNET_OK;
 }
 
@@ -880,7 +903,7 @@ struct OptionDef {
 const OptionDef kOptionDefs[sgdnet::kOptCount] = {
     {"virtual_shards", -1, -1, 8}, {"rng_generators", 0, 0, 64},     {"window_eigenvalue", 1, 0, 1},
     {"host_setup", 0, 0, 1},       {"exact_epoch_blocks", 1, 0, 1}, {"exact_row_registers", 1, 0, 4},
-    {"fused_epoch", 1, 0, 1},
+    {"fused_epoch", 1, 0, 2},
 };
 std::atomic<int> g_options[sgdnet::kOptCount] = {{-1}, {0}, {1}, {0}, {1}, {1}, {1}};
 int find_option(const char* name) {
@@ -1146,6 +1169,7 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
     if (s->pipe.state[i]) (void)hipFree(s->pipe.state[i]);
   }
   if (s->pipe.poly_n) (void)hipFree(s->pipe.poly_n);
+  if (s->pipe.dev) (void)hipFree(s->pipe.dev);
   if (s->pipe.ends) (void)hipFree(s->pipe.ends);
   if (s->st) (void)hipStreamDestroy(s->st);
   delete s;
@@ -1437,7 +1461,56 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   for (int i = 0; i < 2; ++i) SGD_HIP_TRY(hipEventRecord(P.freed[i], s->st));
   P.n = n;
   P.gens = P.used = 0;
+  P.pending_gen = -1;
+  P.raw[0] = P.raw[1] = false;
+  // the same generators as the fused epoch kernel of the virtual shards runs them on its spare workgroups
+  RngDev* want = nullptr;
+  if (generators > 1 && s->d.V > 1 && s->d.vsync) {
+    if (!P.dev) SGD_HIP_TRY(hipMalloc(reinterpret_cast<void**>(&P.dev), sizeof(RngDev)));
+    RngDev h{};
+    h.state[0] = P.state[0];
+    h.state[1] = P.state[1];
+    h.ends = P.ends;
+    h.stream = s->stream_dev;
+    h.poly = P.poly_n;
+    h.n = n;
+    h.seg = seg;
+    h.gens = generators;
+    h.gen = 0u;
+    SGD_HIP_TRY(hipMemcpy(P.dev, &h, sizeof(RngDev), hipMemcpyHostToDevice));
+    want = P.dev;
+  }
+  if (want != s->d.rngdev) {
+    s->d.rngdev = want;
+    drop_graph(s);
+  }
   P.open = true;
+  return SGDNET_OK;
+}
+
+// generation g of the sample order on the side stream: slot g & 1, start states state[g & 1] -> state[(g + 1) & 1]
+static int rng_side_generate(sgdnet_solver* s, int64_t g, bool keep_raw) {
+  auto& P = s->pipe;
+  const int slot = (int)(g & 1);
+  SGD_HIP_TRY(hipStreamWaitEvent(P.st, P.freed[slot], 0));
+  int rc;
+  P.raw[slot] = keep_raw;
+  if (P.G > 1) {
+    rc = launch_rng_fill(P.state[g & 1], P.ends, (uint32_t)s->d.n, s->stream_dev + (int64_t)slot * P.n, P.n,
+                         P.st, s->d.V, s->d.v_size, P.G, P.run_len, keep_raw ? 0 : 1);
+    // the jump's workgroups take their generators in turn: the side stream never holds more CUs than
+    // the generators' own (a wider launch would push gather workgroups into a second round)
+    if (!rc) rc = launch_rng_jump(P.state[g & 1], P.state[(g + 1) & 1], P.poly_n, P.G, P.st,
+                                  std::max(1, s->d.cu_reserve));
+  } else {
+    rc = launch_rng_fill(P.state[g & 1], P.state[(g + 1) & 1], (uint32_t)s->d.n,
+                         s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G, P.run_len,
+                         keep_raw ? 0 : 1);
+  }
+  if (rc) return rc;
+  if (P.dev)                                    // the in-kernel generators continue from here
+    SGD_HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(&P.dev->gen), (int)(g + 1), 1, P.st));
+  SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
   return SGDNET_OK;
 }
 
@@ -1446,28 +1519,22 @@ int solver_rng_prefetch(sgdnet_solver* s) {
   auto& P = s->pipe;
   if (!P.open || P.gens > P.used + 1) return SGDNET_EINVAL;
   SGD_HIP_TRY(hipSetDevice(s->device));
-  const int slot = (int)(P.gens & 1);
-  SGD_HIP_TRY(hipStreamWaitEvent(P.st, P.freed[slot], 0));
-  int rc;
-  // virtual shards with the fused epoch kernel: that kernel holds every CU but the generators' own for the whole
-  // epoch, where the conversion (tempering, unif_rand scaling, floor(n_v u): compute-bound) would take longer than
-  // the epoch; the slot keeps the raw words and every workgroup of the epoch kernel converts its own share
+  // Virtual shards with the fused epoch kernel: that kernel holds every CU for a whole epoch, so its own spare
+  // workgroups produce the next generation (raw words: every workgroup of the NEXT epoch's launch converts the share
+  // it reads), and nothing is launched here: the generation is pending until the launch that carries it is enqueued
+  // (prepare_stream_slot), or until its draws are asked for without such a launch (solver_rng_acquire).
+  // (Generators launched beside the epoch kernel raced it for CUs: dispatched together, one epoch workgroup per XCD
+  //  found its CU taken and the whole epoch waited for the generators, +215 us; dispatched later, their own
+  //  workgroups could stall until the epoch ended -- profiles/r04_rng_placement.txt.)
   const bool keep_raw = s->d.V > 1 && P.run_len == 0 && vs_fused_active(s);
-  P.raw[slot] = keep_raw;
-  if (P.G > 1) {
-    rc = launch_rng_fill(P.state[P.gens & 1], P.ends, (uint32_t)s->d.n, s->stream_dev + (int64_t)slot * P.n, P.n,
-                         P.st, s->d.V, s->d.v_size, P.G, P.run_len, keep_raw ? 0 : 1);
-    // the jump's workgroups take their generators in turn: the side stream never holds more CUs than
-    // the generators' own (a wider launch would push gather workgroups into a second round)
-    if (!rc) rc = launch_rng_jump(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], P.poly_n, P.G, P.st,
-                                  std::max(1, s->d.cu_reserve));
-  } else {
-    rc = launch_rng_fill(P.state[P.gens & 1], P.state[(P.gens + 1) & 1], (uint32_t)s->d.n,
-                         s->stream_dev + (int64_t)slot * P.n, P.n, P.st, s->d.V, s->d.v_size, P.G, P.run_len,
-                         keep_raw ? 0 : 1);
+  if (keep_raw && P.dev && s->d.rngdev && P.G > 1 && P.gens >= 1 && P.pending_gen < 0) {
+    P.pending_gen = P.gens;
+    P.raw[P.gens & 1] = true;
+    ++P.gens;
+    return SGDNET_OK;
   }
+  int rc = rng_side_generate(s, P.gens, keep_raw);
   if (rc) return rc;
-  SGD_HIP_TRY(hipEventRecord(P.ready[slot], P.st));
   ++P.gens;
   return SGDNET_OK;
 }
@@ -1477,6 +1544,13 @@ int solver_rng_acquire(sgdnet_solver* s, int64_t* offset) {
   auto& P = s->pipe;
   if (!P.open || P.gens <= P.used) return SGDNET_EINVAL;
   const int slot = (int)(P.used & 1);
+  if (P.pending_gen == P.used) {                // no fused launch carried this generation: the side stream makes it now
+    const int64_t g = P.pending_gen;
+    P.pending_gen = -1;
+    SGD_HIP_TRY(hipEventRecord(P.freed[slot], s->st));       // after everything enqueued so far
+    int rc = rng_side_generate(s, g, P.raw[slot]);
+    if (rc) return rc;
+  }
   SGD_HIP_TRY(hipStreamWaitEvent(s->st, P.ready[slot], 0));
   *offset = (int64_t)slot * P.n;
   return SGDNET_OK;
@@ -1495,10 +1569,25 @@ int solver_rng_close(sgdnet_solver* s, sgdnet_rng* rng) {
   auto& P = s->pipe;
   if (!P.open) return SGDNET_OK;
   SGD_HIP_TRY(hipSetDevice(s->device));
+  if (P.pending_gen >= 0) {                     // a generation nobody produced: it does not exist (the state below is
+    P.raw[P.pending_gen & 1] = false;           // the one after `used` epochs either way)
+    --P.gens;
+    P.pending_gen = -1;
+  }
   SGD_HIP_TRY(hipStreamSynchronize(P.st));
   SGD_HIP_TRY(hipStreamSynchronize(s->st));
   SGD_HIP_TRY(hipMemcpy(rng, P.state[P.used & 1], sizeof(sgdnet_rng), hipMemcpyDeviceToHost));
+  for (int q = 0; q < 2; ++q) {                 // a slot generated ahead for the fused epoch kernel and never consumed
+    if (!P.raw[q]) continue;
+    int rcq = launch_rng_convert(s->stream_dev + (int64_t)q * P.n, P.n, (uint32_t)s->d.n, s->st, s->d.V, s->d.v_size, P.run_len);
+    if (rcq) return rcq;
+    P.raw[q] = false;
+  }
   P.open = false;
+  if (s->d.rngdev) {
+    s->d.rngdev = nullptr;
+    drop_graph(s);
+  }
   if (s->d.cu_reserve) {
     s->d.cu_reserve = 0;
     if (s->d.V > 1) s->d.v_bps = lds_target_grid(s->d) / s->d.V;
@@ -1705,7 +1794,8 @@ int sgdnet_solver_run(sgdnet_solver* s, int mode, int64_t batch, int64_t stream_
         (void)hipEventCreate(&tev1);
       }
       if (tr) (void)hipEventRecord(tev0, s->st);
-      SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
+      rc = launch_epoch(s, batch, draws_per_epoch);
+      if (rc) return rc;
       if (tr) (void)hipEventRecord(tev1, s->st);
       g_trace_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - tl0).count();
       lam_advance(s, draws_per_epoch, nb);     // mirrors end_epoch on the device
@@ -1778,7 +1868,8 @@ int sgdnet_solver_enqueue_epochs(sgdnet_solver* s, int64_t batch, int64_t stream
   if (rc) return rc;
   const int nb = n_batches(batch, draws_per_epoch);
   for (int e = 0; e < n_epochs; ++e) {
-    SGD_HIP_TRY(hipGraphLaunch(s->gexec, s->st));
+    rc = launch_epoch(s, batch, draws_per_epoch);
+    if (rc) return rc;
     lam_advance(s, draws_per_epoch, nb);
   }
   return SGDNET_OK;
