@@ -22,11 +22,15 @@
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 #define SGD_DM_FN __host__ __device__ static inline
+/* the forms that read the built-in tables: device only in a HIP translation unit (the tables are device symbols
+ * there, a host call would have nothing to read -- and does not compile) */
+#define SGD_DM_TABFN __device__ static inline
 #ifndef SGD_TABLE_QUAL
 #define SGD_TABLE_QUAL static __device__ const
 #endif
 #else
 #define SGD_DM_FN static inline
+#define SGD_DM_TABFN static inline
 #ifndef SGD_TABLE_QUAL
 #define SGD_TABLE_QUAL static const
 #endif
@@ -34,17 +38,8 @@
 
 #include "sgdnet_detmath_tables.h"
 
-#if defined(__HIP_DEVICE_COMPILE__)
 #define SGD_EXP_TABPTR (&sgd_exp_tab[0][0])
 #define SGD_LOG_TABPTR (&sgd_log_tab[0][0])
-#elif defined(__HIPCC__)
-/* host pass of a HIP translation unit: the tables are device symbols; the host copies are not needed there */
-#define SGD_EXP_TABPTR ((const double*)0)
-#define SGD_LOG_TABPTR ((const double*)0)
-#else
-#define SGD_EXP_TABPTR (&sgd_exp_tab[0][0])
-#define SGD_LOG_TABPTR (&sgd_log_tab[0][0])
-#endif
 
 SGD_DM_FN uint64_t sgd_d2u(double x) {
   uint64_t u;
@@ -87,7 +82,7 @@ SGD_DM_FN double NAME(double x, TABPTR_T tab) { \
 }
 SGD_DEFINE_EXP(sgd_exp_from, const double*)
 
-SGD_DM_FN double sgd_exp(double x) { return sgd_exp_from(x, SGD_EXP_TABPTR); }
+SGD_DM_TABFN double sgd_exp(double x) { return sgd_exp_from(x, SGD_EXP_TABPTR); }
 
 /* `tab`: sgd_log_tab as 258 consecutive doubles, or a copy of it under the kernel's pointer type (see SGD_DEFINE_EXP) */
 #define SGD_DEFINE_LOG(NAME, TABPTR_T) \
@@ -116,7 +111,7 @@ SGD_DM_FN double NAME(double x, TABPTR_T tab) { \
 }
 SGD_DEFINE_LOG(sgd_log_from, const double*)
 
-SGD_DM_FN double sgd_log(double x) { return sgd_log_from(x, SGD_LOG_TABPTR); }
+SGD_DM_TABFN double sgd_log(double x) { return sgd_log_from(x, SGD_LOG_TABPTR); }
 
 
 #endif

@@ -186,8 +186,9 @@ int sgdnet_device_count(void);
 /*                        library falls back to by itself when the GPU is     */
 /*                        shared and the launch cannot become resident)       */
 /* Unknown names and out-of-range values return SGDNET_EINVAL.  Options are  */
-/* read when a fit starts; changing them during a fit on another thread      */
-/* affects later fits only.                                                  */
+/* read when a fit starts (exact_row_registers and fused_epoch: whenever     */
+/* sgdnet_solver_run / _enqueue_epochs is called, i.e. once per epoch block  */
+/* of a fit; the results do not depend on either); change them between fits. */
 /* ------------------------------------------------------------------------ */
 int sgdnet_set_option(const char* name, int value);
 int sgdnet_get_option(const char* name, int* value);

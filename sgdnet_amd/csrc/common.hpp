@@ -120,7 +120,8 @@ struct SagaDev {
   char* cP;           // n x 128 B: first cE entries (16-bit feature ids), response, gradient memory
   const char* cQ;     // n x 128 B: entries cE .. cE + 11 of the rows that have them
   const uint32_t* cmeta;  // 2 bits per sample: row longer than cE entries, response != 0 (binomial)
-  int cE;             // entries in plane P: 12 (binomial: the response is a bit of cmeta) or 11
+  int y_binary;       // binomial response verified to be 0 / 1 (solver.cpp): it may ride as one bit of cmeta
+  int cE;             // entries in plane P: 12 (binomial 0 / 1 response: a bit of cmeta) or 11
   int m_rec;          // one-response sparse fits: the gradient memory is inside the records (cP + 120), not in M
   char* m_base;       // ... its address for sample s is m_base + s * m_stride: (M, 8) or (cP + 120, 128)
   int m_stride;

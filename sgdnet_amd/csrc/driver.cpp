@@ -412,7 +412,9 @@ int64_t auto_batch(const Features& X, double max_sample_sqnorm, double* l_f = nu
     // larger dense x: the same power iteration through X itself, over evenly spaced rows
     // (rows x features <= 2e6 per step)
     const size_t p = (size_t)X.p, n = (size_t)X.n;
-    const size_t m_max = std::max<size_t>(1000, (size_t)2000000 / p);
+    // (2e6 elements per step, at least 1000 rows -- but never more than 16M elements: 1000 rows of 10^6 features
+    //  would be 8 GB)
+    const size_t m_max = std::max<size_t>(8, std::max<size_t>(std::min<size_t>(1000, (size_t)16000000 / p), (size_t)2000000 / p));
     const size_t stride = (n + m_max - 1) / m_max, m = (n + stride - 1) / stride;
     std::vector<double> v(p, 1.0 / std::sqrt((double)p)), w(p), u(m);
     double lmax = 0.0;
@@ -557,7 +559,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // L_F for the automatic window from a strided sample of the standardised rows (<= 2e6 elements), while
     // the column-major copy is still there; then transpose + row norms on the device
     if (ctl->mode != SGDNET_MODE_EXACT && ctl->batch <= 0 && p > 1) {
-      const int64_t m_max = std::max<int64_t>(1000, 2000000 / p);
+      const int64_t m_max = std::max<int64_t>(8, std::max<int64_t>(std::min<int64_t>(1000, 16000000 / p), 2000000 / p));   // <= 16M elements
       const int64_t stride = (n + m_max - 1) / m_max, m = (n + stride - 1) / stride;
       std::vector<double> xs((size_t)(m * p));
       int rcd = dense_sample_rows(*X.dev, stride, m, xs.data(), X.st);
@@ -832,8 +834,12 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
           return rc;
         }
         if (getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet]   lambda %d: a bin overflowed -> more room, again\n", li);
+        // (a cold restart: the warm start of the previous lambda goes too, since the void epoch has been applied to
+        //  it; the lambda gets its full max_iter again -- the draws of the void epochs stay consumed, as R's generator
+        //  would have it, and are counted in draws_used)
         rc = solver_reset_state(S, b0.data());
         if (rc) return rc;
+        epochs = 0;
         worse = 0;
         best_ratio = HUGE_VAL;
         converged = 0;
@@ -940,9 +946,19 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     // ... and whatever the order of a user-supplied lambda sequence: a fit whose deviance is above the
     // null model's (w = 0, intercept only -- the point every lambda can reach) is not a fit.
     const bool worse_than_previous = li > 0 && lambda[(size_t)li] < lambda[(size_t)li - 1] && dev > prev_dev * (1.0 + 1e-3);
-    const bool worse_than_null = dev > null_dev_scaled * (1.0 + 1e-3) || !std::isfinite(dev);
-    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && (worse_than_previous || worse_than_null) && batch > kWindowFloor &&
-        retries < 8) {
+    // (a null deviance of exactly 0 -- a constant response -- leaves nothing to compare with: every dev > 0 would
+    //  burn the whole ladder)
+    const bool worse_than_null = (null_dev_scaled > 0.0 && dev > null_dev_scaled * (1.0 + 1e-3)) || !std::isfinite(dev);
+    if (mode == SGDNET_MODE_BATCHED && ctl->batch <= 0 && (worse_than_previous || worse_than_null)) {
+      if (batch <= kWindowFloor || retries >= 8) {
+        // the ladder is exhausted and the fit is still worse than a point every lambda can reach: not a fit.
+        // mode = auto reruns the whole fit with the exact iteration (sgdnet_fit_*), explicit batched reports it
+        set_error("batched mode: the fit at lambda[%d] is worse than %s (deviance %.6g) after %d restarts down to a window of "
+                  "%lld draws; use mode = exact", li, worse_than_null ? "the null model" : "the previous lambda's", dev, retries,
+                  (long long)batch);
+        t_batched_diverged = true;
+        return SGDNET_EUNSUPPORTED;
+      }
       if (getenv("SGDNET_TRACE"))
         fprintf(stderr, "[sgdnet]   lambda %d: deviance %.6g (previous lambda %.6g, null model %.6g) -> window %lld / 4, again\n",
                 li, dev, prev_dev, null_dev_scaled, (long long)batch);

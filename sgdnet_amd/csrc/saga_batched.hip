@@ -3281,7 +3281,9 @@ bool compact_eligible(const SagaDev& d) {
   return (double)d.n * 2.0 * kCStride <= 48e9 && d.n < (int64_t)kIdMask;
 }
 
-int compact_entries(const SagaDev& d) { return d.family == SGDNET_BINOMIAL ? 12 : 11; }
+// (a binomial response in another coding -- proportions, -1 / +1: sgdnet_solver_create does not forbid it, only
+//  sgdnet_fit_* does -- keeps its value in the record: 11 entries)
+int compact_entries(const SagaDev& d) { return d.family == SGDNET_BINOMIAL && d.y_binary ? 12 : 11; }
 
 int launch_pack_compact(const SagaDev& d, char* P, char* Q, uint32_t* meta, hipStream_t st) {
   SGD_HIP_TRY(hipMemsetAsync(meta, 0, sizeof(uint32_t) * (size_t)((d.n + 15) / 16 + 1), st));

@@ -486,7 +486,19 @@ constexpr size_t kK1FixedLds = sizeof(double) * (kK1Sum + 128) + kOwnSlots;
 
 constexpr int kRing = 16;                                          // slots (a power of two)
 constexpr int kSlotHdr = 10;                                       // doubles per slot header
-constexpr unsigned kK1xSpinLimit = 1u << 24;                       // polls of ~100 cycles: a second
+// Every wait in these kernels gives up after kSpinLimitTicks of the 100 MHz wall clock (an exit every wavefront
+// reaches) -- by the clock, not by a poll count: a wait may legitimately span another wavefront's serial pass over
+// K * p entries (ConvergenceCheck, the rescale sweep), and a count of 2^24 polls (~1 s) could expire on ~1e8 of them.
+constexpr long long kSpinLimitTicks = 3000000000ll;                 // 30 s
+__device__ __forceinline__ bool spin_expired(unsigned& spins, long long& t0) {
+  if ((++spins & 4095u) != 0u) return false;
+  const long long now = wall_clock64();
+  if (t0 == 0) {
+    t0 = now;
+    return false;
+  }
+  return now - t0 > kSpinLimitTicks;
+}
 constexpr size_t kK1xFixedLds = kK1FixedLds + kRing * (sizeof(int) * kWave + sizeof(double) * (kWave + kSlotHdr)) + 32;
 
 // SoftThreshold (prox.h:32-39) of the register-resident kernels.  For s >= 0 (and for NaN operands)
@@ -653,10 +665,11 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
           if (u > total || stop) break;
           if (u - freed >= kRing) {                                  // ring full: the consumer frees a slot per draw
             unsigned spins = 0;
+            long long spin_t0 = 0;
             for (;;) {
               freed = (int64_t)ctrl_load(ctrl + 1);
               if (u - freed < kRing) break;
-              if (ctrl_load(ctrl + 2) != 0ull || ++spins > kK1xSpinLimit) {   // (the limit: an exit every wavefront reaches)
+              if (ctrl_load(ctrl + 2) != 0ull || spin_expired(spins, spin_t0)) {   // (the limit: an exit every wavefront reaches)
                 stop = true;
                 break;
               }
@@ -747,10 +760,11 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
   auto read_slot = [&](int64_t u) {
     if (u >= avail) {
       unsigned spins = 0;
+      long long spin_t0 = 0;
       for (;;) {
         avail = (int64_t)ctrl_load(ctrl);
         if (u < avail) break;
-        if (++spins > kK1xSpinLimit) {
+        if (spin_expired(spins, spin_t0)) {
           stalled = true;
           break;
         }
@@ -1108,15 +1122,18 @@ __global__ __launch_bounds__(2 * kWave) void saga_sparse_exact_k1x_kernel(SagaDe
 // draws share features all the time.  A row longer than a wavefront works on memory and alone: it waits for every draw
 // before it and every draw behind it waits for it (a stamp of its own at registration); so does the draw that finds
 // w_scale below SMALL and rescales w (the producers know which: the sequence of w_scale does not depend on the data).
-// Every wait loop gives up after kK1xSpinLimit polls or when another wavefront has raised the abort flag.
+// Every wait loop gives up after kSpinLimitTicks (spin_expired) or when another wavefront has raised the abort flag.
 // --------------------------------------------------------------------------
 constexpr int kCons = 6;                // consumer wavefronts (8 and 10 measured slower: the draws meet in the chain)
 constexpr int kProd = 2;               // producer wavefronts: draw i of a batch of sixteen belongs to producer i % kProd
 constexpr int kDepSlots = 16384;
 constexpr int kK1mCtrl = 8;         // produced, registered, chain_done, stop/abort, barrier count, converged, epochs, spare
-constexpr size_t kK1mFixedLds = sizeof(double) * ((size_t)kCons * kK1Sum + 128 + kRing * (kWave + kSlotHdr) + 4 + kWave) +
+constexpr int kHist = 2 * kWave;        // (sample, gradient) pairs of the latest draws: the producers read the gradient memory up to
+                                        // kRing + 32 + kCons draws ahead of the draw in hand, and a store of the last few draws before
+                                        // THAT read may not have landed: the history reaches past both
+constexpr size_t kK1mFixedLds = sizeof(double) * ((size_t)kCons * kK1Sum + 128 + kRing * (kWave + kSlotHdr) + 4 + kHist) +
                                 sizeof(unsigned long long) * (kK1mCtrl + 2 * kRing + kWave) +
-                                sizeof(int) * (kRing * kWave) + sizeof(unsigned) * (kWave + kDepSlots);
+                                sizeof(int) * (kRing * kWave) + sizeof(unsigned) * (kHist + kDepSlots);
 
 __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m_kernel(SagaDev d, const LamParams* lamp,
                                                                                     ExactCtl ctl) {
@@ -1132,14 +1149,14 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
   SGD_LDS(double)* rval = sexp + 128;                                         // [kRing][kWave]
   SGD_LDS(double)* rhdr = rval + kRing * kWave;                               // [kRing][kSlotHdr]
   SGD_LDS(double)* chainv = rhdr + kRing * kSlotHdr;                          // b, g_sum_intercept, w_scale at the epoch end, spare
-  SGD_LDS(double)* hist_g = chainv + 4;                                       // [kWave]
-  volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(hist_g + kWave);   // [kK1mCtrl]
+  SGD_LDS(double)* hist_g = chainv + 4;                                       // [kHist]
+  volatile SGD_LDS(unsigned long long)* ctrl = (volatile SGD_LDS(unsigned long long)*)(hist_g + kHist);   // [kK1mCtrl]
   volatile SGD_LDS(unsigned long long)* readslot = ctrl + kK1mCtrl;           // [kRing]: slot u % kRing was read for draw u
   volatile SGD_LDS(unsigned long long)* filled = readslot + kRing;            // [kRing]: slot u % kRing holds draw u
   volatile SGD_LDS(unsigned long long)* done_slot = filled + kRing;           // [kWave]: draw u complete -> [u % 64] = u + 1
   SGD_LDS(int)* ridx = (SGD_LDS(int)*)(done_slot + kWave);                    // [kRing][kWave]
-  SGD_LDS(unsigned)* hist_s = (SGD_LDS(unsigned)*)(ridx + kRing * kWave);     // [kWave]
-  SGD_LDS(unsigned)* lastw = hist_s + kWave;                                  // [kDepSlots]
+  SGD_LDS(unsigned)* hist_s = (SGD_LDS(unsigned)*)(ridx + kRing * kWave);     // [kHist]
+  SGD_LDS(unsigned)* lastw = hist_s + kHist;                                  // [kDepSlots]
   SGD_LDS(double)* sls = (SGD_LDS(double)*)(lastw + kDepSlots);               // [L]
   double* w = d.w;
   double* G = d.G;
@@ -1155,8 +1172,8 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
     readslot[tid] = 0ull;
     filled[tid] = 0ull;
   }
-  if (tid < kWave) {
-    done_slot[tid] = 0ull;
+  if (tid < kWave) done_slot[tid] = 0ull;
+  if (tid < kHist) {
     hist_s[tid] = 0xffffffffu;
     hist_g[tid] = 0.0;
   }
@@ -1183,6 +1200,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
   int spin_kind = 0;
   auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* c, unsigned long long target, bool eager = false) -> bool {
     unsigned spins = 0;
+    long long spin_t0 = 0;
     for (;;) {
       const unsigned long long now = ctrl_load(c);
       if (now >= target) break;
@@ -1191,7 +1209,7 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       ++spin_count[spin_kind];
 #endif
       if ((spins & 15u) == 15u && aborted()) return false;
-      if (++spins > kK1xSpinLimit) {
+      if (spin_expired(spins, spin_t0)) {
         if (lane == 0) ctrl[3] = 2ull;
         return false;
       }
@@ -1408,12 +1426,18 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
       if (mine) lastw[hsl] = it + 1u;
       if ((longrow || rescale) && lane == 0) ctrl[6] = (unsigned long long)(it + 1u);
       // ... and the sample: the latest of the 64 draws before this one that drew it too, if any, hands its gradient on
-      const int r0 = (int)(u & (kWave - 1));
-      const unsigned long long same = __ballot(hist_s[lane] == s);
-      int repeat_lane = -1;
-      if (same != 0ull) {
-        const unsigned long long rot = r0 ? ((same >> r0) | (same << (kWave - r0))) : same;     // bit k: lane (k + r0) % 64, age 64 - k
-        repeat_lane = ((63 - __builtin_clzll(rot)) + r0) & (kWave - 1);
+      const int r0 = (int)(u & (kHist - 1));
+      const unsigned long long same_lo = __ballot(hist_s[lane] == s), same_hi = __ballot(hist_s[kWave + lane] == s);
+      int repeat_lane = -1;                                            // entry of the LATEST of the kHist draws before this one
+      if ((same_lo | same_hi) != 0ull) {
+        // entries in order of age: r0 - 1 down to 0, then kHist - 1 down to r0 (all wave-uniform arithmetic)
+        const int h0 = r0 & (kWave - 1);
+        const unsigned long long below = h0 ? ((1ull << h0) - 1ull) : 0ull;
+        const unsigned long long cur = r0 < kWave ? same_lo : same_hi, oth = r0 < kWave ? same_hi : same_lo;
+        const int cur_base = r0 < kWave ? 0 : kWave, oth_base = r0 < kWave ? kWave : 0;
+        if (cur & below) repeat_lane = cur_base + 63 - __builtin_clzll(cur & below);
+        else if (oth) repeat_lane = oth_base + 63 - __builtin_clzll(oth);
+        else repeat_lane = cur_base + 63 - __builtin_clzll(cur & ~below);
       }
       lanes_publish();
       if (lane == 0) {
@@ -1435,7 +1459,10 @@ __global__ __launch_bounds__((kCons + kProd) * kWave) void saga_sparse_exact_k1m
         need = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
         if (need != 0u) {
           const unsigned v_it = need - 1u;                           // the latest earlier draw sharing a feature (or a hash slot)
-          const unsigned lo = it + 1u > (unsigned)kCons ? it + 1u - (unsigned)kCons : 0u;
+          // (a wavefront flags draw u complete only after it has REGISTERED its next draw u + kCons, so a draw that
+          //  has passed the registration wait may still find the stores of draws back to it - 2 kCons unacknowledged:
+          //  the window covers them; the older flags are almost always set already)
+          const unsigned lo = it + 1u > 2u * (unsigned)kCons ? it + 1u - 2u * (unsigned)kCons : 0u;
           spin_kind = 2;
           for (unsigned dd = lo; dd <= v_it && dd < it && ok; ++dd)
             ok = wait_ge(done_slot + ((base + dd) & (kWave - 1)), (unsigned long long)(base + dd + 1));
@@ -1722,11 +1749,12 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
   auto aborted = [&]() -> bool { return ctrl_load(ctrl + 2) != 0ull; };
   auto wait_ge = [&](volatile SGD_LDS(unsigned long long)* cnt, unsigned long long target, bool eager) -> bool {
     unsigned spins = 0;
+    long long spin_t0 = 0;
     for (;;) {
       const unsigned long long now = ctrl_load(cnt);
       if (now >= target) break;
       if ((spins & 15u) == 15u && aborted()) return false;
-      if (++spins > kK1xSpinLimit) {
+      if (spin_expired(spins, spin_t0)) {
         if (lane == 0) ctrl[2] = 2ull;
         return false;
       }
@@ -1830,7 +1858,7 @@ __global__ __launch_bounds__(kMc * kWave) void saga_sparse_exact_mc_kernel(SagaD
         need = (unsigned)__builtin_amdgcn_readfirstlane((int)need);
         if (need != 0u) {
           const unsigned v_it = need - 1u;
-          const unsigned lo = it + 1u > (unsigned)kMc ? it + 1u - (unsigned)kMc : 0u;
+          const unsigned lo = it + 1u > 2u * (unsigned)kMc ? it + 1u - 2u * (unsigned)kMc : 0u;   // (two rounds back: see the k1m kernel)
           for (unsigned dd = lo; dd <= v_it && dd < it && ok; ++dd)
             ok = wait_ge(done_slot + ((base + dd) & (kWave - 1)), (unsigned long long)(base + dd + 1), false);
           if (!ok) break;
@@ -2909,10 +2937,11 @@ __global__ __launch_bounds__(2 * kWave) void saga_dense_exact_small2_kernel(Saga
         if (u < total && !stop) {
         if (u - freed >= kSmallRing) {
           unsigned spins = 0;
+          long long spin_t0 = 0;
           for (;;) {
             freed = (int64_t)ctrl_load(ctrl + 1);
             if (u - freed < kSmallRing) break;
-            if (ctrl_load(ctrl + 2) != 0ull || ++spins > kK1xSpinLimit) {
+            if (ctrl_load(ctrl + 2) != 0ull || spin_expired(spins, spin_t0)) {
               stop = true;
               break;
             }
@@ -2969,10 +2998,11 @@ __global__ __launch_bounds__(2 * kWave) void saga_dense_exact_small2_kernel(Saga
   auto read_slot = [&](int64_t u) {
     if (u >= avail) {
       unsigned spins = 0;
+      long long spin_t0 = 0;
       for (;;) {
         avail = (int64_t)ctrl_load(ctrl);
         if (u < avail) break;
-        if (++spins > kK1xSpinLimit) {
+        if (spin_expired(spins, spin_t0)) {
           stalled = true;
           break;
         }

@@ -487,9 +487,12 @@ __global__ __launch_bounds__(kTB) void dense_xt_times_kernel(const double* x, co
 }
 
 // xt[j + i*p] = x[i + j*n]: 32 x 32 tiles through LDS, both sides coalesced
+// (tiles in a one-dimensional grid: grid.y stops at 65 535 = 2.09M features or samples)
 __global__ __launch_bounds__(256) void dense_transpose_kernel(const double* x, int64_t n, int64_t p, double* xt) {
   __shared__ double tile[32][33];
-  const int64_t i0 = (int64_t)blockIdx.x * 32, j0 = (int64_t)blockIdx.y * 32;
+  const int64_t tiles_i = (n + 31) / 32;
+  const int64_t tj = (int64_t)blockIdx.x / tiles_i, ti = (int64_t)blockIdx.x - tj * tiles_i;
+  const int64_t i0 = ti * 32, j0 = tj * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
   for (int r = ty; r < 32; r += 8) {
     const int64_t i = i0 + tx, j = j0 + r;
@@ -586,8 +589,12 @@ int dense_sample_rows(const DeviceSetup& S, int64_t stride, int64_t m, double* o
 int dense_setup_finish(DeviceSetup& S, hipStream_t st, double* max_sqnorm) {
   int rc;
   if ((rc = dmalloc(&S.xd_t, (size_t)S.n * (size_t)S.p))) return rc;
-  hipLaunchKernelGGL(dense_transpose_kernel, dim3((unsigned)((S.n + 31) / 32), (unsigned)((S.p + 31) / 32)), dim3(256), 0,
-                     st, S.xd_cm, S.n, S.p, S.xd_t);
+  const int64_t tiles = ((S.n + 31) / 32) * ((S.p + 31) / 32);
+  if (tiles > 0x7fffffffll) {
+    set_error("dense x of %lld x %lld is beyond the device setup's transpose", (long long)S.n, (long long)S.p);
+    return SGDNET_EUNSUPPORTED;
+  }
+  hipLaunchKernelGGL(dense_transpose_kernel, dim3((unsigned)tiles), dim3(256), 0, st, S.xd_cm, S.n, S.p, S.xd_t);
   SGD_HIP_TRY(hipGetLastError());
   unsigned long long* mb = nullptr;
   if ((rc = dmalloc(&mb, 1))) return rc;

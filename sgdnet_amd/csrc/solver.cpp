@@ -1078,6 +1078,15 @@ static int solver_create_impl(const sgdnet_problem* pb, DeviceSetup* adopt, sgdn
       d.c = c;
     }
   }
+  d.y_binary = 0;
+  if (d.family == SGDNET_BINOMIAL) {
+    d.y_binary = 1;
+    for (size_t i = 0; i < n * (size_t)d.Ky; ++i)
+      if (pb->y[i] != 0.0 && pb->y[i] != 1.0) {
+        d.y_binary = 0;
+        break;
+      }
+  }
   if (s->sparse && compact_eligible(d)) {
     // an optimisation, not a requirement: without the memory for the planes the K = 1 gather
     // reads the 256-B records
