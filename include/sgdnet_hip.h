@@ -33,10 +33,11 @@ extern "C" {
 #endif
 
 /* 2: sgdnet_control carries losses_sink / losses_ctx, sgdnet_set_option exists.  3: sgdnet_auc_*_rng, the option
- * exact_row_registers, sgdnet_solver_rng_layout (additions only).  A caller compiled against
+ * exact_row_registers, sgdnet_solver_rng_layout (additions only).  4: sgdnet_control ends with n_gpus / devices
+ * (a fit sharded over the GPUs of a node), sgdnet_solver_link_peers, the option fused_epoch.  A caller compiled against
  * another version must not pass its structs: the shim and the Python binding compare sgdnet_abi_version()
  * with this constant when they load the library. */
-#define SGDNET_ABI_VERSION 3
+#define SGDNET_ABI_VERSION 4
 
 /* error codes */
 #define SGDNET_OK          0
@@ -125,6 +126,15 @@ typedef struct sgdnet_control {
   int           device;               /* HIP device ordinal */
   sgdnet_losses_fn losses_sink;       /* debug: receives each lambda's losses (result.losses may then be NULL) */
   void*         losses_ctx;
+  /* ---- ABI 4: the fit sharded over several GPUs of one node (R: options(sgdnet.gpus = N)) ----
+   * n_gpus <= 1: one GPU, `device`.  n_gpus = 2..8: the samples are cut into n_gpus contiguous ranges, one solver per
+   * GPU (`devices[0 .. n_gpus)`, or device, device + 1, ... when devices is NULL), each with its own virtual shards;
+   * all replicas are averaged periodically inside the GPUs' epoch kernels by direct peer loads
+   * (sgdnet_solver_link_peers).  Batched iteration (mode = batched / auto) of sparse x with one response, the
+   * built-in generator, an even number of features; anything else returns SGDNET_EUNSUPPORTED.  The same device may
+   * be named more than once (the ranks then share its CUs: rehearsals on one GPU). */
+  int           n_gpus;
+  const int*    devices;
 } sgdnet_control;
 
 /* Caller-allocated mirror of the list returned by src/sgdnet.cpp:275-284. */
@@ -313,6 +323,18 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
  * run / enqueue with that batch has sized its scratch), 3 = the fused epoch of the virtual shards
  * (saga_vs_epoch_kernel: gathers, sweeps and merges of a whole epoch in one launch). */
 int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch);
+
+/* Sample-sharded solvers of ONE process, one per GPU of a node: after this call the periodic
+ * replica average of every solver's batched epochs runs over the virtual shards of ALL of them -- inside the
+ * fused epoch kernel, by direct loads from the other GPUs' exchange buffers (hipDeviceEnablePeerAccess) behind
+ * counters the ranks add to remotely; no collective library, no launch per merge.  Rank q holds a contiguous
+ * range of the samples; every solver needs the same number of virtual shards, and the epochs of all ranks must be
+ * enqueued (sgdnet_solver_enqueue_epochs) before any of them is waited for.  n == 1 unlinks.
+ * sgdnet_fit_sparse does all of this itself when control.n_gpus > 1. */
+int sgdnet_solver_link_peers(sgdnet_solver** solvers, int n);
+/* CUs a solver's batched launches may fill (0: the device's): linked solvers that share ONE GPU -- tests, or two
+ * fits side by side -- must fit their persistent launches side by side. */
+int sgdnet_solver_set_cu_budget(sgdnet_solver* s, int cus);
 
 /* 2 * sum_i Loss_i (src/utils.h:304-329) over the resident samples. */
 int sgdnet_solver_deviance(sgdnet_solver* s, double* out);

@@ -30,9 +30,10 @@ EXPORTS = [
     "sgdnet_solver_export_delta_weighted_async", "sgdnet_solver_set_virtual_shards", "sgdnet_solver_set_merge_period",
     "sgdnet_score_sparse", "sgdnet_score_dense", "sgdnet_predict_sparse", "sgdnet_predict_dense",
     "sgdnet_auc_sparse", "sgdnet_auc_dense", "sgdnet_auc_sparse_rng", "sgdnet_auc_dense_rng",
+    "sgdnet_solver_link_peers", "sgdnet_solver_set_cu_budget",
     "sgdnet_solver_rng_layout", "sgdnet_solver_rng_open", "sgdnet_solver_rng_next", "sgdnet_solver_rng_done", "sgdnet_solver_rng_close",
 ]
-ABI_VERSION = 3   # include/sgdnet_hip.h: SGDNET_ABI_VERSION
+ABI_VERSION = 4   # include/sgdnet_hip.h: SGDNET_ABI_VERSION
 MEASURES = {"deviance": 0, "mse": 1, "mae": 2, "class": 3, "auc": 4}
 
 FAMILIES = {"gaussian": 0, "binomial": 1, "multinomial": 2, "mgaussian": 3}
@@ -65,7 +66,8 @@ class Control(C.Structure):
                 ("unif", UNIF_FN), ("unif_ctx", C.c_void_p), ("seed", C.c_uint32),
                 ("rng_state", C.POINTER(Rng)),
                 ("mode", C.c_int), ("batch", C.c_int64), ("device", C.c_int),
-                ("losses_sink", LOSSES_FN), ("losses_ctx", C.c_void_p)]
+                ("losses_sink", LOSSES_FN), ("losses_ctx", C.c_void_p),
+                ("n_gpus", C.c_int), ("devices", C.POINTER(C.c_int))]
 
 
 class Result(C.Structure):
@@ -160,6 +162,8 @@ def load():
     L.sgdnet_solver_set_n_total.argtypes = [C.c_void_p, C.c_int64]
     L.sgdnet_solver_set_virtual_shards.argtypes = [C.c_void_p, C.c_int]
     L.sgdnet_solver_set_merge_period.argtypes = [C.c_void_p, C.c_int64]
+    L.sgdnet_solver_link_peers.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    L.sgdnet_solver_set_cu_budget.argtypes = [C.c_void_p, C.c_int]
     L.sgdnet_solver_export_delta_weighted_async.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     L.sgdnet_solver_convergence.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int)]
     L.sgdnet_solver_last_change.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -63,7 +63,7 @@ def _has_nan(a):
 def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None, lambda_=None,
            maxit=1000, standardize=True, intercept=True, thresh=0.001,
            standardize_response=False, *, debug=False, seed=0, rng=None, sample_stream=None,
-           unif=None, mode="exact", batch=0, device=0):
+           unif=None, mode="exact", batch=0, device=0, devices=None):
     """Fit an elastic-net GLM path with SAGA on one MI355X.
 
     Positional/keyword arguments up to `standardize_response` are those of the reference's
@@ -196,6 +196,11 @@ def sgdnet(x, y, family="gaussian", alpha=1, nlambda=100, lambda_min_ratio=None,
     ctl.mode = MODES[mode]
     ctl.batch = int(batch)
     ctl.device = int(device)
+    if devices is not None and len(devices) > 1:          # the fit sharded over several GPUs (control.n_gpus, ABI 4)
+        dev_arr = (C.c_int * len(devices))(*[int(v) for v in devices])
+        keep.append(dev_arr)
+        ctl.n_gpus = len(devices)
+        ctl.devices = dev_arr
 
     K, p, nl = n_classes, n_features, nlambda
     a0 = np.zeros((K, nl), order="F")

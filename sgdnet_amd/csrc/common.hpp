@@ -69,6 +69,17 @@ struct RngDev {
   unsigned gen;           // the generation the next producing launch makes
 };
 
+// Solvers linked for the replica average across GPUs (the fused epoch kernel's merge, saga_batched.hip): what every
+// rank's kernel needs to reach the others -- their exchange buffers and barrier counters (peer pointers, or
+// hipIpc mappings of them) and their shard sizes.  Lives in device memory.
+struct FusedPeers {
+  double* pub[8];         // every rank's exchange buffer (its SagaDev::vx), this rank's own included
+  unsigned* sync[8];      // every rank's barrier counters (SagaDev::vsync)
+  double vsize[8][8];     // samples of rank q's shard u
+  double tot_size;        // samples of the whole job
+  int n, rank;
+};
+
 // Device view of one problem + its solver state.  Passed to kernels by value.
 struct SagaDev {
   int family;
@@ -97,6 +108,9 @@ struct SagaDev {
   // exchange buffer [2 parities x V published slices | V reference copies | c.w partials]
   unsigned* vsync;
   double* vx;
+  FusedPeers* peers;     // linked solvers (one per GPU): their replicas take part in the merge; n_peers <= 1: none
+  int n_peers;
+  int cu_budget;         // > 0: CUs this solver may fill (several linked solvers sharing one GPU in tests); 0: the device's
   int vs_xcd_local;      // fused epoch kernel: shards whose workgroups share an XCD hand off through its L2 (plain stores)
   RngDev* rngdev;        // sample-order generators inside the fused epoch kernel (cu_reserve workgroups), or nullptr
   unsigned long long* dbg;  // SGDNET_PHASE_TIMING builds only: per-workgroup phase stamps
@@ -244,6 +258,8 @@ bool vs_eligible(const SagaDev& d, int m);
 // the whole epoch of the virtual shards in ONE launch (saga_vs_epoch_kernel)
 bool vs_fused_eligible(const SagaDev& d);
 size_t vs_fused_sync_words();
+size_t vs_fused_sync_sticky_word();
+size_t vs_fused_sync_col_word();
 size_t vs_fused_exchange_doubles(const SagaDev& d, int n_shards);
 int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);

@@ -674,17 +674,78 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   pb.y_rows = Ky;
   pb.device = ctl->device;
 
-  sgdnet_solver* S = nullptr;
-  pt.mark("response, path, step sizes");
-  int rc = X.dev ? solver_create_adopting(&pb, *X.dev, &S) : sgdnet_solver_create(&pb, &S);
-  if (rc) return rc;
-  pt.mark("solver create (pack + H2D)");
-  struct Guard {
-    sgdnet_solver* s;
-    ~Guard() { sgdnet_solver_destroy(s); }
-  } guard{S};
+  // ---- the fit sharded over several GPUs of the node (control.n_gpus, ABI 4) ----
+  // Rank q holds the samples [q n / N, (q + 1) n / N) on its own GPU with its own virtual shards; the ranks' epoch
+  // kernels average ALL replicas among themselves (sgdnet_solver_link_peers).  SS[0] == S leads: every rank holds
+  // the same coefficients after an epoch, so the path's decisions are taken from S and applied to all.
+  const int NG = ctl->n_gpus > 1 ? ctl->n_gpus : 1;
+  std::vector<int> rank_dev((size_t)NG, ctl->device);
+  std::vector<int64_t> rank_lo((size_t)NG + 1, 0);
+  if (NG > 1) {
+    if (NG > 8 || !X.sparse || X.dev || K != 1 || mode != SGDNET_MODE_BATCHED || (p & 1) || ctl->debug ||
+        ctl->sample_stream || ctl->unif) {
+      set_error("control.n_gpus = %d: a fit is sharded over GPUs in batched mode (mode = batched / auto with a window the "
+                "rule accepts), for sparse x with one response and an even number of features, with the built-in "
+                "generator and without debug losses (at most 8 GPUs)", NG);
+      return SGDNET_EUNSUPPORTED;
+    }
+    for (int q = 0; q < NG; ++q) {
+      rank_dev[(size_t)q] = ctl->devices ? ctl->devices[q] : ctl->device + q;
+      if (rank_dev[(size_t)q] < 0 || rank_dev[(size_t)q] >= ndev) {
+        set_error("control.n_gpus = %d: device %d out of range (%d devices)", NG, rank_dev[(size_t)q], ndev);
+        return SGDNET_EINVAL;
+      }
+      rank_lo[(size_t)q + 1] = n / NG * (q + 1) + std::min<int64_t>(q + 1, n % NG);     // sgdnet_amd/parallel.py: shard_bounds
+    }
+  }
+  rank_lo[(size_t)NG] = n;
 
-  rc = sgdnet_solver_set_state(S, 1, b0.data());
+  sgdnet_solver* S = nullptr;
+  std::vector<sgdnet_solver*> SS;
+  pt.mark("response, path, step sizes");
+  struct Guard {
+    std::vector<sgdnet_solver*>* ss;
+    ~Guard() {
+      for (sgdnet_solver* q : *ss) sgdnet_solver_destroy(q);
+    }
+  } guard{&SS};
+  int rc = SGDNET_OK;
+  if (NG == 1) {
+    rc = X.dev ? solver_create_adopting(&pb, *X.dev, &S) : sgdnet_solver_create(&pb, &S);
+    if (rc) return rc;
+    SS.push_back(S);
+  } else {
+    std::vector<int64_t> ptr_q;
+    for (int q = 0; q < NG && !rc; ++q) {
+      const int64_t lo = rank_lo[(size_t)q], hi = rank_lo[(size_t)q + 1];
+      sgdnet_problem pq = pb;
+      pq.n_samples = hi - lo;
+      pq.n_total = hi - lo;                       // local normalisation: a rank's shards average their own samples
+      ptr_q.assign(X.sptr.begin() + lo, X.sptr.begin() + hi + 1);
+      const int64_t off = ptr_q[0];
+      for (int64_t& v : ptr_q) v -= off;
+      pq.rowptr = ptr_q.data();
+      pq.colidx = X.sidx.data() + off;
+      pq.values = X.sval.data() + off;
+      pq.y = yt.data() + lo * Ky;
+      pq.device = rank_dev[(size_t)q];
+      sgdnet_solver* sq = nullptr;
+      rc = sgdnet_solver_create(&pq, &sq);
+      if (!rc) SS.push_back(sq);
+    }
+    if (rc) return rc;
+    S = SS[0];
+  }
+  pt.mark("solver create (pack + H2D)");
+  auto for_all = [&](auto f) -> int {
+    for (sgdnet_solver* q : SS) {
+      const int r = f(q);
+      if (r) return r;
+    }
+    return SGDNET_OK;
+  };
+
+  rc = for_all([&](sgdnet_solver* q) { return sgdnet_solver_set_state(q, 1, b0.data()); });
   if (rc) return rc;
   if (mode == SGDNET_MODE_BATCHED && K > 16 && !solver_batched_available(S, batch)) {
     // 17..64 classes have one batched form, the binned one, and it needs feature ranges (at most 2048 of them)
@@ -710,11 +771,31 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     if (n >= 200000)
       while (V < 8 && (int64_t)(2 * V) * 100 * p <= n) V *= 2;
     if (option(kOptVirtualShards) >= 0) V = option(kOptVirtualShards);
-    if (V >= 2 && V <= 8) {
+    if (NG > 1) {
+      // the job stays a V-way average (8 at most: what the averaging tolerates at these sizes), cut over
+      // the ranks -- at least two shards per rank (what the epoch kernel carries)
+      V = std::max(2, std::min(8, V) / NG);
+      std::vector<int> on_dev((size_t)ndev, 0);
+      for (int q = 0; q < NG; ++q) ++on_dev[(size_t)rank_dev[(size_t)q]];
+      for (int q = 0; q < NG && !rc; ++q) {
+        if (on_dev[(size_t)rank_dev[(size_t)q]] > 1)          // ranks that share a GPU (rehearsals) share its CUs
+          rc = sgdnet_solver_set_cu_budget(SS[(size_t)q], 256 / on_dev[(size_t)rank_dev[(size_t)q]]);
+        if (!rc) rc = sgdnet_solver_set_virtual_shards(SS[(size_t)q], V);
+        // a quarter of a shard's own epoch between two averages, the same draw count on every rank
+        if (!rc) rc = sgdnet_solver_set_merge_period(SS[(size_t)q], std::max<int64_t>(1, (n / NG / V) / 4));
+      }
+      if (!rc) rc = sgdnet_solver_link_peers(SS.data(), NG);
+      if (rc) return rc;
+      vshards = V;
+    } else if (V >= 2 && V <= 8) {
       rc = sgdnet_solver_set_virtual_shards(S, V);
       if (rc && rc != SGDNET_EUNSUPPORTED) return rc;
       if (!rc) vshards = V;
     }
+  }
+  if (NG > 1 && vshards < 2) {
+    set_error("control.n_gpus = %d: the sample order cannot be laid out per shard (explicit sample_stream?)", NG);
+    return SGDNET_EUNSUPPORTED;
   }
 
   // built-in generator: the draws are produced in HBM (r_rng_device.hip), one epoch ahead of
@@ -734,11 +815,15 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   } blk;
   const int64_t blk_epochs = std::max<int64_t>(1, std::min<int64_t>(64, (1 << 20) / std::max<int64_t>(1, n)));
   struct PipeGuard {
-    sgdnet_solver* s;
+    std::vector<sgdnet_solver*>* ss;
     sgdnet_rng* rng;
     bool on;
-    ~PipeGuard() { if (on) (void)solver_rng_close(s, rng); }
-  } pipe_guard{S, &draws.rng, false};
+    ~PipeGuard() {
+      if (!on) return;
+      sgdnet_rng scratch;
+      for (size_t q = 0; q < ss->size(); ++q) (void)solver_rng_close((*ss)[q], q == 0 ? rng : &scratch);
+    }
+  } pipe_guard{&SS, &draws.rng, false};
   if (pipe) {
     // batched mode with epochs of 200 000 draws or more: 8-32 generators side by side ON THE ONE
     // R STREAM (one makes 10M draws in 5.3 ms, six epochs of the batched kernels at C4): generator g
@@ -753,11 +838,35 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       // C4 epochs 1.07 / 0.93 / 0.86 ms with 8 / 16 / 32 generators (0.85 with the stream resident)
       gens = forced > 0 ? forced : (n >= 200000 ? (int)std::min<int64_t>(32, std::max<int64_t>(8, n / 300000)) : 1);
     }
-    rc = solver_rng_open(S, &draws.rng, n, gens);
-    if (rc) return rc;
-    pipe_guard.on = true;
-    rc = solver_rng_prefetch(S);
-    if (rc) return rc;
+    if (NG == 1) {
+      rc = solver_rng_open(S, &draws.rng, n, gens);
+      if (rc) return rc;
+      pipe_guard.on = true;
+      rc = solver_rng_prefetch(S);
+      if (rc) return rc;
+    } else {
+      // ONE R stream over all ranks: an epoch is n consecutive draws of set.seed()'s generator, rank q takes the
+      // n_q of them that start lo_q draws in -- its generators start there (the caller's state jumped lo_q draws,
+      // mt_jump.cpp) and move n draws per epoch like everybody's.  Rank 0's state after the fit is R's after
+      // epochs * n draws: what one GPU returns.
+      pipe_guard.on = true;
+      for (int q = 0; q < NG; ++q) {
+        sgdnet_rng start = draws.rng;
+        if (rank_lo[(size_t)q] > 0) {
+          std::vector<uint32_t> poly(624);
+          if (!mt_jump_poly((uint64_t)rank_lo[(size_t)q], poly.data())) {
+            set_error("control.n_gpus: the jump polynomial of the generator could not be formed");
+            return SGDNET_EHIP;
+          }
+          mt_jump_host(&draws.rng, poly.data(), &start);
+        }
+        const int64_t nq = rank_lo[(size_t)q + 1] - rank_lo[(size_t)q];
+        const int gq = std::max(2, gens / NG);
+        rc = solver_rng_open(SS[(size_t)q], &start, nq, gq, n);
+        if (!rc) rc = solver_rng_prefetch(SS[(size_t)q]);
+        if (rc) return rc;
+      }
+    }
   }
   std::vector<uint32_t> chunk((size_t)n);
   std::vector<double> w((size_t)(K * p)), b((size_t)K), xbb((size_t)K);
@@ -777,7 +886,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     const double L = (norm_max + (fit_intercept ? 1.0 : 0.0)) * L_scaling + alpha[(size_t)li];
     const double mu_n = 2.0 * (double)n * alpha[(size_t)li];
     const double gamma = 1.0 / (2.0 * L + std::min(L, mu_n));
-    rc = sgdnet_solver_set_penalty(S, penalty, gamma, alpha[(size_t)li], beta[(size_t)li]);
+    rc = for_all([&](sgdnet_solver* q) { return sgdnet_solver_set_penalty(q, penalty, gamma, alpha[(size_t)li], beta[(size_t)li]); });
     if (rc) return rc;
 
     unsigned epochs = 0;
@@ -792,6 +901,36 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       int64_t stream_off = 0;
       auto t0 = now();
       unsigned want_epochs = 1;
+      const bool multi = pipe && NG > 1;
+      if (multi) {
+        // every rank's epoch is enqueued before any of them is waited for: the ranks' kernels wait for each other
+        int64_t offs[8] = {0};
+        for (int q = 0; q < NG && !rc; ++q) {
+          rc = solver_rng_prefetch(SS[(size_t)q]);
+          if (!rc) rc = solver_rng_acquire(SS[(size_t)q], &offs[q]);
+        }
+        draws.pos += n;
+        t_rng += since(t0);
+        t0 = now();
+        for (int q = 0; q < NG && !rc; ++q)
+          rc = sgdnet_solver_enqueue_epochs(SS[(size_t)q], batch, offs[q], rank_lo[(size_t)q + 1] - rank_lo[(size_t)q], 1);
+        for (int q = 0; q < NG && !rc; ++q) rc = solver_rng_release(SS[(size_t)q]);
+        // ConvergenceCheck on every rank: the same coefficients everywhere, each rank keeps its own w_prev
+        for (int q = 0; q < NG && !rc; ++q) {
+          int cq = 0;
+          rc = sgdnet_solver_convergence(SS[(size_t)q], ctl->tol, &cq);
+          if (q == 0) converged = cq;
+          if (!rc && solver_fused_aborted(SS[(size_t)q])) {
+            set_error("control.n_gpus = %d: rank %d's epoch kernel could not run (its GPU is shared with other work, or "
+                      "the ranks' kernels did not get to run side by side)", NG, q);
+            rc = SGDNET_EHIP;
+          }
+        }
+        if (rc) return rc;
+        t_run += since(t0);
+        t0 = now();
+        epochs += 1;
+      } else {
       if (exact_blocks) {
         if (!blk.have || blk.cap - blk.used < n) {
           blk.start = draws.rng;
@@ -857,6 +996,7 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       t_run += since(t0);
       t0 = now();
       epochs += ran;
+      }   // one rank
       if (mode == SGDNET_MODE_BATCHED) {
         // guard of the automatic window: the stale-sum step is only stable below ~L_max/L_F
         // draws, and the bound used by sgdnet_auto_batch is optimistic for correlated
@@ -871,6 +1011,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
           rc = sgdnet_solver_get_state(S, 1, b.data());
           if (rc) return rc;
           for (int k = 0; k < K; ++k) finite = finite && std::isfinite(b[(size_t)k]);
+        }
+        if (!finite && NG > 1) {
+          set_error("control.n_gpus = %d: the batched iteration diverged (non-finite coefficients); fit on one GPU, or pass a "
+                    "smaller control.batch", NG);
+          return SGDNET_EUNSUPPORTED;
         }
         if (!finite) {
           // restart this lambda from the null model: first without virtual shards (their
@@ -936,7 +1081,12 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     };
 
     double dev = 0.0;
-    rc = sgdnet_solver_deviance(S, &dev);                                        // sgdnet.cpp:246-256
+    rc = for_all([&](sgdnet_solver* q) {                                         // sgdnet.cpp:246-256 (every rank: its samples)
+      double dq = 0.0;
+      const int r = sgdnet_solver_deviance(q, &dq);
+      dev += dq;
+      return r;
+    });
     if (rc) return rc;
     // Safety net of the automatic window: along a decreasing lambda path the deviance of the
     // training data can only fall.  A window that is too long for the data does not have to blow
@@ -962,13 +1112,13 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
       if (getenv("SGDNET_TRACE"))
         fprintf(stderr, "[sgdnet]   lambda %d: deviance %.6g (previous lambda %.6g, null model %.6g) -> window %lld / 4, again\n",
                 li, dev, prev_dev, null_dev_scaled, (long long)batch);
-      if (vshards > 1) {
+      if (vshards > 1 && NG == 1) {
         vshards = 0;
         rc = sgdnet_solver_set_virtual_shards(S, 0);
         if (rc) return rc;
       }
       auto_window = std::max<int64_t>(kWindowFloor, batch / 4);
-      rc = solver_reset_state(S, b0.data());
+      rc = for_all([&](sgdnet_solver* q) { return solver_reset_state(q, b0.data()); });
       if (rc) return rc;
       ++retries;
       --li;
@@ -1008,8 +1158,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   out->draws_used = draws.pos;
   if (pipe) {
     pipe_guard.on = false;
-    rc = solver_rng_close(S, &draws.rng);          // state after exactly the epochs that ran
-    if (rc) return rc;
+    for (size_t q = 0; q < SS.size(); ++q) {
+      sgdnet_rng other;
+      rc = solver_rng_close(SS[q], q == 0 ? &draws.rng : &other);   // (rank 0:) state after exactly the epochs that ran
+      if (rc) return rc;
+    }
   }
   if (exact_blocks && blk.have) {                    // state after exactly the draws that were used
     draws.rng = blk.start;
@@ -1089,7 +1242,7 @@ static int fit_sparse_impl(const sgdnet_csc* x, const double* y, int y_cols, con
       return SGDNET_EINVAL;
     }
   }
-  if (!option(kOptHostSetup)) {
+  if (!option(kOptHostSetup) && !(ctl->n_gpus > 1)) {   // (a fit sharded over several GPUs cuts the host copy into the ranks' ranges)
     // default: the per-fit O(nnz) passes run on the device (setup_device.hip)
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {

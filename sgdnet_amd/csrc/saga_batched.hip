@@ -2001,6 +2001,7 @@ constexpr int kSyncGo = 0, kSyncExit = 1, kSyncStart = 2, kSyncCnt1 = 3, kSyncCn
 constexpr int kFusedMaxBps = 128;              // workgroups per shard
 constexpr int kSyncLines = kSyncCol + kFusedMaxBps;
 constexpr int kSyncSticky = kSyncLines;        // abort code of any launch since the host last looked (never reset on the device)
+constexpr int kSyncSeq = kSyncLines + 1;       // linked solvers: launches since they were linked (their slice counters run on)
 constexpr int kFusedChunks = 3;                // 64-lane chunks of 16-byte pairs in a workgroup's feature slice
 constexpr long long kFusedStartTicks = 2000000;      // 20 ms of the 100 MHz wall clock: the start barrier
 constexpr long long kFusedWaitTicks = 200000000;     // 2 s: every later wait (never reached unless there is a bug)
@@ -2039,6 +2040,13 @@ __device__ __forceinline__ void st_sc1(double* q, double x) {
 __device__ __forceinline__ double ld_sc1(const double* q) {
   return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// across GPUs (fine-grained memory of a peer or of this device that peers write): system scope
+__device__ __forceinline__ void st_sys(double* q, double x) {
+  __hip_atomic_store(q, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double ld_sys(const double* q) {
+  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __device__ __forceinline__ unsigned sync_load(unsigned* sync, int word) {
   return __hip_atomic_load(sync + word * kSyncLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2052,10 +2060,13 @@ __device__ __forceinline__ void fused_arrive(unsigned* sync, int word) {
 }
 
 // one lane: counter >= target, or give up (returns false; *fail set on a timeout of this lane's own)
-__device__ __forceinline__ bool fused_poll(unsigned* sync, int word, unsigned target, LamParams* lamp) {
+// (system: the counter receives remote adds of linked solvers on other GPUs)
+__device__ __forceinline__ bool fused_poll(unsigned* sync, int word, unsigned target, LamParams* lamp, bool system = false) {
   const long long t0 = wall_clock64();
   for (unsigned spins = 1;; ++spins) {
-    if (sync_load(sync, word) >= target) return true;
+    const unsigned now = system ? __hip_atomic_load(sync + word * kSyncLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                : sync_load(sync, word);
+    if (now >= target) return true;
     __builtin_amdgcn_s_sleep(4);
     if ((spins & 63u) == 0) {
       if (sync_load(sync, kSyncGo) != 1u) return false;          // somebody else gave up
@@ -2128,8 +2139,12 @@ __device__ __forceinline__ void fused_leave(const SagaDev& d, LamParams* lamp, i
     if (epoch_done && blockIdx.x == 0) end_epoch(lamp, nb);
     const unsigned prev = __hip_atomic_fetch_add(sync + kSyncExit * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev + 1u == gridDim.x) {
-      for (int wd = 0; wd < kSyncLines; ++wd)
+      // (linked solvers: the other ranks add to this rank's slice counters whenever THEY get there -- those run on
+      //  from launch to launch, with the launch count as their base)
+      const bool linked = d.n_peers > 1;
+      for (int wd = 0; wd < (linked ? kSyncCol : kSyncLines); ++wd)
         __hip_atomic_store(sync + wd * kSyncLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (linked && epoch_done) __hip_atomic_fetch_add(sync + kSyncSeq * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d.rngdev && lamp->rng_generate) d.rngdev->gen += 1u;
     }
   }
@@ -2258,6 +2273,12 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
   __syncthreads();
   bool done = false;
   bool alive = sh_ok != 0;
+  unsigned col_base = 0u;                       // linked solvers: merges of the launches before this one
+  if (d.n_peers > 1) {
+    int merges = 0;
+    for (int r = 0; r < nb; ++r) merges += (r + 1 == nb || (r + 1) % every == 0) ? 1 : 0;
+    col_base = sync_load(sync, kSyncSeq) * (unsigned)merges;
+  }
   const bool local = (sh_ok & 2) != 0 && d.vs_xcd_local != 0;
   int mi = 0;                                   // merges so far
   // the sample ids of a round's first two passes are requested a phase ahead; only they are carried over (the
@@ -2459,43 +2480,72 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     FPH(4);
     if (merge_due) {
       // ---- periodic average of the replicas, slice by slice ------------------------------------------
+      // Linked solvers (one per GPU of a node, SagaDev::peers): the average runs over the replicas of EVERY rank.
+      // A workgroup publishes its slice in its own exchange buffer, adds to counter col[i] of every rank (remote
+      // atomics over xGMI), waits for its own counter and reads the ranks' buffers with direct loads: the
+      // "all-reduce" of this scheme is 2 (p / S) doubles per workgroup and shard, inside the epoch's one launch.
+      // Those buffers and counters are fine-grained allocations, the accesses system-scope (sc0 sc1).
+      const FusedPeers* PR = d.n_peers > 1 ? d.peers : nullptr;
+      const int NP = PR ? d.n_peers : 1;
       double* pubv = d.vx + (int64_t)((mi & 1) * V + v) * L;
-      if (upd) {
-        st_sc1(pubv + j, g_new);
-        st_sc1(pubv + p + j, w_new);
+      if (PR) {
+        if (upd) {
+          st_sys(pubv + j, g_new);
+          st_sys(pubv + p + j, w_new);
+        }
+        if (icpt) {
+          st_sys(pubv + 2 * p, gb_new);
+          st_sys(pubv + 2 * p + 1, b_new);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tq == 0)
+          for (int q = 0; q < NP; ++q)
+            __hip_atomic_fetch_add(PR->sync[q] + (kSyncCol + wi) * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      } else {
+        if (upd) {
+          st_sc1(pubv + j, g_new);
+          st_sc1(pubv + p + j, w_new);
+        }
+        if (icpt) {
+          st_sc1(pubv + 2 * p, gb_new);
+          st_sc1(pubv + 2 * p + 1, b_new);
+        }
+        fused_arrive(sync, kSyncCol + wi);
       }
-      if (icpt) {
-        st_sc1(pubv + 2 * p, gb_new);
-        st_sc1(pubv + 2 * p + 1, b_new);
-      }
-      fused_arrive(sync, kSyncCol + wi);
-      if (tq == 0) sh_ok = fused_poll(sync, kSyncCol + wi, (unsigned)V * (unsigned)(mi + 1), lamp) ? 1 : 0;
+      if (tq == 0)
+        sh_ok = fused_poll(sync, kSyncCol + wi, (unsigned)(NP * V) * (col_base + (unsigned)(mi + 1)), lamp, PR != nullptr) ? 1 : 0;
       __syncthreads();
       if (!sh_ok) break;
-      const double* pub0 = d.vx + (int64_t)((mi & 1) * V) * L;
-      double xg[8], xw[8], xgb[8], xb[8];       // every load of the exchange first: one round trip
+      double mg = rg, mw = rw, mgb = rgb, mb = rb;
+      const double tot_all = PR ? PR->tot_size : tot_size;
+      for (int q = 0; q < NP; ++q) {              // rank after rank, shard after shard: the same order everywhere
+        const double* pub0 = (PR ? PR->pub[q] : d.vx) + (int64_t)((mi & 1) * V) * L;
+        double xg[8], xw[8], xgb[8], xb[8];       // every load of a rank's exchange first: one round trip
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        xg[u] = xw[u] = xgb[u] = xb[u] = 0.0;
-        if (u < V && upd) {
-          xg[u] = ld_sc1(pub0 + (int64_t)u * L + j);
-          xw[u] = ld_sc1(pub0 + (int64_t)u * L + p + j);
+        for (int u = 0; u < 8; ++u) {
+          xg[u] = xw[u] = xgb[u] = xb[u] = 0.0;
+          if (u < V && upd) {
+            xg[u] = PR ? ld_sys(pub0 + (int64_t)u * L + j) : ld_sc1(pub0 + (int64_t)u * L + j);
+            xw[u] = PR ? ld_sys(pub0 + (int64_t)u * L + p + j) : ld_sc1(pub0 + (int64_t)u * L + p + j);
+          }
+          if (u < V && icpt) {
+            xgb[u] = PR ? ld_sys(pub0 + (int64_t)u * L + 2 * p) : ld_sc1(pub0 + (int64_t)u * L + 2 * p);
+            xb[u] = PR ? ld_sys(pub0 + (int64_t)u * L + 2 * p + 1) : ld_sc1(pub0 + (int64_t)u * L + 2 * p + 1);
+          }
         }
-        if (u < V && icpt) {
-          xgb[u] = ld_sc1(pub0 + (int64_t)u * L + 2 * p);
-          xb[u] = ld_sc1(pub0 + (int64_t)u * L + 2 * p + 1);
-        }
-      }
-      if (upd) {
-        double mg = rg, mw = rw;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           if (u < V) {
-            const double wt = d.v_size[u] / tot_size;
+            const double wt = (PR ? PR->vsize[q][u] : d.v_size[u]) / tot_all;
             mg += wt * (xg[u] - rg);
             mw += wt * (xw[u] - rw);
+            mgb += wt * (xgb[u] - rgb);
+            mb += wt * (xb[u] - rb);
           }
         }
+      }
+      if (upd) {
         g_new = mg;
         w_new = mw;
         st_sc1(refv + j, mg);
@@ -2506,15 +2556,6 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
         }
       }
       if (icpt) {
-        double mgb = rgb, mb = rb;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (u < V) {
-            const double wt = d.v_size[u] / tot_size;
-            mgb += wt * (xgb[u] - rgb);
-            mb += wt * (xb[u] - rb);
-          }
-        }
         gb_new = mgb;
         b_new = mb;
         st_sc1(refv + 2 * p, mgb);
@@ -3170,7 +3211,8 @@ int batched_max_classes() { return 64; }   // 17..64: sparse x only (binned form
 int lds_target_grid(const SagaDev& d) {
   static const int forced = exp_env_int("SGDNET_LDS_GRID", 0);
   if (forced > 0) return forced;
-  const int g = 256 - d.cu_reserve;
+  const int cus = d.cu_budget > 0 && d.cu_budget < 256 ? d.cu_budget : 256;
+  const int g = cus - d.cu_reserve;
   return g < 64 ? 64 : g;
 }
 
@@ -3630,7 +3672,9 @@ static size_t fused_lds_bytes(const SagaDev& d) {
   const int64_t part = (int64_t)(kLdsBlock / 64) * fused_slice(d);     // the slice sweep's per-wavefront partial sums
   return sizeof(double) * (size_t)(d.p + (part > d.p ? part : d.p)) + 16;
 }
-size_t vs_fused_sync_words() { return (size_t)(kSyncLines + 1) * kSyncLine; }
+size_t vs_fused_sync_words() { return (size_t)(kSyncLines + 2) * kSyncLine; }
+size_t vs_fused_sync_sticky_word() { return (size_t)kSyncSticky * kSyncLine; }
+size_t vs_fused_sync_col_word() { return (size_t)kSyncCol * kSyncLine; }
 size_t vs_fused_exchange_doubles(const SagaDev& d, int n_shards) {
   return (size_t)3 * n_shards * (size_t)(2 * d.p + 2) + (size_t)n_shards * kFusedMaxBps;
 }

@@ -56,9 +56,10 @@ int solver_create_adopting(const sgdnet_problem* pb, DeviceSetup& S, sgdnet_solv
 
 // solver.cpp: sample-order pipeline of the fit driver (the next epoch's draws are generated on a
 // side stream while the current epoch runs)
-int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators = 1);
+int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators = 1, int64_t jump_draws = 0);
 int solver_reset_state(sgdnet_solver* s, const double* b0);
 bool solver_bin_overflowed(const sgdnet_solver* s);
+bool solver_fused_aborted(const sgdnet_solver* s);   // the last ConvergenceCheck found a fused epoch launch that gave up
 int solver_grow_bins(sgdnet_solver* s);
 bool solver_batched_available(sgdnet_solver* s, int64_t batch);
 int solver_rng_prefetch(sgdnet_solver* s);

@@ -127,6 +127,7 @@ struct sgdnet_solver {
   bool fused_off = false;
   bool fused_in_graph = false;   // the captured epochs use it
   int fused_abort_seen = 0;      // LamParams::fused_abort as the last ConvergenceCheck read it
+  FusedPeers* peers_dev = nullptr;   // sgdnet_solver_link_peers
 };
 
 namespace {
@@ -735,7 +736,7 @@ int fused_recover(sgdnet_solver* s, int code, int64_t draws, int batches, bool* 
   s->fused_off = true;
   s->fused_abort_seen = 0;
   SGD_HIP_TRY(hipMemsetAsync(reinterpret_cast<char*>(s->lam_dev) + offsetof(LamParams, fused_abort), 0, sizeof(int), s->st));
-  SGD_HIP_TRY(hipMemsetAsync(s->d.vsync + vs_fused_sync_words() - 32, 0, sizeof(unsigned), s->st));
+  SGD_HIP_TRY(hipMemsetAsync(s->d.vsync + vs_fused_sync_sticky_word(), 0, sizeof(unsigned), s->st));
   if (code != 1) {
     set_error("batched mode: a wait inside the fused epoch kernel timed out (internal error; the epoch is void)");
     return SGDNET_EHIP;
@@ -1350,6 +1351,7 @@ int sgdnet_solver_generate_stream(sgdnet_solver* s, sgdnet_rng* rng, int64_t cou
 // w = g_sum = g_memory = g_sum_intercept = 0, intercept = b0 (K values): the state a fit starts
 // from (driver.cpp restarts a lambda from here when the automatic staleness window diverged)
 // Binned form, recovery from a bin overflow (driver.cpp): true when the last synchronisation found one.
+bool solver_fused_aborted(const sgdnet_solver* s) { return s && s->fused_abort_seen != 0; }
 bool solver_bin_overflowed(const sgdnet_solver* s) { return s && s->bin_overflowed; }
 
 // After an overflow: twice the room in every bin (rebuilt by the next run); after three doublings the
@@ -1410,7 +1412,9 @@ int solver_reset_state(sgdnet_solver* s, const double* b0) {
 // caller's generator for segment 0, and for segment g a generator seeded (set.seed scrambling,
 // r_rng.cpp) with floor(2^32 * unif_rand()) drawn from the caller's generator at this point.
 // One generator makes 10M draws in 5.3 ms, which is six epochs of the batched kernels at C4.
-int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators) {
+// jump_draws: draws of the WHOLE job per epoch when this solver holds one rank's range of a stream shared by several
+// (driver.cpp, control.n_gpus); 0: n
+int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators, int64_t jump_draws) {
   SGD_HIP_TRY(hipSetDevice(s->device));
   auto& P = s->pipe;
   if (generators < 1) generators = 1;
@@ -1432,7 +1436,8 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   // keeps a single generator.
   const int64_t seg = (n + generators - 1) / generators;
   std::vector<uint32_t> poly_seg(624), poly_n(624);
-  if (generators > 1 && !(mt_jump_poly((uint64_t)seg, poly_seg.data()) && mt_jump_poly((uint64_t)n, poly_n.data())))
+  if (generators > 1 && !(mt_jump_poly((uint64_t)seg, poly_seg.data()) &&
+                          mt_jump_poly((uint64_t)(jump_draws > 0 ? jump_draws : n), poly_n.data())))
     generators = 1;
   P.G = generators;
   {
@@ -1905,7 +1910,7 @@ int sgdnet_solver_sync(sgdnet_solver* s) {
   SGD_HIP_TRY(hipSetDevice(s->device));
   if (s->fused_in_graph && s->d.vsync) {        // epochs enqueued without a check of their own: did a fused launch give up?
     unsigned code = 0;
-    SGD_HIP_TRY(hipMemcpyAsync(&code, s->d.vsync + vs_fused_sync_words() - 32, sizeof(unsigned), hipMemcpyDeviceToHost, s->st));
+    SGD_HIP_TRY(hipMemcpyAsync(&code, s->d.vsync + vs_fused_sync_sticky_word(), sizeof(unsigned), hipMemcpyDeviceToHost, s->st));
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     if (code) {
       bool rerun = false;
@@ -2254,6 +2259,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   d.V = 0;
   d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = d.vx = nullptr;
   d.vsync = nullptr;
+  d.peers = nullptr;                            // links name the buffers just freed: link again
+  d.n_peers = 0;
   if (n_shards < 2) return SGDNET_OK;
   if (d.K > 16 || (d.K > 1 && !s->sparse)) {
     set_error("virtual shards: one response, or up to 16 classes of sparse x");
@@ -2275,11 +2282,22 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   if (!rc) rc = alloc(&d.vcw, 8 * (size_t)d.K);
   if (!rc) rc = alloc(&d.vd0, 256 * (size_t)d.K);
   if (!rc) rc = alloc(&d.vref, (size_t)(2 * KP + 2 * d.K));
-  if (!rc && d.K == 1) {                        // the fused epoch kernel's barrier counters and exchange buffer
-    double* words = nullptr;
-    rc = alloc(&words, (vs_fused_sync_words() * sizeof(unsigned) + sizeof(double) - 1) / sizeof(double));
-    d.vsync = reinterpret_cast<unsigned*>(words);
-    if (!rc) rc = alloc(&d.vx, vs_fused_exchange_doubles(d, n_shards));
+  if (!rc && d.K == 1) {
+    // the fused epoch kernel's barrier counters and exchange buffer: fine-grained device memory, because linked
+    // solvers on other GPUs add to the counters and read the buffer while the kernels run (sgdnet_solver_link_peers)
+    auto alloc_fg = [&](void** out, size_t bytes) -> int {
+      void* q = nullptr;
+      if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc(&q, bytes) != hipSuccess) return SGDNET_ENOMEM;   // (one GPU: any device memory will do)
+      }
+      (void)hipMemset(q, 0, bytes);
+      s->vs_owned.push_back(q);
+      *out = q;
+      return SGDNET_OK;
+    };
+    rc = alloc_fg(reinterpret_cast<void**>(&d.vsync), vs_fused_sync_words() * sizeof(unsigned));
+    if (!rc) rc = alloc_fg(reinterpret_cast<void**>(&d.vx), vs_fused_exchange_doubles(d, n_shards) * sizeof(double));
   }
   if (rc) {
     set_error("virtual shards: out of device memory");
@@ -2298,6 +2316,86 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
     d.vsync = nullptr;
     set_error("virtual shards: n_features too large for the LDS-resident gather");
     return SGDNET_EUNSUPPORTED;
+  }
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_set_cu_budget(sgdnet_solver* s, int cus) {
+  if (!s || cus < 0) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  s->d.cu_budget = cus;
+  if (s->d.V > 1) s->d.v_bps = lds_target_grid(s->d) / s->d.V;
+  drop_graph(s);
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_link_peers(sgdnet_solver** solvers, int n) {
+  if (!solvers || n < 1 || n > 8) {
+    set_error("sgdnet_solver_link_peers: 1..8 solvers");
+    return SGDNET_EINVAL;
+  }
+  for (int q = 0; q < n; ++q) {
+    sgdnet_solver* s = solvers[q];
+    if (!s || !s->d.vsync || !s->d.vx || s->d.V < 1 || s->d.V != solvers[0]->d.V || s->d.v_bps != solvers[0]->d.v_bps ||
+        s->d.p != solvers[0]->d.p || s->d.K != 1) {
+      set_error("sgdnet_solver_link_peers: every solver needs the same number of virtual shards (>= 2), workgroups per shard "
+                "and features, and one response (rank %d does not)", q);
+      return SGDNET_EUNSUPPORTED;
+    }
+    if (n > 1 && !vs_fused_eligible(s->d)) {
+      set_error("sgdnet_solver_link_peers: the replica average across GPUs runs inside the fused epoch kernel, which rank %d's "
+                "problem cannot use (sparse x, one response, an even number of features)", q);
+      return SGDNET_EUNSUPPORTED;
+    }
+  }
+  double tot = 0.0;
+  for (int q = 0; q < n; ++q)
+    for (int u = 0; u < solvers[q]->d.V; ++u) tot += solvers[q]->d.v_size[u];
+  for (int q = 0; q < n; ++q) {
+    sgdnet_solver* s = solvers[q];
+    SGD_HIP_TRY(hipSetDevice(s->device));
+    SGD_HIP_TRY(hipStreamSynchronize(s->st));
+    drop_graph(s);
+    if (n == 1) {
+      s->d.peers = nullptr;
+      s->d.n_peers = 0;
+      continue;
+    }
+    for (int r = 0; r < n; ++r) {               // direct loads, stores and atomics on the other ranks' buffers
+      if (solvers[r]->device == s->device) continue;
+      int can = 0;
+      SGD_HIP_TRY(hipDeviceCanAccessPeer(&can, s->device, solvers[r]->device));
+      if (!can) {
+        set_error("sgdnet_solver_link_peers: device %d cannot access device %d", s->device, solvers[r]->device);
+        return SGDNET_EUNSUPPORTED;
+      }
+      const hipError_t e = hipDeviceEnablePeerAccess(solvers[r]->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+        set_error("hipDeviceEnablePeerAccess(%d -> %d) failed: %s", s->device, solvers[r]->device, hipGetErrorString(e));
+        return SGDNET_EHIP;
+      }
+      (void)hipGetLastError();
+    }
+    FusedPeers h{};
+    h.n = n;
+    h.rank = q;
+    h.tot_size = tot;
+    for (int r = 0; r < n; ++r) {
+      h.pub[r] = solvers[r]->d.vx;
+      h.sync[r] = solvers[r]->d.vsync;
+      for (int u = 0; u < 8; ++u) h.vsize[r][u] = solvers[r]->d.v_size[u];
+    }
+    if (!s->peers_dev) {
+      void* pd = nullptr;
+      SGD_HIP_TRY(hipMalloc(&pd, sizeof(FusedPeers)));
+      s->owned.push_back(pd);
+      s->peers_dev = static_cast<FusedPeers*>(pd);
+    }
+    SGD_HIP_TRY(hipMemcpy(s->peers_dev, &h, sizeof(FusedPeers), hipMemcpyHostToDevice));
+    SGD_HIP_TRY(hipMemset(s->d.vsync, 0, vs_fused_sync_words() * sizeof(unsigned)));   // slice counters and launch count start together
+    s->d.peers = s->peers_dev;
+    s->d.n_peers = n;
   }
   return SGDNET_OK;
 }

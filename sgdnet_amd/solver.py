@@ -80,6 +80,14 @@ def get_option(name):
     return v.value
 
 
+def link_peers(solvers):
+    """sgdnet_solver_link_peers: the replica average of these sample-sharded solvers (one per GPU) runs over the
+    virtual shards of all of them, inside their fused epoch kernels.  An empty / one-element list unlinks."""
+    L = _lib.load()
+    arr = (C.c_void_p * len(solvers))(*[s._h for s in solvers])
+    check(L.sgdnet_solver_link_peers(arr, len(solvers)))
+
+
 class option:
     """with sgdnet_amd.option("virtual_shards", 0): ...   -- the previous value comes back on exit."""
 
@@ -310,6 +318,10 @@ class SagaSolver:
 
     def set_merge_period(self, draws_per_shard):
         check(self._L.sgdnet_solver_set_merge_period(self._h, draws_per_shard))
+
+    def set_cu_budget(self, cus):
+        """CUs this solver's batched launches may fill (0: the device's): linked solvers sharing one GPU."""
+        check(self._L.sgdnet_solver_set_cu_budget(self._h, int(cus)))
 
     def sharded_stream(self, rngs, epochs):
         """Host-side sample order for virtual shards: per epoch, shard after shard, n // V draws

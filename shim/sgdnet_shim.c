@@ -29,7 +29,8 @@
  *     (src/sgdnet.cpp:275-284);
  *   - inputs are borrowed read-only; failures become R errors after cleanup.
  * Backend extensions are read from R options so that the R code needs no change:
- *   options(sgdnet.mode = "exact" | "batched" | "auto", sgdnet.batch = <int>, sgdnet.device = <int>)
+ *   options(sgdnet.mode = "exact" | "batched" | "auto", sgdnet.batch = <int>, sgdnet.device = <int>,
+ *           sgdnet.gpus = <int>)
  */
 #include <R.h>
 #include <Rinternals.h>
@@ -117,6 +118,10 @@ static void fill_control(SEXP control, sgdnet_control* c) {
   if (opt != R_NilValue) c->batch = (int64_t)Rf_asReal(opt);
   opt = Rf_GetOption1(Rf_install("sgdnet.device"));
   if (opt != R_NilValue) c->device = Rf_asInteger(opt);
+  /* options(sgdnet.gpus = N): the fit sharded over GPUs device .. device + N - 1 of this node (ABI 4; batched
+   * iteration of sparse x with one response, the backend says so otherwise) */
+  opt = Rf_GetOption1(Rf_install("sgdnet.gpus"));
+  if (opt != R_NilValue && Rf_asInteger(opt) > 1) c->n_gpus = Rf_asInteger(opt);
 }
 
 /* Debug losses (options(sgdnet.debug = TRUE)): the backend reports each lambda's per-epoch losses

@@ -97,3 +97,77 @@ def test_fit_with_the_generators_inside_the_epoch_kernel(sa):
     host.stream(n, a.draws_used)
     want = host.unif(32)
     assert np.array_equal(want, rngs[1].unif(32)) and np.array_equal(want, rngs[0].unif(32))
+
+
+@pytest.mark.parametrize("ranks,V,centred", [(2, 4, False), (2, 4, True)])
+def test_linked_solvers_average_their_replicas_inside_the_epoch_kernel(sa, ranks, V, centred):
+    """sgdnet_solver_link_peers (the multi-GPU merge of SURVEY.md 8e, round 4): `ranks` sample-sharded solvers with V
+    virtual shards each run as ONE ranks * V-way average -- every rank's epoch kernel adds to the slice counters of
+    all ranks and reads their exchange buffers directly.  On this one-GPU box the ranks share the device (a CU
+    budget each, ordinary pointers instead of peer pointers); the arithmetic is that of one solver holding all
+    samples with ranks * V shards, in the same order: equal to rounding.
+    (Two ranks only: the ranks' kernels wait for each other, so they must RUN side by side; four solver streams
+    on one device can end up behind each other in one of the process's four hardware queues.)"""
+    n, p, batch, epochs, family = 48_000, 64, 700, 3, "binomial"
+    G = ranks * V
+    x, y = _problem(n, p, family, seed=8)                  # x: (p, n), sample i = column i
+    c = np.random.default_rng(3).normal(0.05, 0.1, p) if centred else None
+    period = 2 * batch                                     # draws per shard between merges, the same for every solver
+    one = sa.SagaSolver(x, y, family=family, n_classes=1, x_center_scaled=c)
+    one.set_penalty("elasticnet", 0.004, 1e-4, 1e-4)
+    one.set_virtual_shards(G)
+    one.set_merge_period(period)
+    one.upload_stream(one.sharded_stream([sa.RRng(90 + v) for v in range(G)], epochs))
+    one.run(mode="batched", batch=batch, draws_per_epoch=G * (n // G), max_epochs=epochs, tol=0.0)
+    want = {k: one.get(k) for k in STATE}
+    one.close()
+
+    nl = n // ranks
+    solvers = []
+    for q in range(ranks):
+        S = sa.SagaSolver(x[:, q * nl:(q + 1) * nl].tocsc(), y[..., q * nl:(q + 1) * nl], family=family, n_classes=1,
+                          x_center_scaled=c)
+        S.set_penalty("elasticnet", 0.004, 1e-4, 1e-4)
+        S.set_cu_budget(256 // ranks)
+        S.set_virtual_shards(V)
+        S.set_merge_period(period)
+        S.upload_stream(S.sharded_stream([sa.RRng(90 + q * V + u) for u in range(V)], epochs))
+        solvers.append(S)
+    sa.link_peers(solvers)
+    for S in solvers:                                      # every rank's epochs are enqueued before any is waited for
+        assert S._L.sgdnet_solver_gather_form(S._h, batch) == 3
+        S.enqueue_epochs(epochs, batch=batch, stream_offset=0, draws_per_epoch=V * (nl // V))
+    for S in solvers:
+        S.sync()
+    for k in ("w", "intercept", "g_sum", "g_sum_intercept"):
+        for S in solvers:
+            assert relerr(S.get(k), want[k]) < 1e-13, k
+    gm = np.concatenate([S.get("g_memory") for S in solvers], axis=1)
+    assert relerr(gm, want["g_memory"]) < 1e-13
+    sa.link_peers(solvers[:1])
+    for S in solvers:
+        S.close()
+
+
+def test_fit_sharded_over_two_ranks_equals_the_fit_on_one_gpu(sa):
+    """control.n_gpus (ABI 4): sgdnet_fit_sparse cuts the samples into one range per GPU, gives every rank its own
+    solver, virtual shards and generators on R's ONE stream (rank q's start lo_q draws in, all of them moving n draws
+    per epoch), links the solvers and runs the path -- here with both ranks on this box's one GPU.  The job is the
+    same 8-way average over the same draws as the single-GPU fit: same epochs, same coefficients, and R's generator
+    ends on the same draw."""
+    from sgdnet_amd import data as D
+    n, p = 240_000, 100
+    pr = D.make_sparse_glm(n, p, 0.05, family="binomial", seed=31)
+    x, y = D.as_scipy(pr).T.tocsc(), pr["y"].ravel()
+    kw = dict(family="binomial", alpha=0.5, lambda_=[3e-3, 1.5e-3, 7e-4], standardize=True, thresh=1e-7, maxit=80,
+              mode="batched")
+    r1, r2 = sa.RRng(12), sa.RRng(12)
+    one = sa.sgdnet(x, y, rng=r1, **kw)
+    two = sa.sgdnet(x, y, rng=r2, devices=[0, 0], **kw)
+    assert two.npasses == one.npasses and two.draws_used == one.draws_used
+    assert np.abs(two.beta - one.beta).max() <= 1e-11 * np.abs(one.beta).max()
+    assert np.abs(two.a0 - one.a0).max() <= 1e-11
+    assert np.abs(np.asarray(two.dev_ratio) - np.asarray(one.dev_ratio)).max() < 1e-12
+    assert np.array_equal(r1.unif(32), r2.unif(32))
+    with pytest.raises(Exception, match="n_gpus"):          # what the sharded fit does not cover says so
+        sa.sgdnet(x, y, rng=sa.RRng(1), devices=[0, 0], **dict(kw, mode="exact"))
