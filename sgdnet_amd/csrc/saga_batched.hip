@@ -2136,7 +2136,12 @@ __device__ __forceinline__ void fused_leave(const SagaDev& d, LamParams* lamp, i
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned* sync = d.vsync;
-    if (epoch_done && blockIdx.x == 0) end_epoch(lamp, nb);
+    if (epoch_done && blockIdx.x == 0) {
+      end_epoch(lamp, nb);
+      // linked solvers: one more launch whose merges the slice counters have counted (this workgroup says so, not
+      // the last one out: that may be a generators' workgroup, which knows nothing of the epoch)
+      if (d.n_peers > 1) __hip_atomic_fetch_add(sync + kSyncSeq * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const unsigned prev = __hip_atomic_fetch_add(sync + kSyncExit * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (prev + 1u == gridDim.x) {
       // (linked solvers: the other ranks add to this rank's slice counters whenever THEY get there -- those run on
@@ -2144,7 +2149,6 @@ __device__ __forceinline__ void fused_leave(const SagaDev& d, LamParams* lamp, i
       const bool linked = d.n_peers > 1;
       for (int wd = 0; wd < (linked ? kSyncCol : kSyncLines); ++wd)
         __hip_atomic_store(sync + wd * kSyncLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (linked && epoch_done) __hip_atomic_fetch_add(sync + kSyncSeq * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d.rngdev && lamp->rng_generate) d.rngdev->gen += 1u;
     }
   }
