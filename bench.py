@@ -90,9 +90,12 @@ def main():
     ap.add_argument("--weak", action="store_true",
                     help="weak scaling: every rank holds a full copy of the workload's sample count (n = N x n_workload, "
                          "lambda = 1/n); the default is BASELINE's strong scaling of the fixed problem")
-    ap.add_argument("--merge", default="avg", choices=["avg", "sync"],
-                    help="N > 1: periodic averaging of locally normalised shard runs (default), or a "
-                         "per-batch all-reduce of the scatter accumulator (exact single-GPU iterates)")
+    ap.add_argument("--merge", default="peers", choices=["peers", "avg", "sync"],
+                    help="N > 1: peers (default) = the ranks' replicas are averaged INSIDE their epoch kernels by direct loads "
+                         "from the other GPUs' exchange buffers (hipIpc mappings; no collective, one launch per epoch and rank; "
+                         "falls back to avg where the link cannot be made); avg = periodic RCCL all-reduce of the weighted "
+                         "state deltas between local runs; sync = a per-batch all-reduce of the scatter accumulator (exact "
+                         "single-GPU iterates)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -179,6 +182,7 @@ def main():
         dist.all_reduce(cs, op=dist.ReduceOp.SUM)
     batch = args.batch if args.batch > 0 else sa.auto_batch(max_sq, float(cs.max()) / n)
     sync_mode = (world > 1 or force_merge) and args.merge == "sync"
+    peers_mode = world > 1 and args.merge == "peers" and K == 1
     if not sync_mode:
         batch = min(batch, n_local)       # sync mode: `batch` is the GLOBAL staleness window
     note(f"gamma={gamma:.5g} batch={batch}")
@@ -189,6 +193,8 @@ def main():
     if K == 1 and not sync_mode:
         while V < 8 and 2 * V * 100 * p <= n_local:
             V *= 2
+        if peers_mode:                                         # the job stays (at most) an 8-way average, >= 2 shards per rank
+            V = max(2, min(V, 8 // world))
         if args.vshards >= 0:
             V = max(1, args.vshards)
     S = sa.SagaSolver(X, prob["y"], family=family, n_classes=K, fit_intercept=True, n_total=n,
@@ -198,7 +204,7 @@ def main():
     # sample order: R's Mersenne-Twister, set.seed(config id [+ rank] [+ 100 shard]).  With virtual
     # shards every local run (an epoch, or a merge segment when N > 1) is laid out shard after shard
     # (include/sgdnet_hip.h: sgdnet_solver_set_virtual_shards)
-    merged_job = (world > 1 or force_merge) and not sync_mode
+    merged_job = (world > 1 or force_merge) and not sync_mode and not peers_mode
     # every shard (virtual or not) runs n / 32 draws between merges: a rank with V virtual shards
     # exchanges after V * n / 32 draws, when its own shards are averaged on the device anyway
     # measured with the HIP kernels (profiles/r02d_multi_gpu_emulation.txt): the averaging keeps the
@@ -222,8 +228,25 @@ def main():
         min(32, max(8, n_local // 300000)) if n_local >= 200000 else 1)
     if V > 1:
         from sgdnet_amd.parallel import shard_bounds as sb
+        if os.environ.get("SGDNET_BENCH_ONE_GPU") == "1" and world > 1:
+            S.set_cu_budget(256 // world - 16)                 # rehearsal: the ranks share one GPU's CUs
         S.set_virtual_shards(V)
         S.set_merge_period(shard_period)
+        if peers_mode:
+            # link the ranks' solvers (sgdnet_solver_link_ipc); every rank must succeed, else everybody takes the RCCL scheme
+            ok = 1.0
+            try:
+                infos = [None] * world
+                dist.all_gather_object(infos, S.peer_info())
+                S.link_ipc(rank, infos)
+            except Exception as e:                             # noqa: BLE001
+                note(f"peer link failed: {e}")
+                ok = 0.0
+            flag = torch.tensor([ok], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            dist.barrier()
+            if float(flag[0]) < 0.5:
+                sys.exit("bench.py --merge peers: the solvers could not be linked (hipIpc); rerun with --merge avg")
         rngs = [sa.RRng(seed + rank + 100 * v) for v in range(V)]
 
         def host_stream(epochs):
@@ -273,7 +296,19 @@ def main():
                 f"{segs[0]} draws per rank ({len(segs)} per epoch)" + (", stream-ordered" if fused else ""))
         return sj.epoch, sh, desc, 0
 
-    run_epoch, shard, merge_desc, sync_rounds = make_job("sync" if sync_mode else "avg")
+    if peers_mode:
+        class _NoShard:                                        # the epoch is the single-GPU loop below: nothing to exchange here
+            offset = 0
+
+            def close(self):
+                pass
+
+        S.set_n_total(n_local)
+        run_epoch, shard, sync_rounds = None, _NoShard(), 0
+        merge_desc = (f"peers: {world * V}-way replica average inside the ranks' epoch kernels (direct loads from the peers' "
+                      f"exchange buffers, hipIpc), every {shard_period} draws per shard; one launch per epoch and rank, no collective")
+    else:
+        run_epoch, shard, merge_desc, sync_rounds = make_job("sync" if sync_mode else "avg")
     if pipe and merged_job:
         job_epoch = run_epoch
 
@@ -296,15 +331,19 @@ def main():
         torch.cuda.synchronize()
 
     note("solver resident, stream uploaded")
+    timed_kernel = {}
+
     def timed_epochs(epoch_fn):
         for _ in range(args.warmup):
             epoch_fn()
         fence()
+        S.epoch_timing(True)                       # dispatch events of exactly the timed region's epoch launches
         t0 = time.perf_counter()
         for _ in range(args.steps):
             epoch_fn()
         fence()
         dt = time.perf_counter() - t0
+        timed_kernel["ms"], timed_kernel["launches"] = S.epoch_timing(False)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -326,6 +365,9 @@ def main():
     if pipe:
         S.rng_done()
     alg_bytes_epoch = D.algorithmic_bytes(S.row_nnz, epoch_draws, K)
+    if prof["gather_kernel"] == "saga_vs_epoch_kernel" and timed_kernel.get("launches", 0) == args.steps and not merged_job:
+        # the dominant kernel IS the epoch: its dispatch durations over the timed region itself (one launch per step)
+        prof = dict(prof, gather_ms=timed_kernel["ms"] / args.steps, gather_launches=1, timed_region_events=True)
     gather_s = prof["gather_ms"] * 1e-3
     achieved = alg_bytes_epoch / gather_s / 1e9
     alg_bytes_epoch_job = alg_bytes_epoch * (n_local / prof_draws)     # this rank's whole epoch
@@ -368,21 +410,21 @@ def main():
             "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
             "launches": prof["gather_launches"],
+            "timed_over": ("the timed region's own launches (HIP events bound to every dispatch)" if prof.get("timed_region_events")
+                           else "one more epoch after the timed region (HIP events bound to every dispatch)"),
             "avg_launch_us": 1e3 * prof["gather_ms"] / max(1, prof["gather_launches"]),
             "algorithmic_bytes_per_launch": alg_bytes_epoch / max(1, prof["gather_launches"]),
             "sweep_avg_launch_us": 1e3 * prof["sweep_ms"] / max(1, prof["sweep_launches"]),
-            # other ceilings for this access pattern (GB/s): the guide's measured float4 copy, and
-            # random 256-B records streamed by scripts/microbench/gather_rate (profiles/)
-            # ... and one returning device-scope exchange per draw on the gradient memory: the
-            # memory-side atomic units sustain 21.7 G/s alone (profiles/r01_microbench.txt), i.e.
-            # 21.7e9 x bytes-per-draw with nothing else on the fabric
-            # ... and the floor of the K = 1 gather's compulsory pattern, measured with no compute at all in
-            # the product's launch geometry (scripts/microbench/gather_exchange.hip,
-            # profiles/r02c_gather_exchange_floor_microbench.txt): one random 128-B record + one dependent
-            # returning exchange per draw run at 20.8 G draws/s, the exchanges alone at 23.7 G/s
-            "ceilings": {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0,
-                         "one_returning_exchange_per_draw": 23.66 * alg_bytes_epoch / max(1, n_local),
-                         "record_plus_dependent_exchange_floor": 20.79 * alg_bytes_epoch / max(1, n_local)}
+            # floors of this access pattern, measured with no compute at all in the product's launch geometry on a FRESH
+            # segment of the sample order per repetition (scripts/microbench/gather_patterns.hip,
+            # profiles/r03j_gather_patterns_microbench.txt, r03b_*): microseconds per 2^20 draws -> GB/s at this
+            # workload's algorithmic bytes per draw.  (Round 2's 39.5 % floor replayed one segment out of the Infinity
+            # Cache and is gone.)
+            "ceilings": {"hbm_copy_measured": 6290.0,
+                         "one_random_128B_line_per_draw": (alg_bytes_epoch / max(1, prof_draws)) * 2 ** 20 / 24.1e-6 / 1e9,
+                         "line_plus_exchange_into_the_line": (alg_bytes_epoch / max(1, prof_draws)) * 2 ** 20 / 51.6e-6 / 1e9,
+                         "line_plus_plain_store_into_the_line": (alg_bytes_epoch / max(1, prof_draws)) * 2 ** 20 / 42.6e-6 / 1e9,
+                         "source": "profiles/r03j_gather_patterns_microbench.txt"}
             if K == 1 else
                         {"hbm_copy_measured": 6290.0, "random_256B_records": 6650.0},
         },

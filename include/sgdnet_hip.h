@@ -317,6 +317,12 @@ int sgdnet_solver_profile_epoch(sgdnet_solver* s, int64_t batch, int64_t stream_
                                 int64_t draws_per_epoch, double* gather_ms, int* gather_launches,
                                 double* sweep_ms, int* sweep_launches);
 
+/* Dispatch timing of the fused epoch launches (gather form 3) enqueued from now on: enable != 0 starts collecting
+ * start / stop events bound to every such launch on the solver's stream; every call first synchronises and returns
+ * what was collected since the previous call (summed kernel milliseconds, launches) -- the benchmark brackets
+ * exactly its timed region with two calls.  Either pointer may be NULL. */
+int sgdnet_solver_epoch_timing(sgdnet_solver* s, int enable, double* sum_ms, int* launches);
+
 /* Which gather kernel a batch of `batch` draws uses: 0 = saga_batch_gather_kernel (global
  * atomics), 1 = saga_batch_gather_lds_kernel (LDS-privatised scatter), 2 = the binned form
  * (saga_binned_gather_kernel + saga_binned_sweep_kernel: K x p tables that fit no LDS; valid after a
@@ -332,6 +338,14 @@ int sgdnet_solver_gather_form(const sgdnet_solver* s, int64_t batch);
  * enqueued (sgdnet_solver_enqueue_epochs) before any of them is waited for.  n == 1 unlinks.
  * sgdnet_fit_sparse does all of this itself when control.n_gpus > 1. */
 int sgdnet_solver_link_peers(sgdnet_solver** solvers, int n);
+/* The same link between solvers of DIFFERENT processes (one process per GPU): every rank fills
+ * sgdnet_solver_peer_info_bytes() bytes with sgdnet_solver_peer_info (hipIpc handles of its exchange buffer and counters,
+ * its shard sizes), the caller gathers the ranks' blocks in rank order (any transport: MPI, torch.distributed, a pipe) and
+ * every rank calls sgdnet_solver_link_ipc with all of them; a barrier of the caller's must separate the last link from the
+ * first epoch.  The peers' buffers are mapped with hipIpcOpenMemHandle and unmapped when the solver is destroyed. */
+int sgdnet_solver_peer_info_bytes(void);
+int sgdnet_solver_peer_info(sgdnet_solver* s, void* out);
+int sgdnet_solver_link_ipc(sgdnet_solver* s, int rank, int n_ranks, const void* infos);
 /* CUs a solver's batched launches may fill (0: the device's): linked solvers that share ONE GPU -- tests, or two
  * fits side by side -- must fit their persistent launches side by side. */
 int sgdnet_solver_set_cu_budget(sgdnet_solver* s, int cus);

@@ -17,6 +17,29 @@ for name, d in (("FETCH_SIZE", pf), ("WRITE_SIZE", pw)):
                  for k, v in agg.items() if "sgdnet" in k[0]}
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 kern = bench["roofline"]["kernel"]
+# ---- the timed region alone: the dominant kernel's dispatches in launch order, the warm-up ones skipped, the next `steps`
+# kept (what follows them -- the event-profiled epoch, the convergence leg, the kernel-alone epoch -- is not the timed region)
+tr = (glob.glob(os.path.join(prof, "*_kernel_trace.csv")) + glob.glob(os.path.join(prof, "*", "*_kernel_trace.csv")))
+if tr:
+    rows = [r for r in csv.DictReader(open(tr[0])) if kern in r["Kernel_Name"]]
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    per_step = max(1, int(bench["roofline"]["launches"]))
+    lo, hi = bench["warmup"] * per_step, (bench["warmup"] + bench["steps"]) * per_step
+    sel = rows[lo:hi]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in sel]
+    if dur:
+        span = int(sel[-1]["End_Timestamp"]) - int(sel[0]["Start_Timestamp"])
+        mean_ns = sum(dur) / len(dur)
+        alg = bench["roofline"]["algorithmic_bytes_per_launch"]
+        timed = {"kernel": kern, "dispatches": len(dur), "mean_ns": mean_ns, "min_ns": min(dur), "max_ns": max(dur),
+                 "span_first_start_to_last_end_ns": span, "ms_per_step_from_trace": span / bench["steps"] / 1e6,
+                 "kernel_share_of_span": sum(dur) / span,
+                 "algorithmic_bytes_per_launch": alg, "frac_of_8TBps_from_trace": alg / mean_ns / 8000.0,
+                 "frac_in_bench_line": bench["roofline"]["frac"], "ms_per_step_in_bench_line": bench["ms_per_step"],
+                 "note": "rocprofv3 --kernel-trace of the same command as the bench line (another run on the same box); "
+                         "dispatches [warmup * launches_per_step, (warmup + steps) * launches_per_step) of the dominant kernel"}
+        json.dump(timed, open(f"profiles/{tag}_timed_region.json", "w"), indent=1)
+        print(json.dumps(timed, indent=1))
 def pick(d):
     best = max(((v["dispatches"], v["mean_KB_per_dispatch"]) for k, v in d.items() if kern in k), default=(0, 0.0))
     return best[1]

@@ -30,7 +30,8 @@ EXPORTS = [
     "sgdnet_solver_export_delta_weighted_async", "sgdnet_solver_set_virtual_shards", "sgdnet_solver_set_merge_period",
     "sgdnet_score_sparse", "sgdnet_score_dense", "sgdnet_predict_sparse", "sgdnet_predict_dense",
     "sgdnet_auc_sparse", "sgdnet_auc_dense", "sgdnet_auc_sparse_rng", "sgdnet_auc_dense_rng",
-    "sgdnet_solver_link_peers", "sgdnet_solver_set_cu_budget",
+    "sgdnet_solver_link_peers", "sgdnet_solver_set_cu_budget", "sgdnet_solver_epoch_timing",
+    "sgdnet_solver_peer_info_bytes", "sgdnet_solver_peer_info", "sgdnet_solver_link_ipc",
     "sgdnet_solver_rng_layout", "sgdnet_solver_rng_open", "sgdnet_solver_rng_next", "sgdnet_solver_rng_done", "sgdnet_solver_rng_close",
 ]
 ABI_VERSION = 4   # include/sgdnet_hip.h: SGDNET_ABI_VERSION
@@ -164,6 +165,9 @@ def load():
     L.sgdnet_solver_set_merge_period.argtypes = [C.c_void_p, C.c_int64]
     L.sgdnet_solver_link_peers.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     L.sgdnet_solver_set_cu_budget.argtypes = [C.c_void_p, C.c_int]
+    L.sgdnet_solver_peer_info.argtypes = [C.c_void_p, C.c_void_p]
+    L.sgdnet_solver_link_ipc.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.sgdnet_solver_epoch_timing.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.sgdnet_solver_export_delta_weighted_async.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
     L.sgdnet_solver_convergence.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int)]
     L.sgdnet_solver_last_change.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]

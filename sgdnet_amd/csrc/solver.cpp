@@ -128,6 +128,10 @@ struct sgdnet_solver {
   bool fused_in_graph = false;   // the captured epochs use it
   int fused_abort_seen = 0;      // LamParams::fused_abort as the last ConvergenceCheck read it
   FusedPeers* peers_dev = nullptr;   // sgdnet_solver_link_peers
+  // sgdnet_solver_epoch_timing: dispatch start / stop events of every fused epoch launch (the benchmark's timed region)
+  bool time_epochs = false;
+  std::vector<hipEvent_t> epoch_ev;
+  std::vector<void*> ipc_opened;   // sgdnet_solver_link_ipc: the peers' buffers as mapped here
 };
 
 namespace {
@@ -557,6 +561,13 @@ int enqueue_epoch_kernels_vs(sgdnet_solver* s, int64_t batch, int64_t draws, std
       ev->push_back(z[1]);
       return SGDNET_OK;
     }
+    if (s->time_epochs) {
+      hipEvent_t e[2];
+      for (auto& x : e) SGD_HIP_TRY(hipEventCreate(&x));
+      s->epoch_ev.push_back(e[0]);
+      s->epoch_ev.push_back(e[1]);
+      return launch_vs_epoch(d, s->lam_dev, nb, every, s->st, e[0], e[1]);
+    }
     return launch_vs_epoch(d, s->lam_dev, nb, every, s->st);
   }
   int rc = launch_vs_broadcast(d, s->st);
@@ -739,6 +750,11 @@ int fused_recover(sgdnet_solver* s, int code, int64_t draws, int batches, bool* 
   SGD_HIP_TRY(hipMemsetAsync(s->d.vsync + vs_fused_sync_sticky_word(), 0, sizeof(unsigned), s->st));
   if (code != 1) {
     set_error("batched mode: a wait inside the fused epoch kernel timed out (internal error; the epoch is void)");
+    return SGDNET_EHIP;
+  }
+  if (s->d.n_peers > 1) {                       // the separate launches know nothing of the other ranks
+    set_error("batched mode: the epoch kernel of a linked solver could not become resident on its GPU (shared with other "
+              "work?); the ranks' replicas are averaged inside that kernel, so there is no fallback");
     return SGDNET_EHIP;
   }
   if (getenv("SGDNET_TRACE"))
@@ -1158,6 +1174,8 @@ void sgdnet_solver_destroy(sgdnet_solver* s) {
   (void)hipSetDevice(s->device);
   if (s->st) (void)hipStreamSynchronize(s->st);
   drop_graph(s);
+  for (void* q : s->ipc_opened) (void)hipIpcCloseMemHandle(q);
+  for (hipEvent_t e : s->epoch_ev) (void)hipEventDestroy(e);
   for (void* p : s->owned) (void)hipFree(p);
   if (s->LS_dev) (void)hipFree(s->LS_dev);
   if (s->d.slab) (void)hipFree(s->d.slab);
@@ -2320,6 +2338,27 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   return SGDNET_OK;
 }
 
+int sgdnet_solver_epoch_timing(sgdnet_solver* s, int enable, double* sum_ms, int* launches) {
+  if (!s) return SGDNET_EINVAL;
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  double tot = 0.0;
+  int cnt = 0;
+  for (size_t i = 0; i + 1 < s->epoch_ev.size(); i += 2) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->epoch_ev[i], s->epoch_ev[i + 1]) == hipSuccess) {
+      tot += ms;
+      ++cnt;
+    }
+  }
+  for (hipEvent_t e : s->epoch_ev) (void)hipEventDestroy(e);
+  s->epoch_ev.clear();
+  s->time_epochs = enable != 0;
+  if (sum_ms) *sum_ms = tot;
+  if (launches) *launches = cnt;
+  return SGDNET_OK;
+}
+
 int sgdnet_solver_set_cu_budget(sgdnet_solver* s, int cus) {
   if (!s || cus < 0) return SGDNET_EINVAL;
   SGD_HIP_TRY(hipSetDevice(s->device));
@@ -2397,6 +2436,88 @@ int sgdnet_solver_link_peers(sgdnet_solver** solvers, int n) {
     s->d.peers = s->peers_dev;
     s->d.n_peers = n;
   }
+  return SGDNET_OK;
+}
+
+// ---- the same link between solvers of DIFFERENT processes (one process per GPU: bench.py under torch.distributed.run) ----
+// info: 2 hipIpcMemHandle_t (exchange buffer, barrier counters) + 8 shard sizes + V + workgroups per shard + features
+struct PeerInfo {
+  hipIpcMemHandle_t vx, vsync;
+  double vsize[8];
+  int V, v_bps;
+  int64_t p;
+};
+
+int sgdnet_solver_peer_info_bytes(void) { return (int)sizeof(PeerInfo); }
+
+int sgdnet_solver_peer_info(sgdnet_solver* s, void* out) {
+  if (!s || !out || !s->d.vx || !s->d.vsync) {
+    set_error("sgdnet_solver_peer_info: set the virtual shards first (one response, sparse x)");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  PeerInfo h{};
+  SGD_HIP_TRY(hipIpcGetMemHandle(&h.vx, s->d.vx));
+  SGD_HIP_TRY(hipIpcGetMemHandle(&h.vsync, s->d.vsync));
+  for (int u = 0; u < 8; ++u) h.vsize[u] = s->d.v_size[u];
+  h.V = s->d.V;
+  h.v_bps = s->d.v_bps;
+  h.p = s->d.p;
+  memcpy(out, &h, sizeof(h));
+  return SGDNET_OK;
+}
+
+int sgdnet_solver_link_ipc(sgdnet_solver* s, int rank, int n, const void* infos) {
+  if (!s || !infos || n < 2 || n > 8 || rank < 0 || rank >= n) {
+    set_error("sgdnet_solver_link_ipc: 2..8 ranks");
+    return SGDNET_EINVAL;
+  }
+  SGD_HIP_TRY(hipSetDevice(s->device));
+  SGD_HIP_TRY(hipStreamSynchronize(s->st));
+  if (!vs_fused_eligible(s->d)) {
+    set_error("sgdnet_solver_link_ipc: the replica average across GPUs runs inside the fused epoch kernel, which this "
+              "problem cannot use (sparse x, one response, an even number of features, virtual shards set)");
+    return SGDNET_EUNSUPPORTED;
+  }
+  const PeerInfo* I = static_cast<const PeerInfo*>(infos);
+  FusedPeers h{};
+  h.n = n;
+  h.rank = rank;
+  for (int r = 0; r < n; ++r) {
+    if (I[r].V != s->d.V || I[r].v_bps != s->d.v_bps || I[r].p != s->d.p) {
+      set_error("sgdnet_solver_link_ipc: rank %d has %d shards of %d workgroups on %lld features, this rank %d of %d on %lld",
+                r, I[r].V, I[r].v_bps, (long long)I[r].p, s->d.V, s->d.v_bps, (long long)s->d.p);
+      return SGDNET_EUNSUPPORTED;
+    }
+    for (int u = 0; u < 8; ++u) {
+      h.vsize[r][u] = I[r].vsize[u];
+      if (u < I[r].V) h.tot_size += I[r].vsize[u];
+    }
+    if (r == rank) {
+      h.pub[r] = s->d.vx;
+      h.sync[r] = s->d.vsync;
+    } else {
+      void *px = nullptr, *py = nullptr;
+      SGD_HIP_TRY(hipIpcOpenMemHandle(&px, I[r].vx, hipIpcMemLazyEnablePeerAccess));
+      SGD_HIP_TRY(hipIpcOpenMemHandle(&py, I[r].vsync, hipIpcMemLazyEnablePeerAccess));
+      s->ipc_opened.push_back(px);
+      s->ipc_opened.push_back(py);
+      h.pub[r] = static_cast<double*>(px);
+      h.sync[r] = static_cast<unsigned*>(py);
+    }
+  }
+  drop_graph(s);
+  if (!s->peers_dev) {
+    void* pd = nullptr;
+    SGD_HIP_TRY(hipMalloc(&pd, sizeof(FusedPeers)));
+    s->owned.push_back(pd);
+    s->peers_dev = static_cast<FusedPeers*>(pd);
+  }
+  SGD_HIP_TRY(hipMemcpy(s->peers_dev, &h, sizeof(FusedPeers), hipMemcpyHostToDevice));
+  // (the counters were zeroed when the shards were set; every rank links before any of them enqueues an epoch -- the
+  //  caller's barrier -- so nothing is cleared here that a peer may already have added to)
+  s->d.peers = s->peers_dev;
+  s->d.n_peers = n;
   return SGDNET_OK;
 }
 

@@ -319,6 +319,23 @@ class SagaSolver:
     def set_merge_period(self, draws_per_shard):
         check(self._L.sgdnet_solver_set_merge_period(self._h, draws_per_shard))
 
+    def epoch_timing(self, enable):
+        """(kernel milliseconds, launches) of the fused epoch launches since the previous call; enable: keep collecting."""
+        ms, cnt = C.c_double(0), C.c_int(0)
+        check(self._L.sgdnet_solver_epoch_timing(self._h, int(bool(enable)), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def peer_info(self):
+        """This rank's block for link_ipc (bytes): hipIpc handles of its exchange buffer and counters, its shard sizes."""
+        buf = C.create_string_buffer(self._L.sgdnet_solver_peer_info_bytes())
+        check(self._L.sgdnet_solver_peer_info(self._h, buf))
+        return buf.raw
+
+    def link_ipc(self, rank, infos):
+        """infos: every rank's peer_info() in rank order.  A barrier of the caller's must follow before the first epoch."""
+        blob = b"".join(infos)
+        check(self._L.sgdnet_solver_link_ipc(self._h, int(rank), len(infos), C.c_char_p(blob)))
+
     def set_cu_budget(self, cus):
         """CUs this solver's batched launches may fill (0: the device's): linked solvers sharing one GPU."""
         check(self._L.sgdnet_solver_set_cu_budget(self._h, int(cus)))

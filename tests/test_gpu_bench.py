@@ -58,7 +58,18 @@ def test_bench_launches_its_own_ranks(have_gpu):
                      {"SGDNET_BENCH_BACKEND": "gloo", "SGDNET_BENCH_ONE_GPU": "1"})
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2       # an all-reduce really summed over two ranks
     assert out["steps"] == 3 and out["value"] > 0
-    assert out["config"]["samples_per_gpu"] == 50_000 and out["config"]["merge"].startswith("avg")
+    # the default exchange: the ranks' replicas averaged inside their epoch kernels through hipIpc-mapped buffers
+    assert out["config"]["samples_per_gpu"] == 50_000 and out["config"]["merge"].startswith("peers")
+    assert out["roofline"]["kernel"] == "saga_vs_epoch_kernel"
     assert out["scaling"] == "strong"
     conv = out.get("convergence")
     assert conv is None or conv["epochs"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_rccl_scheme_still_runs(have_gpu):
+    # --merge avg: local runs between merges + an all-reduce of the weighted state deltas (gloo here)
+    out = _run_bench(["--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                      "--no-convergence", "--merge", "avg"],
+                     {"SGDNET_BENCH_BACKEND": "gloo", "SGDNET_BENCH_ONE_GPU": "1"})
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["merge"].startswith("avg")

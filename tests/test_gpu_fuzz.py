@@ -139,6 +139,19 @@ def test_random_fit_matches_the_oracle_fit(sa, oracle, seed):
     assert np.allclose(fit.dev_ratio, ref["dev_ratio"], rtol=1e-8, atol=1e-10)
 
 
+@pytest.mark.parametrize("registers", [0, 2, 3, 4])
+def test_random_fits_with_every_exact_kernel_forced(sa, oracle, registers):
+    # the same random fits with option exact_row_registers forcing each family of exact kernels wherever it is
+    # legal -- 3 puts the multi-wavefront kernels onto the crowded rows (p = 2 ... 30: every draw in flight shares
+    # features) and the tiny epochs the default rule keeps away from them, 0 / 2 / 4 the general, memory-state and
+    # one-consumer kernels; the sparse fits are what the option changes (round 3's 700-fit sweep,
+    # scripts/dev/exact_fuzz_forced.py, as a bounded test: 12 fits per value, ~10 s)
+    fn = getattr(test_random_fit_matches_the_oracle_fit, "__wrapped__", test_random_fit_matches_the_oracle_fit)
+    with sa.option("exact_row_registers", registers):
+        for seed in range(200 + 12 * registers, 212 + 12 * registers):
+            fn(sa, oracle, seed)
+
+
 # seeds 88 and 91 (few strongly scaled dense features): the rule's 64-draw floor blows up; the driver restarts
 # with a 16-draw window, and mode = "auto" would rerun the fit in exact mode if that failed too
 @pytest.mark.parametrize("seed", sorted(set(range(int(os.environ.get("SGDNET_FUZZ_BATCHED_FITS", 24)))) | {88, 91}))
