@@ -231,3 +231,41 @@ def test_binned_form_with_row_clustered_column_blocks(sa, oracle):
     fit = sa.sgdnet(X.T.tocsc(), y.ravel(), family="multinomial", alpha=0.5, nlambda=3, standardize=False,
                     thresh=1e-3, maxit=50, seed=1, mode="auto")
     assert np.all(np.isfinite(np.asarray(fit.dev_ratio))) and np.asarray(fit.dev_ratio)[-1] > 0.0
+
+
+@pytest.mark.timeout(1500)
+def test_config5_path_slice_at_full_size(sa):
+    """BASELINE config 5 as stated -- the warm-started lambda path at 50M x 100k, K = 10 (src/sgdnet.cpp:217-273) --
+    for the first 10 points of the 100-point path (lambda.min.ratio 1e-4, alpha 0.5), through sgdnet(mode = "auto") on
+    one GPU: every lambda converges within maxit, dev.ratio rises along the path, and the multinomial elastic-net KKT
+    residual of the last lambda is small against the gradient scale of the null model.  The whole 100-point path is
+    recorded by scripts/c5_path.py in profiles/r04_c5_path.json (29 s, 465 epochs)."""
+    import importlib.util
+    import os
+    from sgdnet_amd import data as D
+    if _mem_available_gb() < 90:
+        pytest.skip("needs ~60 GB of host memory for the 5e8-entry matrix and its checks")
+    spec = importlib.util.spec_from_file_location(
+        "c5_path", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "c5_path.py"))
+    c5 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(c5)
+    n, p, K, nlam, first = 50_000_000, 100_000, 10, 100, 10
+    pr = D.make_sparse_glm(n, p, 1e-4, family="multinomial", n_classes=K, seed=5)
+    X = D.as_scipy(pr)
+    y = pr["y"].ravel()
+    cnt = np.bincount(y.astype(np.int64), minlength=K).astype(float)
+    Yc = -np.tile(cnt / n, (n, 1))
+    Yc[np.arange(n), y.astype(np.int64)] += 1.0
+    G0 = np.abs(X @ Yc) / n                                # |gradient| of the null model: lambda_max * alpha is its maximum
+    lmax = float(G0.max()) / 0.5
+    del Yc
+    lam = np.exp(np.log(lmax) + np.arange(nlam) * (np.log(lmax * 1e-4) - np.log(lmax)) / (nlam - 1))[:first]
+    fit = sa.sgdnet(X.T.tocsc(), y, family="multinomial", alpha=0.5, lambda_=lam, standardize=False, thresh=1e-3,
+                    maxit=1000, mode="auto", seed=5)
+    assert not np.asarray(fit.return_codes).any()          # every lambda converged
+    dr = np.asarray(fit.dev_ratio)
+    assert np.all(np.diff(dr) >= -1e-6) and dr[-1] > dr[0]
+    beta = np.stack([np.asarray(b) for b in fit.beta])
+    assert np.count_nonzero(beta[:, :, -1]) > np.count_nonzero(beta[:, :, 1])   # the active set grows along the path
+    kkt, icpt = c5.multinomial_kkt(X, y, K, beta[:, :, -1], np.asarray(fit.a0)[:, -1], 0.5 * lam[-1], 0.5 * lam[-1])
+    assert kkt <= 0.05 * float(G0.max()) and icpt <= 0.05 * float(G0.max())
