@@ -73,8 +73,8 @@ struct RngDev {
 // rank's kernel needs to reach the others -- their exchange buffers and barrier counters (peer pointers, or
 // hipIpc mappings of them) and their shard sizes.  Lives in device memory.
 struct FusedPeers {
-  double* pub[8];         // every rank's exchange buffer (its SagaDev::vx), this rank's own included
-  unsigned* sync[8];      // every rank's barrier counters (SagaDev::vsync)
+  double* pub[8];         // every rank's published slices (its SagaDev::vpub), this rank's own included
+  unsigned* sync[8];      // every rank's slice counters (SagaDev::vcol)
   double vsize[8][8];     // samples of rank q's shard u
   double tot_size;        // samples of the whole job
   int n, rank;
@@ -106,8 +106,13 @@ struct SagaDev {
   double* vref;          // snapshot [g_sum | w | g_sum_b | b] the replicas started from
   // fused epoch of the virtual shards (saga_vs_epoch_kernel): counters of its in-launch barriers, and the
   // exchange buffer [2 parities x V published slices | V reference copies | c.w partials]
-  unsigned* vsync;
-  double* vx;
+  unsigned* vsync;       // shard-local barrier counters, start / go / exit words
+  double* vx;            // [V reference copies | c.w partials]
+  // ... and what the merges exchange, in FINE-GRAINED memory of their own (linked solvers on other GPUs add to the slice
+  // counters and read the published slices while the kernels run; kept apart from the per-round counters above, which
+  // are polled every round: fine-grained memory for those cost the epoch 20 %)
+  unsigned* vcol;        // slice counters col[i]: one 128-B line each
+  double* vpub;          // 2 parities x V published slices [g_sum | w | g_sum_b | b]
   FusedPeers* peers;     // linked solvers (one per GPU): their replicas take part in the merge; n_peers <= 1: none
   int n_peers;
   int cu_budget;         // > 0: CUs this solver may fill (several linked solvers sharing one GPU in tests); 0: the device's
@@ -259,7 +264,8 @@ bool vs_eligible(const SagaDev& d, int m);
 bool vs_fused_eligible(const SagaDev& d);
 size_t vs_fused_sync_words();
 size_t vs_fused_sync_sticky_word();
-size_t vs_fused_sync_col_word();
+size_t vs_fused_col_words();
+size_t vs_fused_publish_doubles(const SagaDev& d, int n_shards);
 size_t vs_fused_exchange_doubles(const SagaDev& d, int n_shards);
 int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStream_t st, hipEvent_t ev0 = nullptr,
                     hipEvent_t ev1 = nullptr);

@@ -1997,9 +1997,9 @@ __global__ void saga_epoch_end_kernel(LamParams* lamp, int batches) {
 // --------------------------------------------------------------------------
 constexpr int kSyncLine = 32;                  // unsigned words per 128-B line: every polled word has a line of its own
 constexpr int kSyncGo = 0, kSyncExit = 1, kSyncStart = 2, kSyncCnt1 = 3, kSyncCnt2 = kSyncCnt1 + 8,
-              kSyncXcd = kSyncCnt2 + 8, kSyncCol = kSyncXcd + 8;
+              kSyncXcd = kSyncCnt2 + 8;
 constexpr int kFusedMaxBps = 128;              // workgroups per shard
-constexpr int kSyncLines = kSyncCol + kFusedMaxBps;
+constexpr int kSyncLines = kSyncXcd + 8;         // (the slice counters col[i] of the merges have an array of their own: SagaDev::vcol)
 constexpr int kSyncSticky = kSyncLines;        // abort code of any launch since the host last looked (never reset on the device)
 constexpr int kSyncSeq = kSyncLines + 1;       // linked solvers: launches since they were linked (their slice counters run on)
 constexpr int kFusedChunks = 3;                // 64-lane chunks of 16-byte pairs in a workgroup's feature slice
@@ -2061,11 +2061,14 @@ __device__ __forceinline__ void fused_arrive(unsigned* sync, int word) {
 
 // one lane: counter >= target, or give up (returns false; *fail set on a timeout of this lane's own)
 // (system: the counter receives remote adds of linked solvers on other GPUs)
-__device__ __forceinline__ bool fused_poll(unsigned* sync, int word, unsigned target, LamParams* lamp, bool system = false) {
+// ctr: the array the counter lives in (vsync, or vcol for the merges' slice counters); sync: vsync (go / abort words)
+__device__ __forceinline__ bool fused_poll(unsigned* ctr, int word, unsigned target, LamParams* lamp, bool system = false,
+                                           unsigned* sync = nullptr) {
+  if (!sync) sync = ctr;
   const long long t0 = wall_clock64();
   for (unsigned spins = 1;; ++spins) {
-    const unsigned now = system ? __hip_atomic_load(sync + word * kSyncLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                : sync_load(sync, word);
+    const unsigned now = system ? __hip_atomic_load(ctr + word * kSyncLine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                : sync_load(ctr, word);
     if (now >= target) return true;
     __builtin_amdgcn_s_sleep(4);
     if ((spins & 63u) == 0) {
@@ -2146,14 +2149,20 @@ __device__ __forceinline__ void fused_leave(const SagaDev& d, LamParams* lamp, i
     if (prev + 1u == gridDim.x) {
       // (linked solvers: the other ranks add to this rank's slice counters whenever THEY get there -- those run on
       //  from launch to launch, with the launch count as their base)
-      const bool linked = d.n_peers > 1;
-      for (int wd = 0; wd < (linked ? kSyncCol : kSyncLines); ++wd)
+      for (int wd = 0; wd < kSyncLines; ++wd)
         __hip_atomic_store(sync + wd * kSyncLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!(d.n_peers > 1))
+        for (int wd = 0; wd < kFusedMaxBps; ++wd)
+          __hip_atomic_store(d.vcol + wd * kSyncLine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (d.rngdev && lamp->rng_generate) d.rngdev->gen += 1u;
     }
   }
 }
 
+// kPeers: the instantiation for linked solvers (the merge reaches over the ranks).  A template parameter, not a run-time
+// branch: the draw loop has no register to spare, and the extra live values of the linked merge pushed three of its
+// values into scratch (+20 % per epoch on ONE GPU, measured) -- the unlinked instantiation does not carry them.
+template <bool kPeers>
 __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, LamParams* lamp, int nb, int every) {
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   __shared__ int ticket_counter;
@@ -2191,27 +2200,38 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
   f64x2_t* W2 = reinterpret_cast<f64x2_t*>(Wl);
   // per-lambda parameters: read once (the epoch's bookkeeping rewrites LamParams at the end)
   const int penalty = lamp->penalty;
-  const double gamma = lamp->gamma, beta = lamp->beta;
-  const double r_full = lamp->r_full, ls_full = lamp->ls_full, r_tail = lamp->r_tail, ls_tail = lamp->ls_tail;
+  // (the round's scalars are kept in LDS and read where they are used: as kernel-long register values they -- with the
+  //  other uniform values of this kernel -- overflowed the scalar registers into vector registers the draw loop needs)
+  __shared__ double sh_par[10];                 // gamma, beta, r_full, ls_full, r_tail, ls_tail, n_v, lo_v, total samples
+  if (tid == 0) {
+    sh_par[0] = lamp->gamma;
+    sh_par[1] = lamp->beta;
+    sh_par[2] = lamp->r_full;
+    sh_par[3] = lamp->ls_full;
+    sh_par[4] = lamp->r_tail;
+    sh_par[5] = lamp->ls_tail;
+    double tot = 0.0, lo = 0.0;
+    for (int u = 0; u < d.V; ++u) {
+      tot += d.v_size[u];
+      if (u < (int)blockIdx.x % d.V) lo += d.v_size[u];
+    }
+    sh_par[6] = d.v_size[(int)blockIdx.x % d.V];
+    sh_par[7] = lo;
+    sh_par[8] = tot;
+  }
   const int64_t m_full = lamp->m_full;
   const int64_t sbase = lamp->stream_base;
   const bool raw_words = lamp->stream_raw != 0;   // the stream holds the generators' raw words: every workgroup turns its own share into draws
   const int64_t dps = d.v_dps;
-  const double n_d = d.v_size[v];
   const bool std_x = d.standardize != 0;
   const int64_t L = 2 * p + 2;                  // [g_sum | w | g_sum_intercept | intercept]
   double* vwv = d.vw + (int64_t)v * p;
   double* vGv = d.vG + (int64_t)v * p;
-  double* refv = d.vx + (int64_t)(2 * V + v) * L;
-  double* cwp = d.vx + (int64_t)3 * V * L;      // c . w of every workgroup's slice: V x kFusedMaxBps
+  double* refv = d.vx + (int64_t)v * L;
+  double* cwp = d.vx + (int64_t)V * L;          // c . w of every workgroup's slice: V x kFusedMaxBps
   unsigned* sync = d.vsync;
   const __amdgpu_buffer_rsrc_t rs_slab = fused_rsrc(d.slab, (int64_t)V * S * p * 8);
   const __amdgpu_buffer_rsrc_t rs_w = fused_rsrc(vwv, p * 8);
-  double tot_size = 0.0, lo_v = 0.0;
-  for (int u = 0; u < V; ++u) {
-    tot_size += d.v_size[u];
-    if (u < v) lo_v += d.v_size[u];
-  }
   // this workgroup's share of a shard-batch of m draws (the ranges K1Compact::begin hands out): [lo, hi)
   uint32_t* const stream_v = const_cast<uint32_t*>(d.stream) + sbase + (int64_t)v * dps;
   // raw words -> draws from shard v's sample range, in place, in two steps: the words of this workgroup's share
@@ -2236,6 +2256,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     int lo, hi;
     conv_range(m, lo, hi);
     uint32_t* q = stream_v + t0;
+    const double n_d = sh_par[6], lo_v = sh_par[7];
 #pragma unroll
     for (int c = 0; c < kC; ++c) {
       const int i = lo + (int)threadIdx.x + c * kLdsBlock;
@@ -2278,7 +2299,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
   bool done = false;
   bool alive = sh_ok != 0;
   unsigned col_base = 0u;                       // linked solvers: merges of the launches before this one
-  if (d.n_peers > 1) {
+  if (kPeers) {
     int merges = 0;
     for (int r = 0; r < nb; ++r) merges += (r + 1 == nb || (r + 1) % every == 0) ? 1 : 0;
     col_base = sync_load(sync, kSyncSeq) * (unsigned)merges;
@@ -2306,7 +2327,6 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     const int64_t t0 = (int64_t)r * m_full;
     const int m = (int)(dps - t0 < m_full ? dps - t0 : m_full);
     const bool tail = m != m_full;
-    const double r_m = tail ? r_tail : r_full, ls_m = tail ? ls_tail : ls_full;
     const bool last = r + 1 == nb;
     const bool merge_due = last || (r + 1) % every == 0;
 
@@ -2391,26 +2411,27 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     fused_arrive(sync, kSyncCnt1 + v);
     FPH(2);
     // behind the arrival, while the rest of the shard finishes: this workgroup's own coefficients (nobody else
-    // writes them), and the next round's share of the sample order
-    const int64_t j = j0 + tq;
+    // writes them), and the next round's share of the sample order.
+    // A thread owns one PAIR (A, B) of the replicated state: (g_sum_j, w_j) of its feature j, or -- the first thread
+    // past the slice in the shard's workgroup 0 -- (g_sum_intercept, intercept): sweep and merge treat both alike
+    // (fewer values in flight than two code paths: the phases of this kernel compete with the draw loop for registers)
     const bool upd = tq < jn;
-    const bool icpt = wi == 0 && tq == 0;
-    double w_old = 0.0, g_old = 0.0, c_own = 0.0, rg = 0.0, rw = 0.0, b_new = 0.0, gb_new = 0.0, rgb = 0.0, rb = 0.0;
-    if (upd) {
-      w_old = r == 0 ? d.w[j] : ld_sc1(vwv + j);
-      g_old = r == 0 ? d.G[j] : ld_sc1(vGv + j);
-      if (std_x) c_own = d.c[j];
+    const bool icpt = wi == 0 && tq == jn;
+    const bool act = upd || icpt;
+    const int64_t j = j0 + tq;
+    const int64_t oa = upd ? j : 2 * p, ob = upd ? p + j : 2 * p + 1;      // offsets in [g_sum | w | g_sum_b | b]
+    double* const rep_a = upd ? vGv + j : d.vgb + v;                        // the replica's pair
+    double* const rep_b = upd ? vwv + j : d.vb + v;
+    const double* const own_a = upd ? d.G + j : d.gb;                       // the solver's own state (the epoch's start)
+    const double* const own_b = upd ? d.w + j : d.b;
+    double a_old = 0.0, b_old = 0.0, c_own = 0.0, ra = 0.0, rb = 0.0;
+    if (act) {
+      a_old = r == 0 ? *own_a : ld_sc1(rep_a);
+      b_old = r == 0 ? *own_b : ld_sc1(rep_b);
+      if (std_x && upd) c_own = d.c[j];
       if (merge_due) {
-        rg = mi == 0 ? d.G[j] : ld_sc1(refv + j);
-        rw = mi == 0 ? d.w[j] : ld_sc1(refv + p + j);
-      }
-    }
-    if (icpt) {
-      b_new = r == 0 ? d.b[0] : ld_sc1(d.vb + v);
-      gb_new = r == 0 ? d.gb[0] : ld_sc1(d.vgb + v);
-      if (merge_due) {
-        rgb = mi == 0 ? d.gb[0] : ld_sc1(refv + 2 * p);
-        rb = mi == 0 ? d.b[0] : ld_sc1(refv + 2 * p + 1);
+        ra = mi == 0 ? *own_a : ld_sc1(refv + oa);
+        rb = mi == 0 ? *own_b : ld_sc1(refv + ob);
       }
     }
     if (conv_next) conv_store(t0n, mn, xraw);
@@ -2458,28 +2479,32 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
       }
     }
     __syncthreads();
-    const double d0 = sh_val[1];
-    double w_new = 0.0, g_new = 0.0;
-    if (upd) {
-      double dj = 0.0;
+    double a_new = a_old, b_new = b_old;        // (g_sum, w) of the feature, or (g_sum_intercept, intercept)
+    {
+      const double d0 = sh_val[1];
+      const double n_d = sh_par[6], gamma = sh_par[0];
+      if (upd) {
+        double dj = 0.0;
 #pragma unroll
-      for (int wv = 0; wv < kLdsBlock / 64; ++wv) dj += Wl[(int64_t)wv * F + tq];
-      if (std_x) dj -= c_own * d0;              // implicit centring: D_j -= c_j * sum(gc)
-      const double val = r_m * w_old - (gamma * ls_m) * g_old - gamma * dj;
-      const double tau = beta * gamma * ls_m;
-      w_new = val;
-      if (penalty == SGDNET_ELASTICNET) {
-        w_new = soft_threshold(val, tau);
-      } else if (penalty == SGDNET_GROUPLASSO) {          // penalties.h:61-79 with one response
-        const double factor = tau / sqrt(val * val);
-        w_new = factor < 1.0 ? val * (1.0 - factor) : 0.0;
+        for (int wv = 0; wv < kLdsBlock / 64; ++wv) dj += Wl[(int64_t)wv * F + tq];
+        if (std_x) dj -= c_own * d0;            // implicit centring: D_j -= c_j * sum(gc)
+        const double beta = sh_par[1];
+        const double r_m = tail ? sh_par[4] : sh_par[2], ls_m = tail ? sh_par[5] : sh_par[3];
+        const double val = r_m * b_old - (gamma * ls_m) * a_old - gamma * dj;
+        const double tau = beta * gamma * ls_m;
+        b_new = val;
+        if (penalty == SGDNET_ELASTICNET) {
+          b_new = soft_threshold(val, tau);
+        } else if (penalty == SGDNET_GROUPLASSO) {          // penalties.h:61-79 with one response
+          const double factor = tau / sqrt(val * val);
+          b_new = factor < 1.0 ? val * (1.0 - factor) : 0.0;
+        }
+        a_new = (dj != 0.0 || penalty == SGDNET_GROUPLASSO) ? a_old + dj / n_d : a_old;
+      } else if (icpt && d.fit_intercept) {     // saga-sparse.h:300-304 in batches
+        const double dk = d0 / n_d;
+        a_new = a_old + dk;
+        b_new = b_old - gamma * (a_new * (d.xd ? 1.0 : 0.01) * (double)m + dk);
       }
-      g_new = (dj != 0.0 || penalty == SGDNET_GROUPLASSO) ? g_old + dj / n_d : g_old;
-    }
-    if (icpt && d.fit_intercept) {              // saga-sparse.h:300-304 in batches
-      const double dk = d0 / n_d;
-      gb_new += dk;
-      b_new -= gamma * (gb_new * (d.xd ? 1.0 : 0.01) * (double)m + dk);
     }
     FPH(4);
     if (merge_due) {
@@ -2489,99 +2514,71 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
       // atomics over xGMI), waits for its own counter and reads the ranks' buffers with direct loads: the
       // "all-reduce" of this scheme is 2 (p / S) doubles per workgroup and shard, inside the epoch's one launch.
       // Those buffers and counters are fine-grained allocations, the accesses system-scope (sc0 sc1).
-      const FusedPeers* PR = d.n_peers > 1 ? d.peers : nullptr;
-      const int NP = PR ? d.n_peers : 1;
-      double* pubv = d.vx + (int64_t)((mi & 1) * V + v) * L;
+      const FusedPeers* PR = kPeers ? d.peers : nullptr;
+      const int NP = kPeers ? d.n_peers : 1;
+      double* pubv = d.vpub + (int64_t)((mi & 1) * V + v) * L;
       if (PR) {
-        if (upd) {
-          st_sys(pubv + j, g_new);
-          st_sys(pubv + p + j, w_new);
-        }
-        if (icpt) {
-          st_sys(pubv + 2 * p, gb_new);
-          st_sys(pubv + 2 * p + 1, b_new);
+        if (act) {
+          st_sys(pubv + oa, a_new);
+          st_sys(pubv + ob, b_new);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tq == 0)
           for (int q = 0; q < NP; ++q)
-            __hip_atomic_fetch_add(PR->sync[q] + (kSyncCol + wi) * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(PR->sync[q] + wi * kSyncLine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       } else {
-        if (upd) {
-          st_sc1(pubv + j, g_new);
-          st_sc1(pubv + p + j, w_new);
+        if (act) {
+          st_sc1(pubv + oa, a_new);
+          st_sc1(pubv + ob, b_new);
         }
-        if (icpt) {
-          st_sc1(pubv + 2 * p, gb_new);
-          st_sc1(pubv + 2 * p + 1, b_new);
-        }
-        fused_arrive(sync, kSyncCol + wi);
+        fused_arrive(d.vcol, wi);
       }
       if (tq == 0)
-        sh_ok = fused_poll(sync, kSyncCol + wi, (unsigned)(NP * V) * (col_base + (unsigned)(mi + 1)), lamp, PR != nullptr) ? 1 : 0;
+        sh_ok = fused_poll(d.vcol, wi, (unsigned)(NP * V) * (col_base + (unsigned)(mi + 1)), lamp, PR != nullptr, sync) ? 1 : 0;
       __syncthreads();
       if (!sh_ok) break;
-      double mg = rg, mw = rw, mgb = rgb, mb = rb;
-      const double tot_all = PR ? PR->tot_size : tot_size;
+      double ma = ra, mb = rb;
+      const double tot_all = PR ? PR->tot_size : sh_par[8];
       for (int q = 0; q < NP; ++q) {              // rank after rank, shard after shard: the same order everywhere
-        const double* pub0 = (PR ? PR->pub[q] : d.vx) + (int64_t)((mi & 1) * V) * L;
-        double xg[8], xw[8], xgb[8], xb[8];       // every load of a rank's exchange first: one round trip
+        const double* pub0 = (PR ? PR->pub[q] : d.vpub) + (int64_t)((mi & 1) * V) * L;
+        double xa[8], xb[8];                      // every load of a rank's exchange first: one round trip
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          xg[u] = xw[u] = xgb[u] = xb[u] = 0.0;
-          if (u < V && upd) {
-            xg[u] = PR ? ld_sys(pub0 + (int64_t)u * L + j) : ld_sc1(pub0 + (int64_t)u * L + j);
-            xw[u] = PR ? ld_sys(pub0 + (int64_t)u * L + p + j) : ld_sc1(pub0 + (int64_t)u * L + p + j);
-          }
-          if (u < V && icpt) {
-            xgb[u] = PR ? ld_sys(pub0 + (int64_t)u * L + 2 * p) : ld_sc1(pub0 + (int64_t)u * L + 2 * p);
-            xb[u] = PR ? ld_sys(pub0 + (int64_t)u * L + 2 * p + 1) : ld_sc1(pub0 + (int64_t)u * L + 2 * p + 1);
+          xa[u] = xb[u] = 0.0;
+          if (u < V && act) {
+            xa[u] = PR ? ld_sys(pub0 + (int64_t)u * L + oa) : ld_sc1(pub0 + (int64_t)u * L + oa);
+            xb[u] = PR ? ld_sys(pub0 + (int64_t)u * L + ob) : ld_sc1(pub0 + (int64_t)u * L + ob);
           }
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           if (u < V) {
             const double wt = (PR ? PR->vsize[q][u] : d.v_size[u]) / tot_all;
-            mg += wt * (xg[u] - rg);
-            mw += wt * (xw[u] - rw);
-            mgb += wt * (xgb[u] - rgb);
+            ma += wt * (xa[u] - ra);
             mb += wt * (xb[u] - rb);
           }
         }
       }
-      if (upd) {
-        g_new = mg;
-        w_new = mw;
-        st_sc1(refv + j, mg);
-        st_sc1(refv + p + j, mw);
-        if (last && v == 0) {
-          d.G[j] = mg;
-          d.w[j] = mw;
-        }
-      }
-      if (icpt) {
-        gb_new = mgb;
+      if (act) {
+        a_new = ma;
         b_new = mb;
-        st_sc1(refv + 2 * p, mgb);
-        st_sc1(refv + 2 * p + 1, mb);
-        if (last && v == 0) {
-          d.gb[0] = mgb;
-          d.b[0] = mb;
+        st_sc1(refv + oa, ma);
+        st_sc1(refv + ob, mb);
+        if (last && v == 0) {                     // the solver's own state: what the epoch returns
+          *const_cast<double*>(own_a) = ma;
+          *const_cast<double*>(own_b) = mb;
         }
       }
       ++mi;
       FPH(5);
     }
-    if (upd) {
-      st_shard(vwv + j, w_new, local);
-      st_shard(vGv + j, g_new, local);
-    }
-    if (icpt) {
-      st_shard(d.vb + v, b_new, local);
-      st_shard(d.vgb + v, gb_new, local);
+    if (act) {
+      st_shard(rep_a, a_new, local);
+      st_shard(rep_b, b_new, local);
     }
     if (std_x) {                                // c . w of the slice, for the next round's linear predictors
-      const double a = fused_block_sum(upd ? c_own * w_new : 0.0, sh_red);
+      const double a = fused_block_sum(upd ? c_own * b_new : 0.0, sh_red);
       if (tq == 0) st_shard(cwp + v * kFusedMaxBps + wi, a, local);
     }
     if (last) {
@@ -3678,14 +3675,16 @@ static size_t fused_lds_bytes(const SagaDev& d) {
 }
 size_t vs_fused_sync_words() { return (size_t)(kSyncLines + 2) * kSyncLine; }
 size_t vs_fused_sync_sticky_word() { return (size_t)kSyncSticky * kSyncLine; }
-size_t vs_fused_sync_col_word() { return (size_t)kSyncCol * kSyncLine; }
+size_t vs_fused_col_words() { return (size_t)kFusedMaxBps * kSyncLine; }
+// local: V reference copies [g_sum | w | g_sum_b | b] + V x 128 c.w partials; published: 2 parities x V slices
 size_t vs_fused_exchange_doubles(const SagaDev& d, int n_shards) {
-  return (size_t)3 * n_shards * (size_t)(2 * d.p + 2) + (size_t)n_shards * kFusedMaxBps;
+  return (size_t)n_shards * (size_t)(2 * d.p + 2) + (size_t)n_shards * kFusedMaxBps;
 }
+size_t vs_fused_publish_doubles(const SagaDev& d, int n_shards) { return (size_t)2 * n_shards * (size_t)(2 * d.p + 2); }
 
 // sparse x, one response, compact records, an even number of features, slices of at most 384 features
 bool vs_fused_eligible(const SagaDev& d) {
-  if (!vs_eligible(d, 0) || d.K != 1 || d.xd || !d.cP || !lanes8_ok(d) || (d.p & 1) || !d.vsync || !d.vx) return false;
+  if (!vs_eligible(d, 0) || d.K != 1 || d.xd || !d.cP || !lanes8_ok(d) || (d.p & 1) || !d.vsync || !d.vx || !d.vcol || !d.vpub) return false;
   if (d.v_bps < 1 || d.v_bps > kFusedMaxBps || d.V * d.v_bps > 1024) return false;
   if (fused_slice(d) > 2 * 64 * kFusedChunks) return false;
   if ((int64_t)d.V * d.v_bps * d.p * 8 >= (1ll << 31)) return false;
@@ -3700,7 +3699,9 @@ int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStre
   int cur_dev = 0;
   (void)hipGetDevice(&cur_dev);
   if (!attr_done_dev[cur_dev & 63]) {
-    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_vs_epoch_kernel),
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_vs_epoch_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
+    SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_vs_epoch_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
     attr_done_dev[cur_dev & 63] = true;
   }
@@ -3708,8 +3709,12 @@ int launch_vs_epoch(const SagaDev& d, LamParams* lam, int nb, int every, hipStre
   const int rng_wgs = vs_fused_rng_workgroups(d);
   size_t lds = fused_lds_bytes(d);
   if (rng_wgs > 0 && lds < kJumpLds) lds = kJumpLds;
-  hipExtLaunchKernelGGL(saga_vs_epoch_kernel, dim3(vs_grid(d) + rng_wgs), dim3(kLdsBlock), lds, st, ev0, ev1, 0, d,
-                        lam, nb, every);
+  if (d.n_peers > 1 && d.peers)
+    hipExtLaunchKernelGGL(saga_vs_epoch_kernel<true>, dim3(vs_grid(d) + rng_wgs), dim3(kLdsBlock), lds, st, ev0, ev1, 0, d,
+                          lam, nb, every);
+  else
+    hipExtLaunchKernelGGL(saga_vs_epoch_kernel<false>, dim3(vs_grid(d) + rng_wgs), dim3(kLdsBlock), lds, st, ev0, ev1, 0, d,
+                          lam, nb, every);
   SGD_HIP_TRY(hipGetLastError());
   return SGDNET_OK;
 }

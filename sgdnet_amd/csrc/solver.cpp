@@ -2275,8 +2275,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   s->vs_owned.clear();
   SagaDev& d = s->d;
   d.V = 0;
-  d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = d.vx = nullptr;
-  d.vsync = nullptr;
+  d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = d.vx = d.vpub = nullptr;
+  d.vsync = d.vcol = nullptr;
   d.peers = nullptr;                            // links name the buffers just freed: link again
   d.n_peers = 0;
   if (n_shards < 2) return SGDNET_OK;
@@ -2301,8 +2301,9 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   if (!rc) rc = alloc(&d.vd0, 256 * (size_t)d.K);
   if (!rc) rc = alloc(&d.vref, (size_t)(2 * KP + 2 * d.K));
   if (!rc && d.K == 1) {
-    // the fused epoch kernel's barrier counters and exchange buffer: fine-grained device memory, because linked
-    // solvers on other GPUs add to the counters and read the buffer while the kernels run (sgdnet_solver_link_peers)
+    // the fused epoch kernel's barrier counters and reference copies (ordinary device memory), and what its merges
+    // exchange -- slice counters and published slices -- in fine-grained memory: linked solvers on other GPUs add to
+    // those counters and read those slices while the kernels run (sgdnet_solver_link_peers)
     auto alloc_fg = [&](void** out, size_t bytes) -> int {
       void* q = nullptr;
       if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocFinegrained) != hipSuccess) {
@@ -2314,8 +2315,12 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
       *out = q;
       return SGDNET_OK;
     };
-    rc = alloc_fg(reinterpret_cast<void**>(&d.vsync), vs_fused_sync_words() * sizeof(unsigned));
-    if (!rc) rc = alloc_fg(reinterpret_cast<void**>(&d.vx), vs_fused_exchange_doubles(d, n_shards) * sizeof(double));
+    double* words = nullptr;
+    rc = alloc(&words, (vs_fused_sync_words() * sizeof(unsigned) + sizeof(double) - 1) / sizeof(double));
+    d.vsync = reinterpret_cast<unsigned*>(words);
+    if (!rc) rc = alloc(&d.vx, vs_fused_exchange_doubles(d, n_shards));
+    if (!rc) rc = alloc_fg(reinterpret_cast<void**>(&d.vcol), vs_fused_col_words() * sizeof(unsigned));
+    if (!rc) rc = alloc_fg(reinterpret_cast<void**>(&d.vpub), vs_fused_publish_doubles(d, n_shards) * sizeof(double));
   }
   if (rc) {
     set_error("virtual shards: out of device memory");
@@ -2330,8 +2335,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
     for (void* q : s->vs_owned) (void)hipFree(q);
     s->vs_owned.clear();
     d.V = 0;
-    d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = d.vx = nullptr;
-    d.vsync = nullptr;
+    d.vw = d.vG = d.vb = d.vgb = d.vd0 = d.vref = d.vcw = d.vx = d.vpub = nullptr;
+    d.vsync = d.vcol = nullptr;
     set_error("virtual shards: n_features too large for the LDS-resident gather");
     return SGDNET_EUNSUPPORTED;
   }
@@ -2421,8 +2426,8 @@ int sgdnet_solver_link_peers(sgdnet_solver** solvers, int n) {
     h.rank = q;
     h.tot_size = tot;
     for (int r = 0; r < n; ++r) {
-      h.pub[r] = solvers[r]->d.vx;
-      h.sync[r] = solvers[r]->d.vsync;
+      h.pub[r] = solvers[r]->d.vpub;
+      h.sync[r] = solvers[r]->d.vcol;
       for (int u = 0; u < 8; ++u) h.vsize[r][u] = solvers[r]->d.v_size[u];
     }
     if (!s->peers_dev) {
@@ -2433,6 +2438,7 @@ int sgdnet_solver_link_peers(sgdnet_solver** solvers, int n) {
     }
     SGD_HIP_TRY(hipMemcpy(s->peers_dev, &h, sizeof(FusedPeers), hipMemcpyHostToDevice));
     SGD_HIP_TRY(hipMemset(s->d.vsync, 0, vs_fused_sync_words() * sizeof(unsigned)));   // slice counters and launch count start together
+    SGD_HIP_TRY(hipMemset(s->d.vcol, 0, vs_fused_col_words() * sizeof(unsigned)));
     s->d.peers = s->peers_dev;
     s->d.n_peers = n;
   }
@@ -2451,14 +2457,14 @@ struct PeerInfo {
 int sgdnet_solver_peer_info_bytes(void) { return (int)sizeof(PeerInfo); }
 
 int sgdnet_solver_peer_info(sgdnet_solver* s, void* out) {
-  if (!s || !out || !s->d.vx || !s->d.vsync) {
+  if (!s || !out || !s->d.vpub || !s->d.vcol) {
     set_error("sgdnet_solver_peer_info: set the virtual shards first (one response, sparse x)");
     return SGDNET_EINVAL;
   }
   SGD_HIP_TRY(hipSetDevice(s->device));
   PeerInfo h{};
-  SGD_HIP_TRY(hipIpcGetMemHandle(&h.vx, s->d.vx));
-  SGD_HIP_TRY(hipIpcGetMemHandle(&h.vsync, s->d.vsync));
+  SGD_HIP_TRY(hipIpcGetMemHandle(&h.vx, s->d.vpub));
+  SGD_HIP_TRY(hipIpcGetMemHandle(&h.vsync, s->d.vcol));
   for (int u = 0; u < 8; ++u) h.vsize[u] = s->d.v_size[u];
   h.V = s->d.V;
   h.v_bps = s->d.v_bps;
@@ -2494,8 +2500,8 @@ int sgdnet_solver_link_ipc(sgdnet_solver* s, int rank, int n, const void* infos)
       if (u < I[r].V) h.tot_size += I[r].vsize[u];
     }
     if (r == rank) {
-      h.pub[r] = s->d.vx;
-      h.sync[r] = s->d.vsync;
+      h.pub[r] = s->d.vpub;
+      h.sync[r] = s->d.vcol;
     } else {
       void *px = nullptr, *py = nullptr;
       SGD_HIP_TRY(hipIpcOpenMemHandle(&px, I[r].vx, hipIpcMemLazyEnablePeerAccess));
