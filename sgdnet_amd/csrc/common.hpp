@@ -289,7 +289,7 @@ int launch_range_moment(const SagaDev& d, const uint16_t* feat_range, unsigned l
 size_t binned_max_range_features(int K);
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards = 0, const double* shard_size = nullptr,
-                    int gens = 1, int64_t run_len = 0, int convert = 1, int narrow_cus = 0);
+                    int gens = 1, int64_t run_len = 0, int convert = 1, int narrow_cus = 0, int wgs = 0);
 int launch_rng_convert(uint32_t* out, int64_t count, uint32_t n_samples, hipStream_t st, int n_shards,
                        const double* shard_size, int64_t run_len, int narrow_cus = 0);
 

@@ -34,18 +34,21 @@ constexpr int kGenPerWg = 4;        // generators per workgroup (they step in lo
 // words, 227 busy lanes), so kGenPerWg of them share a workgroup -- and with it a CU: the sample order of a C4
 // epoch then holds 8 CUs instead of 32 for the same ~0.18 ms (the LDS gather forms give their workgroups'
 // CUs up to the generators, lds_target_grid).
-// blk: this workgroup's index among the generators' workgroups; bufs: kGenPerWg x 2 x (kN + 1) words of LDS
-__device__ __forceinline__ void mt_state_body(int blk, uint32_t (*bufs)[2][kMtN + 1], const uint32_t* st_in,
+// blk / nblk: this workgroup's index among the generators' workgroups and their number -- workgroup b carries
+// generators b, b + nblk, b + 2 nblk, ... (at most kGenPerWg of them; nblk * kGenPerWg >= gens), so that a launch with
+// more workgroups than ceil(gens / kGenPerWg) spreads the generators (short epochs: the generators' workgroups must
+// not outlast the epoch they run beside); bufs: kGenPerWg x 2 x (kN + 1) words of LDS
+__device__ __forceinline__ void mt_state_body(int blk, int nblk, uint32_t (*bufs)[2][kMtN + 1], const uint32_t* st_in,
                                               uint32_t* st_out, uint32_t* out, int64_t count, int64_t seg, int gens) {
   constexpr int kN = kMtN, kM = kMtM;
   const int t = threadIdx.x & (kRngBlock - 1);
   const int sub = threadIdx.x / kRngBlock;
-  const int64_t g = (int64_t)blk * kGenPerWg + sub;
+  const int64_t g = (int64_t)sub * nblk + blk;
   const bool live = g < gens;
   uint32_t(*buf)[kN + 1] = bufs[sub];
   int64_t max_count = 0;                      // the longest segment of this workgroup: its generators loop together
   {
-    const int64_t g0 = (int64_t)blk * kGenPerWg;
+    const int64_t g0 = (int64_t)blk;                // the workgroup's first generator: the longest segment among its own
     const int64_t left0 = count - g0 * seg;
     max_count = left0 < 0 ? 0 : (left0 < seg ? left0 : seg);
   }

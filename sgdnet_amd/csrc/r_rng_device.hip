@@ -21,7 +21,7 @@ __global__ __launch_bounds__(kRngBlock* kGenPerWg) void r_mt_state_kernel(const 
                                                                           uint32_t* out, int64_t count, int64_t seg,
                                                                           int gens) {
   __shared__ uint32_t bufs[kGenPerWg][2][kMtN + 1];
-  mt_state_body((int)blockIdx.x, bufs, st_in, st_out, out, count, seg, gens);
+  mt_state_body((int)blockIdx.x, (int)gridDim.x, bufs, st_in, st_out, out, count, seg, gens);
 }
 
 __global__ __launch_bounds__(kJumpBlock) void r_mt_jump_kernel(const uint32_t* st_in_all, uint32_t* st_out_all,
@@ -208,10 +208,12 @@ int launch_rng_convert(uint32_t* out, int64_t count, uint32_t n_samples, hipStre
 // fused epoch kernel of the virtual shards converts its own shares, saga_batched.hip)
 int launch_rng_fill(const uint32_t* state_in, uint32_t* state_out, uint32_t n_samples, uint32_t* out,
                     int64_t count, hipStream_t st, int n_shards, const double* shard_size, int gens, int64_t run_len,
-                    int convert, int narrow_cus) {
+                    int convert, int narrow_cus, int wgs) {
   if (gens < 1) gens = 1;
   const int64_t seg = (count + gens - 1) / gens;
-  hipLaunchKernelGGL(r_mt_state_kernel, dim3((gens + kGenPerWg - 1) / kGenPerWg), dim3(kRngBlock * kGenPerWg), 0, st,
+  int grid = (gens + kGenPerWg - 1) / kGenPerWg;
+  if (wgs > grid) grid = wgs < gens ? wgs : gens;          // the generators spread over the workgroups they were given
+  hipLaunchKernelGGL(r_mt_state_kernel, dim3(grid), dim3(kRngBlock * kGenPerWg), 0, st,
                      state_in, state_out, out, count, seg, gens);
   SGD_HIP_TRY(hipGetLastError());
   if (!convert) return SGDNET_OK;

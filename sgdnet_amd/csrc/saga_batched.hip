@@ -2181,7 +2181,7 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
       const unsigned gen = R->gen;
       uint32_t* lds = reinterpret_cast<uint32_t*>(Dl);
       const int rb = (int)blockIdx.x - V * S, nrb = (int)gridDim.x - V * S;
-      mt_state_body(rb, reinterpret_cast<uint32_t(*)[2][kMtN + 1]>(lds), R->state[gen & 1u], R->ends,
+      mt_state_body(rb, nrb, reinterpret_cast<uint32_t(*)[2][kMtN + 1]>(lds), R->state[gen & 1u], R->ends,
                     R->stream + (int64_t)(gen & 1u) * R->n, R->n, R->seg, R->gens);
       __syncthreads();
       mt_jump_body(rb, nrb, lds, R->state[gen & 1u], R->state[(gen + 1u) & 1u], R->poly, R->gens);

@@ -1460,8 +1460,11 @@ int solver_rng_open(sgdnet_solver* s, sgdnet_rng* rng, int64_t n, int generators
   P.G = generators;
   {
     // the generators' workgroups get CUs of their own: the LDS gather forms shrink their grids
+    // one workgroup per generator up to 8 workgroups, then up to four generators per workgroup: the generators' work
+    // per epoch (state step: seg / 624 blocks of ~0.46 us; jump: ~64 us per generator and workgroup) must stay below the
+    // epoch's own duration -- at C3 (1M draws, 8 generators) two workgroups of four needed 370 us beside a 246-us epoch
     const int per_wg = rng_generators_per_workgroup();
-    const int reserve = generators > 1 ? (generators + per_wg - 1) / per_wg : 0;
+    const int reserve = generators > 1 ? std::max(std::min(generators, 8), (generators + per_wg - 1) / per_wg) : 0;
     // (Tried: confining the side stream to exactly those CUs with hipExtStreamCreateWithCUMask -- mask bit i is a
     // CU of XCC i % 8, scripts/microbench/cu_mask.hip -- so that the conversion kernel's 2048 small workgroups
     // cannot spread over CUs a gather launch is about to need: on 8 CUs that kernel takes 0.8 ms instead of 0.05,
@@ -1529,7 +1532,7 @@ static int rng_side_generate(sgdnet_solver* s, int64_t g, bool keep_raw) {
   P.raw[slot] = keep_raw;
   if (P.G > 1) {
     rc = launch_rng_fill(P.state[g & 1], P.ends, (uint32_t)s->d.n, s->stream_dev + (int64_t)slot * P.n, P.n,
-                         P.st, s->d.V, s->d.v_size, P.G, P.run_len, keep_raw ? 0 : 1);
+                         P.st, s->d.V, s->d.v_size, P.G, P.run_len, keep_raw ? 0 : 1, 0, s->d.cu_reserve);
     // the jump's workgroups take their generators in turn: the side stream never holds more CUs than
     // the generators' own (a wider launch would push gather workgroups into a second round)
     if (!rc) rc = launch_rng_jump(P.state[g & 1], P.state[(g + 1) & 1], P.poly_n, P.G, P.st,
