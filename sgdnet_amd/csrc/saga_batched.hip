@@ -3009,7 +3009,10 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
       double wv[kBinW];
 #pragma unroll
       for (int e = 0; e < kBinW; ++e) {
-        const int j = __shfl(cur.j0, e0 + e, kGrp);
+        int j = __shfl(cur.j0, e0 + e, kGrp);
+        // (timing only, -DSGDNET_EXPERIMENTS: every coefficient row from a 1 MB window -- an upper bound of what
+        //  feature ranges held in one XCD's L2 could buy: profiles/r04_c5_xcd_bound.txt)
+        if (SGD_ABLATE(d, 32)) j &= 8191;
         wv[e] = (have && e0 + e < creg && lane_on) ? d.wpad[(int64_t)j * KS + gl] : 0.0;
       }
 #pragma unroll
@@ -3153,7 +3156,8 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
     double gq[kEnt];
 #pragma unroll
     for (int qq = 0; qq < kEnt; ++qq) {
-      const int t = __shfl((int)mine.t, qq, kGrp);
+      int t = __shfl((int)mine.t, qq, kGrp);
+      if (SGD_ABLATE(d, 64)) t &= 8191;         // (timing only: every gradient-change row from a 1 MB window)
       gq[qq] = (lane_on && e0 + qq < cntb) ? d.gcb[(int64_t)t * d.KS + gl] : 0.0;
     }
 #pragma unroll
