@@ -2390,7 +2390,6 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     const int mn = (int)(dps - t0n < m_full ? dps - t0n : m_full);
     uint32_t xraw[kC];
     const bool conv_next = !last && raw_words;
-    if (conv_next) conv_load(t0n, mn, xraw);    // the next round's share of the sample order: requested now
 
     // ---- publish the slab (write-through) and the sum of the gradient changes -----------------------
     {
@@ -2410,6 +2409,9 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
     }
     fused_arrive(sync, kSyncCnt1 + v);
     FPH(2);
+    // the next round's share of the sample order: requested behind the arrival (in front of it the arrival's drain
+    // waited for these loads: +3 us per round for every workgroup), converted and stored behind the poll below
+    if (conv_next) conv_load(t0n, mn, xraw);
     // behind the arrival, while the rest of the shard finishes: this workgroup's own coefficients (nobody else
     // writes them), and the next round's share of the sample order.
     // A thread owns one PAIR (A, B) of the replicated state: (g_sum_j, w_j) of its feature j, or -- the first thread
@@ -2434,11 +2436,11 @@ __global__ __launch_bounds__(kLdsBlock) void saga_vs_epoch_kernel(SagaDev d, Lam
         rb = mi == 0 ? *own_b : ld_sc1(refv + ob);
       }
     }
-    if (conv_next) conv_store(t0n, mn, xraw);
     if (tq == 0) sh_ok = fused_poll(sync, kSyncCnt1 + v, (unsigned)S * (unsigned)(r + 1), lamp) ? 1 : 0;
     __syncthreads();
     if (!sh_ok) break;
     FPH(3);
+    if (conv_next) conv_store(t0n, mn, xraw);   // (the words arrived while the counter was polled)
 
     // ---- sweep of this workgroup's feature slice ------------------------------------------------
     {
