@@ -172,3 +172,52 @@ def test_fit_sharded_over_two_ranks_equals_the_fit_on_one_gpu(sa):
     assert np.array_equal(r1.unif(32), r2.unif(32))
     with pytest.raises(Exception, match="n_gpus"):          # what the sharded fit does not cover says so
         sa.sgdnet(x, y, rng=sa.RRng(1), devices=[0, 0], **dict(kw, mode="exact"))
+
+
+def test_two_processes_on_one_gpu_fall_back_to_separate_launches(sa, tmp_path):
+    """The epoch kernel's workgroups wait for each other, so a launch needs (nearly) the whole GPU at once; two
+    processes that fit at the same time on ONE GPU (R workers, say) cannot both have it.  The start barrier notices
+    (nothing has been modified yet), the solver runs that epoch -- and the rest of its life -- as separate launches, and
+    the fit comes out as if nothing had happened: both processes return the path a lone process computes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(f'''
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import sgdnet_amd as sa
+from sgdnet_amd import data as D
+n, p = 400_000, 200
+pr = D.make_sparse_glm(n, p, 0.05, family="binomial", seed=41)
+x, y = D.as_scipy(pr).T.tocsc(), pr["y"].ravel()
+kw = dict(family="binomial", alpha=0.5, nlambda=12, standardize=False, thresh=1e-6, maxit=60, mode="batched")
+if sys.argv[1] == "ref":
+    sa.set_option("fused_epoch", 0)
+else:                                  # both workers have their data: start fitting together
+    import os, time
+    open(sys.argv[2] + ".ready", "w").close()
+    t0 = time.time()
+    while not os.path.exists(sys.argv[3] + ".ready") and time.time() - t0 < 120:
+        time.sleep(0.001)
+fits = [sa.sgdnet(x, y, seed=3, **kw) for _ in range(1 if sys.argv[1] == "ref" else 12)]
+np.save(sys.argv[2], np.stack([f.beta for f in fits]))
+print("passes", [f.npasses for f in fits])
+''')
+    env = dict(os.environ, SGDNET_TRACE="1")
+    ref = tmp_path / "ref.npy"
+    subprocess.run([sys.executable, str(script), "ref", str(ref)], check=True, env=env, capture_output=True, timeout=600)
+    outs = [tmp_path / f"w{i}.npy" for i in range(2)]
+    procs = [subprocess.Popen([sys.executable, str(script), "work", str(outs[i]), str(outs[1 - i])], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(2)]
+    logs = [pr.communicate(timeout=600) for pr in procs]
+    for pr, (so, se) in zip(procs, logs):
+        assert pr.returncode == 0, se[-2000:]
+    fell_back = sum("could not become resident" in se for _, se in logs)
+    print(f"workers that fell back to separate launches: {fell_back} of 2")
+    want = np.load(ref)[0]
+    for o in outs:
+        got = np.load(o)
+        for k in range(got.shape[0]):
+            assert np.abs(got[k] - want).max() <= 1e-8 * np.abs(want).max()
