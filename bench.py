@@ -201,6 +201,34 @@ def main():
                       device=local_rank)
     S.set_penalty("elasticnet", gamma, a_l2, b_l1)
     S.set("intercept", b0)
+    if os.environ.get("SGDNET_BENCH_ONE_GPU") == "1" and world > 1 and K == 1 and not sync_mode:
+        S.set_cu_budget(256 // world - 16)                     # rehearsal: the ranks share one GPU's CUs
+    peers_note = ""
+    if peers_mode:
+        # link the ranks' solvers (sgdnet_solver_link_ipc: hipIpc mappings of the exchange buffers); every rank must
+        # succeed, else everybody takes the RCCL scheme (--merge avg) -- the line's `merge` string says which ran
+        ok = 1.0
+        try:
+            S.set_virtual_shards(V)
+            S.set_merge_period(max(1, (n_local // V) // 4))
+            infos = [None] * world
+            dist.all_gather_object(infos, S.peer_info())
+            S.link_ipc(rank, infos)
+        except Exception as e:                                 # noqa: BLE001
+            peers_note = f"{type(e).__name__}: {e}"[:200]
+            note(f"peer link failed: {peers_note}")
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        dist.barrier()
+        if float(flag[0]) < 0.5:
+            peers_mode = False
+            S.set_virtual_shards(0)                            # (also drops a half-made link)
+            V = 1
+            while V < 8 and 2 * V * 100 * p <= n_local:
+                V *= 2
+            if args.vshards >= 0:
+                V = max(1, args.vshards)
     # sample order: R's Mersenne-Twister, set.seed(config id [+ rank] [+ 100 shard]).  With virtual
     # shards every local run (an epoch, or a merge segment when N > 1) is laid out shard after shard
     # (include/sgdnet_hip.h: sgdnet_solver_set_virtual_shards)
@@ -228,25 +256,9 @@ def main():
         min(32, max(8, n_local // 300000)) if n_local >= 200000 else 1)
     if V > 1:
         from sgdnet_amd.parallel import shard_bounds as sb
-        if os.environ.get("SGDNET_BENCH_ONE_GPU") == "1" and world > 1:
-            S.set_cu_budget(256 // world - 16)                 # rehearsal: the ranks share one GPU's CUs
-        S.set_virtual_shards(V)
-        S.set_merge_period(shard_period)
-        if peers_mode:
-            # link the ranks' solvers (sgdnet_solver_link_ipc); every rank must succeed, else everybody takes the RCCL scheme
-            ok = 1.0
-            try:
-                infos = [None] * world
-                dist.all_gather_object(infos, S.peer_info())
-                S.link_ipc(rank, infos)
-            except Exception as e:                             # noqa: BLE001
-                note(f"peer link failed: {e}")
-                ok = 0.0
-            flag = torch.tensor([ok], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            dist.barrier()
-            if float(flag[0]) < 0.5:
-                sys.exit("bench.py --merge peers: the solvers could not be linked (hipIpc); rerun with --merge avg")
+        if not peers_mode:                                     # (the linked solvers have theirs already)
+            S.set_virtual_shards(V)
+            S.set_merge_period(shard_period)
         rngs = [sa.RRng(seed + rank + 100 * v) for v in range(V)]
 
         def host_stream(epochs):
@@ -292,6 +304,7 @@ def main():
                       stage_on_host=(backend != "nccl"), fused=fused)
         sj = ShardedSaga(sh, world, segs, force_merge=force_merge)
         desc = ("none" if world == 1 and not force_merge else
+                (f"(peers link failed: {peers_note}) " if peers_note else "") +
                 f"avg: locally normalised shard runs, {backend} all-reduce of the weighted state deltas every "
                 f"{segs[0]} draws per rank ({len(segs)} per epoch)" + (", stream-ordered" if fused else ""))
         return sj.epoch, sh, desc, 0
