@@ -229,6 +229,11 @@ def main():
                 V *= 2
             if args.vshards >= 0:
                 V = max(1, args.vshards)
+    if args.batch <= 0 and V > 1 and not sync_mode:
+        # the fit driver's rule for shards (sgdnet_shard_window): at most 1/8 beyond the rule's window when that saves the
+        # short last round of every shard's epoch
+        batch = sa.shard_window(batch, n_local // V)
+        note(f"window for {V} shards of {n_local // V} draws: {batch}")
     # sample order: R's Mersenne-Twister, set.seed(config id [+ rank] [+ 100 shard]).  With virtual
     # shards every local run (an epoch, or a merge segment when N > 1) is laid out shard after shard
     # (include/sgdnet_hip.h: sgdnet_solver_set_virtual_shards)

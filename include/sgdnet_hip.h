@@ -463,6 +463,13 @@ int sgdnet_predict_dense(const double* x, int64_t n, int64_t p, int n_classes, c
  * iteration when the rule asks for less than that or an epoch would be more than 16384 batches. */
 int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq);
 
+/* The window of a fit with virtual shards: a shard's epoch of `draws_per_shard` draws is ceil(draws_per_shard / window)
+ * rounds, each with a fixed hand-off cost inside the epoch kernel.  When `window` (sgdnet_auto_batch's, capped) leaves a
+ * short last round and a window at most 1/8 longer saves that round, the longer one is returned (config 4: 1 250 000 draws
+ * per shard, 131 072 -> 138 889: nine rounds instead of ten); `window` otherwise.  sgdnet_fit_* apply it to their automatic
+ * window (the rule of sgdnet_auto_batch keeps a factor 3 to the unstable regime; 1/8 of it is spent here). */
+int64_t sgdnet_shard_window(int64_t window, int64_t draws_per_shard);
+
 #ifdef __cplusplus
 }
 #endif

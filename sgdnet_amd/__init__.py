@@ -9,7 +9,7 @@ from .api import SgdnetFit, sgdnet  # noqa: F401
 from .cv import CvSgdnet, cv_sgdnet  # noqa: F401
 from .predict import coef, predict  # noqa: F401
 from .score import score  # noqa: F401
-from .solver import RRng, SagaSolver, auto_batch, get_option, link_peers, option, set_option  # noqa: F401
+from .solver import RRng, SagaSolver, auto_batch, get_option, link_peers, option, set_option, shard_window  # noqa: F401
 
 __all__ = ["sgdnet", "SgdnetFit", "SagaSolver", "RRng", "auto_batch", "SgdnetError", "load", "LIB_PATH",
            "cv_sgdnet", "CvSgdnet", "predict", "coef", "score", "set_option", "get_option", "option"]

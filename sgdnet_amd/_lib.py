@@ -22,7 +22,7 @@ EXPORTS = [
     "sgdnet_solver_run", "sgdnet_solver_enqueue_epochs", "sgdnet_solver_sync",
     "sgdnet_solver_profile_epoch", "sgdnet_solver_deviance", "sgdnet_solver_snapshot",
     "sgdnet_solver_export_delta", "sgdnet_solver_apply_merged", "sgdnet_solver_delta_len",
-    "sgdnet_solver_convergence", "sgdnet_solver_last_change", "sgdnet_auto_batch",
+    "sgdnet_solver_convergence", "sgdnet_solver_last_change", "sgdnet_auto_batch", "sgdnet_shard_window",
     "sgdnet_solver_gather_form", "sgdnet_solver_stream", "sgdnet_solver_export_delta_async",
     "sgdnet_solver_apply_merged_async", "sgdnet_solver_sync_buffer_len", "sgdnet_solver_sync_bind",
     "sgdnet_solver_sync_begin", "sgdnet_solver_sync_gather", "sgdnet_solver_sync_sweep",
@@ -174,6 +174,8 @@ def load():
     L.sgdnet_solver_gather_form.argtypes = [C.c_void_p, C.c_int64]
     L.sgdnet_auto_batch.argtypes = [C.c_double, C.c_double]
     L.sgdnet_auto_batch.restype = C.c_int64
+    L.sgdnet_shard_window.argtypes = [C.c_int64, C.c_int64]
+    L.sgdnet_shard_window.restype = C.c_int64
     L.sgdnet_fit_sparse.argtypes = [C.POINTER(Csc), C.POINTER(C.c_double), C.c_int,
                                     C.POINTER(Control), C.POINTER(Result)]
     L.sgdnet_fit_dense.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int64,

@@ -797,6 +797,11 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
     set_error("control.n_gpus = %d: the sample order cannot be laid out per shard (explicit sample_stream?)", NG);
     return SGDNET_EUNSUPPORTED;
   }
+  if (vshards > 1 && ctl->batch <= 0 && batch > 0) {
+    // at most 1/8 beyond the rule's window when that saves the short last round of every shard's epoch
+    // (include/sgdnet_hip.h: sgdnet_shard_window; the rule keeps a factor 3 to the unstable regime, profiles/NOTES.md)
+    batch = sgdnet_shard_window(batch, (n / NG) / vshards);
+  }
 
   // built-in generator: the draws are produced in HBM (r_rng_device.hip), one epoch ahead of
   // the epoch that consumes them, on a side stream (solver.cpp: solver_rng_*)

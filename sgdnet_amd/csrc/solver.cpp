@@ -2188,6 +2188,13 @@ int64_t sgdnet_auto_batch(double max_sample_sqnorm, double max_feature_mean_sq) 
   return b < 64.0 ? 64 : (int64_t)b;
 }
 
+int64_t sgdnet_shard_window(int64_t window, int64_t draws_per_shard) {
+  if (window < 1 || draws_per_shard <= window || draws_per_shard % window == 0) return window;
+  const int64_t rounds = (draws_per_shard + window - 1) / window;          // >= 2
+  const int64_t longer = (draws_per_shard + rounds - 2) / (rounds - 1);
+  return longer <= window + window / 8 ? longer : window;
+}
+
 int64_t sgdnet_solver_sync_buffer_len(const sgdnet_solver* s) {
   if (!s) return 0;
   return (int64_t)s->d.K * s->d.p + 2 * 256 * (int64_t)s->d.K;

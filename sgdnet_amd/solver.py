@@ -109,6 +109,12 @@ def auto_batch(max_sample_sqnorm, max_feature_mean_sq):
     return int(_lib.load().sgdnet_auto_batch(float(max_sample_sqnorm), float(max_feature_mean_sq)))
 
 
+def shard_window(window, draws_per_shard):
+    """Window of a fit with virtual shards (sgdnet_shard_window of the C ABI): a slightly longer one when it saves
+    the short last round of every shard's epoch."""
+    return int(_lib.load().sgdnet_shard_window(int(window), int(draws_per_shard)))
+
+
 class SagaSolver:
     """One problem resident in HBM: sample-major x, y and the five SAGA state arrays
     (reference src/sgdnet.cpp:187-198).

@@ -77,6 +77,18 @@ def test_auto_batch_rule():
     assert sa.auto_batch(0.0, 0.0) == 64
 
 
+def test_shard_window_saves_a_short_last_round():
+    import sgdnet_amd as sa
+    assert sa.shard_window(131072, 1250000) == 138889        # config 4, 8 shards: 9 rounds of 138 889 instead of 9 + a tail
+    assert -(-1250000 // 138889) == 9
+    assert sa.shard_window(131072, 262144) == 131072         # no tail to save
+    assert sa.shard_window(131072, 150000) == 131072         # one round would need a window > 9/8 of the rule's
+    assert sa.shard_window(131072, 125000) == 131072         # a single round already
+    assert sa.shard_window(64, 100) == 64
+    assert sa.shard_window(1000, 10050) == 1005
+    assert sa.shard_window(0, 10) == 0
+
+
 def test_backend_options_are_the_documented_ones():
     """sgdnet_set_option is the one documented switchboard (include/sgdnet_hip.h); unknown names and values
     outside the documented range are refused, and the shipped library reads no kernel-selection environment
