@@ -30,8 +30,8 @@ def _run_bench(args, extra_env=None, timeout=600):
 
 @pytest.fixture(scope="module")
 def have_gpu():
-    # asked of the library, not of torch: torch carries its own HIP runtime, and whichever of the two opens the device
-    # second in one process sees none (bench.py itself runs in child processes)
+    # asked of the library, not of torch: torch.cuda.is_available() is false in a process where this library opened the
+    # device first; bench.py itself runs in child processes
     from sgdnet_amd import _lib
     if _lib.load().sgdnet_device_count() < 1:
         pytest.fail("bench.py needs a HIP device: the backend has no CPU fallback")
