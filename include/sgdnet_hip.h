@@ -162,7 +162,7 @@ int sgdnet_device_count(void);
 /* for that (SGDNET_TRACE prints progress to stderr and changes nothing;     */
 /* kernel A/B switches exist only in -DSGDNET_EXPERIMENTS builds).           */
 /*   "virtual_shards"     -1 (default): the driver's rule -- batched fits of */
-/*                        one response (or 2..16 classes of sparse x) with   */
+/*                        up to 16 classes or responses with                 */
 /*                        >= 200 000 samples run as up to 8 averaged         */
 /*                        replicas; 0 or 1: never;             */
 /*                        2..8: that many wherever the kernels allow it      */
@@ -389,7 +389,7 @@ int sgdnet_solver_sync_sweep(sgdnet_solver* s, int64_t m_global, int64_t m_local
 int sgdnet_solver_sync_end(sgdnet_solver* s, int rounds);
 
 /* Virtual shards (batched mode; one response: sparse x with or without implicit centring, or dense x;
- * 2..16 classes or responses: sparse x whose n_classes x n_features table fits the LDS): the samples are
+ * 2..16 classes or responses: sparse or dense x whose n_classes x n_features table fits the LDS): the samples are
  * split into n_shards contiguous ranges (sizes as shard_bounds of sgdnet_amd/parallel.py), every
  * range runs the batched iteration on its own replica of (w, g_sum, intercept) with local
  * normalisation, one launch carries the same batch of all shards, and the replicas are averaged

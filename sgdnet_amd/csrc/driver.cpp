@@ -623,9 +623,9 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   int64_t batch = ctl->batch;
   // SGDNET_MODE_BATCHED means "batched where it is implemented": more than 64 classes run the exact
   // iteration instead (a global options(sgdnet.mode = "batched") in R must not make such fits fail);
-  // dense x with 17..64 classes was handed to the sparse entry point by sgdnet_fit_dense
+  // (dense x with 17..64 classes: the class-lane form of round 4; until then sgdnet_fit_dense handed it to the sparse entry point)
   if (mode == SGDNET_MODE_AUTO) mode = SGDNET_MODE_BATCHED;
-  if (mode == SGDNET_MODE_BATCHED && (K > 64 || (!X.sparse && K > 16))) mode = SGDNET_MODE_EXACT;
+  if (mode == SGDNET_MODE_BATCHED && K > 64) mode = SGDNET_MODE_EXACT;
   if (mode == SGDNET_MODE_BATCHED) {
     if (batch <= 0) {
       double l_f = X.dev_max_mean_sq, raw = 0.0;
@@ -758,18 +758,22 @@ int fit_common(Features& X, const double* y_in, int Ky, const sgdnet_control* ct
   DrawSource draws(ctl);
   int vshards = 0;
   // Virtual shards (include/sgdnet_hip.h): with enough samples per feature the batched fit of
-  // one response (round 3: or of 2..16 classes of sparse x) runs as up to 8 locally normalised replicas over sample ranges, averaged on the
+  // one response (round 3: or of 2..16 classes of sparse x; round 4: of dense x too) runs as up to 8 locally normalised replicas over sample ranges, averaged on the
   // device every n / 32 draws -- same optimum, same epochs to tolerance, 2x the epochs per second
   // at the benchmark shapes.  sgdnet_set_option("virtual_shards", 0) switches it off, V forces V.
   // The shard kernels read a per-shard layout of the sample order: the built-in generator and
   // the unif callback produce it (DrawSource::fill), an explicit sample_stream cannot.
-  if (mode == SGDNET_MODE_BATCHED && (K == 1 || (K <= 16 && X.sparse)) && draws.shardable()) {
+  if (mode == SGDNET_MODE_BATCHED && K <= 16 && draws.shardable()) {
     int V = 1;
     // at least 100 samples per feature in every shard, and a problem large enough for the
     // per-launch cost to matter (small correlated data, e.g. abalone 4177 x 9, converges slower
     // or not at all when its replicas are averaged)
     if (n >= 200000)
       while (V < 8 && (int64_t)(2 * V) * 100 * p <= n) V *= 2;
+    // dense x with several classes (round 4): two replicas.  Its windows are a few hundred draws, an epoch is launch-bound
+    // and V shards make it V times shorter, but on such well-conditioned data the averaged replicas need more epochs
+    // (125 / 213 / 417 at V = 1 / 2 / 4 on 1M x 100, K = 4; profiles/r04_dense_multiclass_vshards.txt): 2 is what pays
+    if (!X.sparse && K > 1 && V > 2) V = 2;
     if (option(kOptVirtualShards) >= 0) V = option(kOptVirtualShards);
     if (NG > 1) {
       // the job stays a V-way average (8 at most: what the averaging tolerates at these sizes), cut over
@@ -1319,25 +1323,6 @@ static int fit_dense_impl(const double* x, int64_t n, int64_t p, const double* y
   }
   rc = validate_response(ctl, y, n);
   if (rc) return rc;
-  if ((ctl->mode == SGDNET_MODE_BATCHED || ctl->mode == SGDNET_MODE_AUTO) && ctl->n_classes > 16 &&
-      ctl->n_classes <= 64 && n * p < (int64_t)2147483647) {
-    // Batched mode, dense x, 17..64 classes: the dense batched kernels stop at 16 classes, the sparse
-    // binned form (a wavefront per draw) goes to 64.  A column-major dense matrix IS a CSC matrix with
-    // every entry stored -- the values are x itself -- and sparse and dense inputs describe the same
-    // model (standardisation included: scale + implicit centring against explicit centring), so the fit is
-    // routed there instead of falling back to the one-wavefront exact iteration.
-    std::vector<int32_t> colptr((size_t)p + 1), rowidx((size_t)(n * p));
-    for (int64_t j = 0; j <= p; ++j) colptr[(size_t)j] = (int32_t)(j * n);
-    for (int64_t j = 0; j < p; ++j)
-      for (int64_t i = 0; i < n; ++i) rowidx[(size_t)(j * n + i)] = (int32_t)i;
-    sgdnet_csc csc{};
-    csc.n_rows = n;
-    csc.n_cols = p;
-    csc.colptr = colptr.data();
-    csc.rowidx = rowidx.data();
-    csc.values = x;
-    return sgdnet_fit_sparse(&csc, y, y_cols, ctl, out);
-  }
   Features X;
   X.sparse = false;
   X.n = n;

@@ -1190,7 +1190,7 @@ __global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaD
   double bk[KMAX], gct[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
-    bk[k] = k < K ? (kVS ? d.vb[vsh] : d.b[k]) : 0.0;
+    bk[k] = k < K ? (kVS ? d.vb[vsh * K + k] : d.b[k]) : 0.0;
     gct[k] = 0.0;
   }
   for (int i = lo + wave; i < hi; i += kThreads / 64) {
@@ -1313,14 +1313,17 @@ __global__ __launch_bounds__(kThreads) void saga_batch_gather_dense_kernel(SagaD
     double* slab = d.slab + (int64_t)blockIdx.x * KP;
     for (int64_t i = threadIdx.x; i < KP; i += kThreads) slab[i] = Dl[i];
   }
-  if (kVS) {                                    // one partial per workgroup, summed per shard by the sweep
-    __shared__ double vpart[kThreads / 64];
-    if (lane == 0) vpart[wave] = gct[0];
+  if (kVS) {                                    // one partial per workgroup and class, summed per shard by the sweep
+    __shared__ double vpart[kThreads / 64][KMAX];
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) vpart[wave][k] = gct[k];
+    }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < K) {
       double tot = 0.0;
-      for (int wv = 0; wv < kThreads / 64; ++wv) tot += vpart[wv];
-      d.vd0[blockIdx.x] = tot;
+      for (int wv = 0; wv < kThreads / 64; ++wv) tot += vpart[wv][threadIdx.x];
+      d.vd0[(int64_t)blockIdx.x * K + threadIdx.x] = tot;
     }
   } else if (d.fit_intercept) {
     store_d0_partial<KMAX, kThreads>(d, K, batch_id, gct);
@@ -1344,7 +1347,11 @@ __global__ __launch_bounds__(kDenseBlock) void saga_dense_tiled_accumulate_kerne
                                                                                   int64_t t0_in_epoch, int m,
                                                                                   int draws_per_chunk) {
   __shared__ double part[kDenseBlock / 64 - 1][KMAX][kTileF];
-  const int K = KMAX == 1 ? 1 : d.K;
+  // more than KMAX classes (round 4, 17..64): blockIdx.z takes KMAX of them at a time; KS = the stride of a draw's
+  // (and a feature's) class vector, K = the classes of this chunk
+  const int KS = KMAX == 1 ? 1 : d.K;
+  const int k0 = (int)blockIdx.z * KMAX;
+  const int K = KS - k0 < KMAX ? KS - k0 : KMAX;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   constexpr int kWaves = kDenseBlock / 64;
@@ -1365,7 +1372,7 @@ __global__ __launch_bounds__(kDenseBlock) void saga_dense_tiled_accumulate_kerne
       on[u] = false;
       xv[u] = 0.0;
       if (i < hi) {
-        const double* gci = d.gcb + (int64_t)i * K;
+        const double* gci = d.gcb + (int64_t)i * KS + k0;
         bool any = false;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) any = any || (k < K && gci[k] != 0.0);
@@ -1376,7 +1383,7 @@ __global__ __launch_bounds__(kDenseBlock) void saga_dense_tiled_accumulate_kerne
 #pragma unroll
     for (int u = 0; u < kTileU; ++u) {
       if (on[u]) {
-        const double* gci = d.gcb + (int64_t)(i0 + u * kWaves) * K;
+        const double* gci = d.gcb + (int64_t)(i0 + u * kWaves) * KS + k0;
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
           if (k < K) acc[k] += xv[u] * gci[k];
@@ -1395,8 +1402,93 @@ __global__ __launch_bounds__(kDenseBlock) void saga_dense_tiled_accumulate_kerne
         double tot = acc[k];
 #pragma unroll
         for (int wv = 0; wv < kWaves - 1; ++wv) tot += part[wv][k][lane];
-        if (tot != 0.0) scatter_add<false>(d.D + j * K + k, tot);
+        if (tot != 0.0) scatter_add<false>(d.D + j * KS + k0 + k, tot);
       }
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// Dense x with 17..64 classes (round 4; src/saga-dense.h:149-185 in batched form): the class-lane form.  A wavefront
+// per draw, lane k = class k: the row arrives 64 features per load (coalesced), feature j's value is handed to all
+// lanes through v_readlane and meets row j of w -- K contiguous doubles, one or a few 128-B lines from L2 -- so x.w
+// needs no reduction across lanes and only the softmax does.  The kernel stops after the gradient, like the tiled
+// form of fewer classes: the gradient change of draw i goes to d.gcb[i * K + k] (zero for a repeated sample),
+// saga_dense_tiled_accumulate_kernel<16> forms D = X_batch^T gc sixteen classes at a time (blockIdx.z) and
+// saga_dense_cl_sweep_kernel updates a feature's K coefficients per wavefront.
+// Algorithmic bytes per draw: 8 p (row, twice: the accumulate pass reads it again) + 8 K p (w, from L2) + 24 K.
+// --------------------------------------------------------------------------
+__device__ __forceinline__ double lane_value(double v, int src) {   // src is wave-uniform
+  const long long q = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(q & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(q >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__global__ __launch_bounds__(kDenseBlock) void saga_dense_cl_gather_kernel(SagaDev d, const LamParams* lamp,
+                                                                           int64_t t0_in_epoch, int m,
+                                                                           int batch_id_offset, int draws_per_block) {
+  __shared__ double part[kDenseBlock / 64][64];
+  const int K = d.K;
+  const int64_t p = d.p;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool lane_on = lane < K;
+  const int kl = lane_on ? lane : 0;                       // idle lanes read class 0 (addresses stay inside the arrays)
+  const int64_t t0 = lamp->stream_base + t0_in_epoch;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  const int lo = (int)blockIdx.x * draws_per_block;
+  const int hi = (lo + draws_per_block < m) ? lo + draws_per_block : m;
+  const double bk = d.b[kl];
+  double gct = 0.0;
+  for (int i = lo + wave; i < hi; i += kDenseBlock / 64) {
+    const uint32_t s = d.stream[t0 + i];
+    const double* xs = d.xd + (int64_t)s * p;
+    int prev = batch_id;
+    if (lane == 0) prev = __hip_atomic_exchange(d.claim + s, batch_id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mold = d.M[kl + (int64_t)s * K];
+    double acc = 0.0;
+    for (int64_t j0 = 0; j0 < p; j0 += 64) {
+      const double xv = j0 + lane < p ? xs[j0 + lane] : 0.0;
+      const int cnt = p - j0 < 64 ? (int)(p - j0) : 64;
+      const double* wr = d.w + j0 * K + kl;
+      for (int e0 = 0; e0 < cnt; e0 += 8) {                // eight rows of w requested before the first is used
+        double wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = e0 + u < cnt ? wr[(int64_t)(e0 + u) * K] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (e0 + u < cnt) acc += lane_value(xv, e0 + u) * wv[u];
+      }
+    }
+    const double lp = acc + bk;
+    double g;
+    if (d.family == SGDNET_MULTINOMIAL) {
+      const double mx = wave_max(lane_on ? lp : -HUGE_VAL);
+      const double ssum = wave_sum(lane_on ? exp(lp - mx) : 0.0);
+      const double lse = log(ssum) + mx;
+      g = exp(lp - lse);
+      if ((unsigned)lane == (unsigned)(d.y[(int64_t)s * d.Ky] + 0.5)) g -= 1.0;
+    } else {                                               // mgaussian: Ky == K responses
+      g = lp - d.y[(int64_t)s * d.Ky + kl];
+    }
+    const bool first = __shfl(prev != batch_id ? 1 : 0, 0, 64) != 0;
+    double gc = 0.0;
+    if (first && lane_on) {
+      gc = g - mold;
+      d.M[lane + (int64_t)s * K] = g;
+    }
+    if (lane_on) d.gcb[(int64_t)i * K + lane] = gc;
+    gct += gc;
+  }
+  if (d.fit_intercept) {                                   // one partial per workgroup and class, summed by the sweep
+    part[wave][lane] = gct;
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+      double tot = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < kDenseBlock / 64; ++wv) tot += part[wv][threadIdx.x];
+      d0_publish(d, batch_id, threadIdx.x, tot);
     }
   }
 }
@@ -1699,6 +1791,43 @@ __global__ __launch_bounds__(kBlock) void saga_batch_sweep_kernel(SagaDev d, Lam
   if (blockIdx.x == 0) {
     if (d.fit_intercept) sweep_intercept(d, q, sh_d0);
     double* nxt = d0_set(d, batch_id + 1);      // the next gather may add into it atomically
+    for (int i = threadIdx.x; i < kD0Slots * K; i += kBlock) nxt[i] = 0.0;
+  }
+}
+
+// Dense class-lane form (17..64 classes, saga_dense_cl_gather_kernel): a wavefront per feature, lane k = class k --
+// D_j, w_j and G_j are K contiguous doubles each, the group norm is a wavefront sum.  Dense x is standardised
+// explicitly, so there is no implicit centring here.
+__global__ __launch_bounds__(kBlock) void saga_dense_cl_sweep_kernel(SagaDev d, LamParams* lamp, int tail, int n_parts,
+                                                                     int batch_id_offset) {
+  __shared__ double sh_d0[64];
+  const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
+  const int K = d.K;
+  const int batch_id = lamp->batch_seq + batch_id_offset;
+  if (blockIdx.x == 0 && d.fit_intercept) block_d0<kBlock>(d, n_parts, batch_id, sh_d0);
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  const bool on = j < d.p && lane < K;
+  const int64_t t = on ? j * K + lane : 0;
+  const double raw = on ? d.D[t] : 0.0, w_old = on ? d.w[t] : 0.0, g_old = on ? d.G[t] : 0.0;
+  double v = on ? q.r_m * w_old - q.gamma * q.ls_m * g_old - q.gamma * raw : 0.0;
+  const double tau = q.beta * q.gamma * q.ls_m;
+  if (q.penalty == SGDNET_GROUPLASSO) {                    // penalties.h:61-79
+    const double factor = tau / sqrt(wave_sum(v * v));
+    v = factor < 1.0 ? v * (1.0 - factor) : 0.0;
+  } else if (q.penalty == SGDNET_ELASTICNET) {
+    v = soft_threshold(v, tau);
+  }
+  if (on) {
+    d.w[t] = v;
+    if (raw != 0.0) {
+      d.G[t] = g_old + raw / q.n_d;
+      d.D[t] = 0.0;
+    }
+  }
+  if (blockIdx.x == 0) {
+    if (d.fit_intercept) sweep_intercept(d, q, sh_d0);
+    double* nxt = d0_set(d, batch_id + 1);                 // the next gather may add into it atomically
     for (int i = threadIdx.x; i < kD0Slots * K; i += kBlock) nxt[i] = 0.0;
   }
 }
@@ -3254,7 +3383,7 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     g.dense = true;
     g.lds = d.slab != nullptr && fits;
     const int waves = kDenseBlock / 64;
-    if (!fits && d.gcb && d.K <= 16) {
+    if (d.gcb && d.K <= 64 && (!fits || d.K > 16)) {     // 17..64 classes: always (the class-lane gather, round 4)
       g.tiled = true;
       int dpb = (m + 8191) / 8192;               // a row is >= 5 KB here: one or a few draws per wavefront
       dpb = (dpb + waves - 1) / waves * waves;
@@ -3366,9 +3495,20 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
                         int batch_id_offset, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
   (void)tail;
   const GatherPlan g = plan_gather(d, m);
-  if (d.K > 16 && !g.binned) {
-    set_error("batched mode with more than 16 classes needs the binned form (sparse x, n_classes <= 64; got %d)", d.K);
+  if (d.K > 16 && !g.binned && !g.tiled) {
+    set_error("batched mode with more than 16 classes needs the binned form (sparse x) or the class-lane form (dense x), "
+              "n_classes <= 64; got %d", d.K);
     return SGDNET_EUNSUPPORTED;
+  }
+  if (g.tiled && d.K > 16) {
+    hipExtLaunchKernelGGL(saga_dense_cl_gather_kernel, dim3(g.grid), dim3(kDenseBlock), 0, st, ev0, nullptr, 0, d, lam,
+                          t0_in_epoch, m, batch_id_offset, g.draws_per_block);
+    SGD_HIP_TRY(hipGetLastError());
+    const dim3 agrid((unsigned)((d.p + kTileF - 1) / kTileF), (unsigned)g.chunks, (unsigned)((d.K + 15) / 16));
+    hipExtLaunchKernelGGL(saga_dense_tiled_accumulate_kernel<16>, agrid, dim3(kDenseBlock), 0, st, nullptr, ev1, 0, d, lam,
+                          t0_in_epoch, m, g.draws_per_chunk);
+    SGD_HIP_TRY(hipGetLastError());
+    return SGDNET_OK;
   }
   if (g.tiled) {
     if (d.K == 1)
@@ -3527,7 +3667,11 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;
   }
-  if (g.lds) {
+  if (g.tiled && d.K > 16) {
+    const int grid = (int)((d.p + kBlock / 64 - 1) / (kBlock / 64));
+    hipExtLaunchKernelGGL(saga_dense_cl_sweep_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0, ev1, 0, d, lam,
+                          tail, n_parts, batch_id_offset);
+  } else if (g.lds) {
     const int F = kSlabElems / d.K;
     const int grid = (int)((d.p + F - 1) / F);
     hipExtLaunchKernelGGL(saga_batch_sweep_slab_kernel, dim3(grid < 1 ? 1 : grid), dim3(kBlock), 0, st, ev0,
@@ -3552,8 +3696,8 @@ bool vs_eligible(const SagaDev& d, int m) {
   (void)m;
   if (d.V < 2 || d.K < 1 || d.K > 16 || (d.standardize && !(d.vcw && d.c)) || d.force_global || !d.vw) return false;
   const size_t table = sizeof(double) * (size_t)d.K * (size_t)d.p;
-  if (d.K > 1) return !d.xd && d.rec && table <= 80 * 1024;
-  if (d.xd) return table <= 80 * 1024;                           // dense x: only the accumulator is staged
+  if (d.xd) return table <= 80 * 1024;                           // dense x (1..16 classes): only the accumulator is staged
+  if (d.K > 1) return d.rec && table <= 80 * 1024;
   return 2 * table + 16 + kLdsStaticReserve <= kLdsPerCu;     // accumulator + coefficient snapshot in LDS
 }
 
@@ -3590,21 +3734,35 @@ int launch_vs_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, int 
     return SGDNET_EINVAL;
   }
   if (d.xd) {
-    constexpr int kDenseVsBlock = 1024;           // 16 wavefronts share one LDS copy of the accumulator
-    const int waves = kDenseVsBlock / 64;
-    int dpb = (m + d.v_bps - 1) / d.v_bps;
-    dpb = (dpb + waves - 1) / waves * waves;
     static bool dense_vs_attr_done[64] = {};
     int dev = 0;
     (void)hipGetDevice(&dev);
+    constexpr int kDenseVsBlock = 1024;           // 16 wavefronts share one LDS copy of the accumulator
     if (!dense_vs_attr_done[dev & 63]) {
       SGD_HIP_TRY(hipFuncSetAttribute(
           reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<1, kDenseVsBlock, true>),
           hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<4, kDenseBlock, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_batch_gather_dense_kernel<16, kDenseBlock, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
       dense_vs_attr_done[dev & 63] = true;
     }
-    hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<1, kDenseVsBlock, true>), dim3(grid), dim3(kDenseVsBlock),
-                          sizeof(double) * (size_t)d.p, st, ev0, ev1, 0, d, lam, t0_in_epoch, m, 0, dpb);
+    const int waves = (d.K > 1 ? kDenseBlock : kDenseVsBlock) / 64;
+    int dpb = (m + d.v_bps - 1) / d.v_bps;
+    dpb = (dpb + waves - 1) / waves * waves;
+    const size_t lds = sizeof(double) * (size_t)d.K * (size_t)d.p;
+    if (d.K == 1)
+      hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<1, kDenseVsBlock, true>), dim3(grid), dim3(kDenseVsBlock), lds, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, 0, dpb);
+    // 2..16 classes (round 4): four wavefronts per workgroup (a draw holds per-class registers), the first-occurrence
+    // claims of a sample are per batch (batch_id_offset = the batch's index in the epoch)
+    else if (d.K <= 4)
+      hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<4, kDenseBlock, true>), dim3(grid), dim3(kDenseBlock), lds, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_index, dpb);
+    else
+      hipExtLaunchKernelGGL((saga_batch_gather_dense_kernel<16, kDenseBlock, true>), dim3(grid), dim3(kDenseBlock), lds, st,
+                            ev0, ev1, 0, d, lam, t0_in_epoch, m, batch_index, dpb);
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;
   }

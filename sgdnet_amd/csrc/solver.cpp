@@ -400,7 +400,9 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
 // batch's gradient changes in d.gcb and D is formed feature tile by feature tile.
 int ensure_dense_tiled(sgdnet_solver* s, int64_t batch) {
   SagaDev& d = s->d;
-  if (!d.xd || d.K > 16 || sizeof(double) * (size_t)d.K * (size_t)d.p <= 80 * 1024) return SGDNET_OK;
+  // the forms that hand the gradient changes of a batch to an accumulate pass: K x p tables beyond the LDS, and 17..64
+  // classes whatever the table (saga_dense_cl_gather_kernel)
+  if (!d.xd || d.K > 64 || (d.K <= 16 && sizeof(double) * (size_t)d.K * (size_t)d.p <= 80 * 1024)) return SGDNET_OK;
   if (batch > s->bin_batch || !s->bin_bufs[1]) {
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     if (s->bin_bufs[1]) (void)hipFree(s->bin_bufs[1]);
@@ -698,13 +700,8 @@ int check_batched_ok(const sgdnet_solver* s) {
     return SGDNET_EUNSUPPORTED;
   }
   if (!s->sparse) {
-    // dense x: one LDS copy of the K x p accumulator per workgroup (saga_batch_gather_dense_kernel), or
-    // the tiled form when that copy fits no LDS (K <= 16)
-    if ((int64_t)s->d.K * s->d.p > 10240 && s->d.K > 16) {
-      set_error("batched mode on dense x with n_classes * n_features > 10240 needs n_classes <= 16 (got %d); use exact mode",
-                s->d.K);
-      return SGDNET_EUNSUPPORTED;
-    }
+    // dense x: one LDS copy of the K x p accumulator per workgroup (saga_batch_gather_dense_kernel), the tiled form when
+    // that copy fits no LDS, the class-lane form for 17..64 classes
     return SGDNET_OK;
   }
   if (!s->d.rec) {
@@ -1394,7 +1391,8 @@ int solver_grow_bins(sgdnet_solver* s) {
 bool solver_batched_available(sgdnet_solver* s, int64_t batch) {
   if (!s) return false;
   if (s->d.K <= 16) return true;
-  if (s->d.K > 64 || !s->sparse) return false;
+  if (s->d.K > 64) return false;
+  if (!s->sparse) return true;                  // dense x: the class-lane form
   if (ensure_binned(s, batch < 1 ? 1 : batch) != SGDNET_OK) return false;
   return s->d.R > 0 && !s->bin_disabled;
 }
@@ -2290,8 +2288,8 @@ int sgdnet_solver_set_virtual_shards(sgdnet_solver* s, int n_shards) {
   d.peers = nullptr;                            // links name the buffers just freed: link again
   d.n_peers = 0;
   if (n_shards < 2) return SGDNET_OK;
-  if (d.K > 16 || (d.K > 1 && !s->sparse)) {
-    set_error("virtual shards: one response, or up to 16 classes of sparse x");
+  if (d.K > 16) {
+    set_error("virtual shards: up to 16 classes");
     return SGDNET_EUNSUPPORTED;
   }
   const int64_t KP = (int64_t)d.K * d.p;

@@ -170,6 +170,29 @@ def test_dense_tiled_form_matches_batched_oracle(sa, oracle, family, K, penalty,
     S.close()
 
 
+@pytest.mark.parametrize("family,K,penalty,p,n,batch", [
+    ("multinomial", 17, "elasticnet", 30, 900, 64), ("mgaussian", 40, "grouplasso", 130, 800, 800),
+    ("multinomial", 64, "ridge", 65, 1200, 500), ("multinomial", 33, "elasticnet", 700, 600, 90),
+    ("mgaussian", 20, "elasticnet", 1, 500, 33)])
+def test_dense_class_lane_form_matches_batched_oracle(sa, oracle, family, K, penalty, p, n, batch):
+    # dense x with 17..64 classes (round 4): a wavefront per draw with lane k = class k, D = X_batch^T gc by feature
+    # tiles sixteen classes at a time, a wavefront per feature in the sweep -- the oracle's batched iteration, repeats
+    # within a batch included, with a table that would fit the LDS (K p <= 10 240) and one that would not
+    x, y = make_problem(family, K, n, p, None, seed=17, dense=True)
+    stream = oracle.Rng(8).stream(n, n * 2)
+    kw = dict(family=family, penalty=penalty, gamma=0.3 / max(p, 4), alpha=1e-3, beta=0.0 if penalty == "ridge" else 2e-3)
+    st = oracle.new_state(K, p, n)
+    oracle.saga(sp.csc_matrix(x), y, st, max_iter=2, tol=0.0, stream=stream, batch=batch, dense_intercept=True, **kw)
+    S = sa.SagaSolver(x, y, family=family, n_classes=K)
+    S.set_penalty(penalty, kw["gamma"], kw["alpha"], kw["beta"])
+    S.upload_stream(stream)
+    ep, _ = S.run(mode="batched", batch=batch, max_epochs=2, tol=0.0)
+    assert ep == 2
+    for k in STATE:
+        assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
+    S.close()
+
+
 def test_wide_dense_fit_in_batched_mode_satisfies_the_kkt_conditions(sa):
     # p > 10 240 through sgdnet(): round 1 fell back to the exact iteration here (0.8 ms per draw at this
     # width).  The CPU oracle needs minutes for this shape, so the optimum is checked by its optimality
@@ -953,8 +976,8 @@ def test_extreme_shapes_batched_and_exact(sa, oracle, family, K, n, p, dens, bat
 
 def test_more_than_sixteen_classes(sa, oracle):
     """17..64 classes: sparse x runs the binned form with a wavefront per draw (per-epoch parity with the
-    batched oracle, then the fit driver against the exact optimum); dense x goes the same way with every
-    entry stored; K > 64 keeps the exact iteration behind mode = "batched"."""
+    batched oracle, then the fit driver against the exact optimum); dense x runs the class-lane form (round 4;
+    until then: the binned form with every entry stored); K > 64 keeps the exact iteration behind mode = "batched"."""
     # kernels: K = 18 and K = 40, elastic net and group lasso, tail batch, small p (the table would fit LDS)
     for family, K, penalty in (("multinomial", 18, "elasticnet"), ("mgaussian", 40, "grouplasso")):
         x, y = make_problem(family, K, 3000, 50, 0.2, seed=12)
@@ -974,14 +997,16 @@ def test_more_than_sixteen_classes(sa, oracle):
     assert fit.return_codes[0] == 0
     for k in range(K):
         assert np.abs(fit.beta[k][:, 0] - ref["beta"][k, :, 0]).max() < 1e-7
-    # dense x with 17..64 classes in batched mode: handed to the sparse binned form with every entry stored
-    # (round 1 and most of round 2: the exact iteration) -- same optimum, also with standardisation
+    # dense x with 17..64 classes in batched mode: the class-lane form of the dense kernels (saga_dense_cl_gather_kernel;
+    # rounds 2-3: the sparse binned form with every entry stored) -- same optimum, also with standardisation
     for std in (False, True):
         kw["standardize"] = std
         Xd = np.asarray(X.todense()) + (0.3 if std else 0.0)
         ref = oracle.fit(Xd, y, seed=2, thresh=1e-10, **{k_: v for k_, v in kw.items() if k_ != "thresh"})
         fit = sa.sgdnet(Xd, y, seed=2, mode="batched", batch=64, thresh=1e-10, **{k_: v for k_, v in kw.items() if k_ != "thresh"})
-        assert fit.return_codes[0] == 0 and fit.npasses != ref["npasses"]
+        assert fit.return_codes[0] == 0
+        # (the batched kernels ran, not the exact iteration behind them: that one reproduces the oracle's bits)
+        assert any(np.abs(fit.beta[k][:, 0] - ref["beta"][k, :, 0]).max() > 0 for k in range(K))
         for k in range(K):
             assert np.abs(fit.beta[k][:, 0] - ref["beta"][k, :, 0]).max() < 1e-7, (std, k)
         a0 = ref["a0"][:, 0] - ref["a0"][:, 0].mean()              # R/sgdnet.R:409-410 centres the class intercepts
@@ -1160,6 +1185,31 @@ def _virtual_shards_case(sa, oracle, V, n, p, batch, family, dense, c=None):
     ep, _ = S.run(mode="batched", batch=batch, draws_per_epoch=draws, max_epochs=epochs, tol=0.0)
     assert ep == epochs
     st = _oracle_virtual_shards(oracle, x, y, V, batch, stream, epochs, kw)
+    for k in STATE:
+        assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
+    S.set_virtual_shards(0)
+    S.close()
+
+
+@pytest.mark.parametrize("V,n,p,batch,family,K,penalty", [
+    (2, 3000, 40, 50, "multinomial", 3, "elasticnet"), (4, 6002, 70, 90, "mgaussian", 2, "grouplasso"),
+    (8, 8003, 33, 100, "multinomial", 10, "ridge"), (2, 3001, 25, 3001, "mgaussian", 16, "elasticnet")])
+def test_virtual_shards_on_dense_x_with_several_classes(sa, oracle, V, n, p, batch, family, K, penalty):
+    """Round 4: the dense batched gather carries virtual shards for 2..16 classes too (K-vector replicas, per-class
+    intercept partials, first-occurrence claims per batch): the oracle's batch halves through the same shards, streams
+    and merge points, saga-dense.h's intercept step."""
+    x, y = make_problem(family, K, n, p, 0.5, seed=37)
+    kw = dict(family=family, penalty=penalty, gamma=0.003, alpha=1e-4, beta=0.0 if penalty == "ridge" else 1e-4,
+              dense_intercept=True)
+    epochs = 3
+    S = sa.SagaSolver(np.asfortranarray(x.toarray()), y, family=family, n_classes=K)
+    S.set_penalty(penalty, kw["gamma"], kw["alpha"], kw["beta"])
+    S.set_virtual_shards(V)
+    stream = S.sharded_stream([sa.RRng(80 + v) for v in range(V)], epochs)
+    S.upload_stream(stream)
+    ep, _ = S.run(mode="batched", batch=batch, draws_per_epoch=V * (n // V), max_epochs=epochs, tol=0.0)
+    assert ep == epochs
+    st = _oracle_virtual_shards(oracle, x, y, V, min(batch, n // V), stream, epochs, dict(kw, K=K))
     for k in STATE:
         assert relerr(S.get(k), st[k]) < TOL_BATCHED, k
     S.set_virtual_shards(0)
