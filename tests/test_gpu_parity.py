@@ -491,9 +491,17 @@ def test_unsupported_and_stream_errors(sa):
         S.run(mode="exact", max_epochs=1)          # 200 draws needed, 100 resident
     assert e.value.code == -6
     S.close()
-    # dense x with more than 16 classes whose K x p accumulator exceeds a workgroup's LDS copy has no batched path
+    # more than 64 classes have no batched path (round 4: dense x with 17..64 classes has one, the class-lane form --
+    # it used to be refused when its K x p accumulator exceeded a workgroup's LDS copy)
     x, y = make_problem("mgaussian", 18, 64, 600, None, seed=1, dense=True)
     S = sa.SagaSolver(x, y, family="mgaussian", n_classes=18)
+    S.set_penalty("ridge", 1e-5, 1e-3, 0.0)
+    S.upload_stream(np.zeros(64, dtype=np.uint32))
+    ep, _ = S.run(mode="batched", batch=8, max_epochs=1, tol=0.0)
+    assert ep == 1 and np.isfinite(S.get("w")).all()
+    S.close()
+    x, y = make_problem("mgaussian", 65, 64, 20, None, seed=1, dense=True)
+    S = sa.SagaSolver(x, y, family="mgaussian", n_classes=65)
     S.set_penalty("ridge", 1e-5, 1e-3, 0.0)
     S.upload_stream(np.zeros(64, dtype=np.uint32))
     with pytest.raises(SgdnetError) as e:
