@@ -3053,7 +3053,9 @@ __device__ __forceinline__ double shfl_d(double v, int src) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
-template <int kGrp>
+// kMulti: the multinomial family alone (config 5's) -- the other families' code and their pointers leave the draw loop,
+// which sits at the 128-register limit of a 1024-thread workgroup (round 4: two scratch reloads per draw otherwise)
+template <int kGrp, bool kMulti = false>
 __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d, const LamParams* lamp,
                                                                        int64_t t0_in_epoch, int m,
                                                                        int batch_id_offset) {
@@ -3122,6 +3124,11 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   for (int pass = 0; pass < passes; ++pass, i += kG) {
     const uint32_t s_nn = (i + 2 * kG < hi) ? d.stream[t0 + i + 2 * kG] : 0u;
     const BinDraw nxt = bin_fetch(d, i + kG, s_nxt, i + kG < hi, gl, batch_id);
+    // the class index of this lane, opaque to the compiler inside the loop: it otherwise keeps (array + 8 gl) of every
+    // K-fastest array in a register pair across the loop, and the loop is at the 128-register limit (spills reloaded
+    // per draw behind s_waitcnt vmcnt(0), i.e. behind the prefetched record)
+    int glo = gl;
+    asm volatile("" : "+v"(glo));
     // ---- the current draw ----
     const bool have = cur.i >= 0;
     const int cap = d.rec_cap;
@@ -3132,7 +3139,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
     // x . w: the feature ids sit in the group's registers, so the K-contiguous reads of w are all
     // requested before the first one is used
     const unsigned r0 = range_of(cur.j0);
-    const double mold = (have && lane_on) ? d.M[gl + (int64_t)cur.s * K] : 0.0;
+    const double mold = (have && lane_on) ? d.M[glo + (int64_t)cur.s * K] : 0.0;
     double acc = 0.0;
 #pragma unroll
     for (int e0 = 0; e0 < kGrp; e0 += kBinW) {
@@ -3144,7 +3151,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
         // (timing only, -DSGDNET_EXPERIMENTS: every coefficient row from a 1 MB window -- an upper bound of what
         //  feature ranges held in one XCD's L2 could buy: profiles/r04_c5_xcd_bound.txt)
         if (SGD_ABLATE(d, 32)) j &= 8191;
-        wv[e] = (have && e0 + e < creg && lane_on) ? d.wpad[(int64_t)j * KS + gl] : 0.0;
+        wv[e] = (have && e0 + e < creg && lane_on) ? d.wpad[(int64_t)j * KS + glo] : 0.0;
       }
 #pragma unroll
       for (int e = 0; e < kBinW; ++e) acc += shfl_d<kGrp>(cur.v0, e0 + e) * wv[e];
@@ -3160,32 +3167,34 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
       for (int e = 0; e < kGrp; ++e) {
         const int j = __shfl(j1, e, kGrp);
         const double v = shfl_d<kGrp>(v1, e);
-        if (have && kGrp + e < creg && lane_on) acc += v * d.wpad[(int64_t)j * KS + gl];
+        if (have && kGrp + e < creg && lane_on) acc += v * d.wpad[(int64_t)j * KS + glo];
       }
     }
     if (rest)
       row_rest_uniform<kGrp>(d, base, cur.nnz, cur.ovf, [&](uint32_t j, double v) {
-        if (lane_on) acc += v * d.wpad[(int64_t)j * KS + gl];
+        if (lane_on) acc += v * d.wpad[(int64_t)j * KS + glo];
       });
     const double lp = acc + bl;
     double g;
-    if (d.family == SGDNET_MULTINOMIAL) {
+    if (kMulti || d.family == SGDNET_MULTINOMIAL) {
+      // softmax as exp(lp - max) / sum: the same number as families.h:235-260's exp(lp - logsumexp) up to rounding
+      // (batched parity is a 1e-9 tolerance), one exp and no log per class lane, and none of the log's sixteen
+      // constant registers in a loop that sits at the register limit
       const double mx = grp_max<kGrp>(lane_on ? lp : -HUGE_VAL);
-      const double ssum = grp_sum<kGrp>(lane_on ? exp(lp - mx) : 0.0);
-      const double lse = log(ssum) + mx;
-      g = exp(lp - lse);
+      const double ex = lane_on ? exp(lp - mx) : 0.0;
+      g = ex / grp_sum<kGrp>(ex);
       if ((unsigned)gl == (unsigned)(cur.y0 + 0.5)) g -= 1.0;
     } else if (d.family == SGDNET_BINOMIAL) {
       g = 1.0 - cur.y0 - 1.0 / (1.0 + exp(lp));
     } else {
-      g = lp - ((have && lane_on) ? d.y[(int64_t)cur.s * d.Ky + gl] : 0.0);
+      g = lp - ((have && lane_on) ? d.y[(int64_t)cur.s * d.Ky + glo] : 0.0);
     }
     // a repeat inside the batch sees the same snapshot: gradient change 0, nothing to stage
     const bool first = have && (__shfl(cur.prev != batch_id ? 1 : 0, 0, kGrp) != 0);
     if (first && lane_on) {
       const double gc = g - mold;
-      d.M[gl + (int64_t)cur.s * K] = g;
-      d.gcb[(int64_t)cur.i * KS + gl] = gc;
+      d.M[glo + (int64_t)cur.s * K] = g;
+      d.gcb[(int64_t)cur.i * KS + glo] = gc;
       gct += gc;
     }
     stage(first && gl < creg, cur.i, (uint32_t)cur.j0, cur.v0, r0);
@@ -3222,24 +3231,28 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   __syncthreads();
   PHASE(4);
   const unsigned staged = n_ent < (unsigned)kBinEntCap ? n_ent : (unsigned)kBinEntCap;
+  static_assert(sizeof(BinEntry) == sizeof(uint4), "an entry moves as one 16-byte vector");
   for (unsigned e = threadIdx.x; e < staged; e += kBinBlock) {
-    BinEntry en = ent[e];
-    const unsigned r = en.t >> 20;
-    en.t &= 0xfffffu;
+    const uint4 en = reinterpret_cast<const uint4*>(ent)[e];  // (a modified struct copy went through scratch memory here)
+    const unsigned r = en.x >> 20;
     const unsigned at = rbase[r];
     const unsigned k = atomicAdd(cnt + r, 1u);
-    if (at != 0xffffffffu) reinterpret_cast<BinEntry*>(d.bins)[(size_t)at + k] = en;
+    if (at != 0xffffffffu) reinterpret_cast<uint4*>(d.bins)[(size_t)at + k] = make_uint4(en.x & 0xfffffu, en.y, en.z, en.w);
   }
   if ((d.fit_intercept || d.standardize) && (int)threadIdx.x < K)
     d0_publish(d, batch_id, threadIdx.x, d0s[threadIdx.x]);
   PHASE(5);
 }
 
-template <int kGrp>
+// kGrouped: the group-lasso update (a feature's K coefficients in one thread's registers); false: ridge / elastic net
+// per element -- that instantiation (config 5's) keeps nothing in scratch memory: a kernel that declares a private
+// segment pays for its set-up at every dispatch, and this one is launched 382 times per epoch
+template <int kGrp, bool kGrouped>
 __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev d, LamParams* lamp, int tail,
                                                                         int n_parts, int batch_id_offset) {
   extern __shared__ __attribute__((aligned(16))) double Dl[];
   __shared__ double sh_d0[kGrp];
+  __shared__ double sh_cw[kGrp];
   const SweepParams q = load_sweep_params(d, lamp, tail, SweepOverride{0.0, 0.0, 0.0});
   const int K = d.K;
   const int r = blockIdx.x;
@@ -3304,9 +3317,9 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
   PHASE(9);
   if (threadIdx.x == 0) d.bin_count[r] = 0u;                 // the next batch fills the bin again
   // ---- per-feature update of this range ----
-  double cwp[kGrp];
-  for (int k = 0; k < K; ++k) cwp[k] = 0.0;
-  if (q.penalty == SGDNET_GROUPLASSO) {
+  if (kGrouped) {
+    double cwp[kGrp];
+    for (int k = 0; k < K; ++k) cwp[k] = 0.0;
     for (int f = threadIdx.x; f < hi - lo; f += kRangeBlock) {
       const int64_t j = lo + f;
       double dj[kGrp], wn[kGrp];
@@ -3317,8 +3330,13 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
       if (d.wpad != d.w)
         for (int k = 0; k < K; ++k) d.wpad[j * d.KS + k] = wn[k];
     }
+    if (d.standardize) cw_accumulate<kRangeBlock>(d, batch_id, cwp);
   } else {
     const double tau = q.beta * q.gamma * q.ls_m, gls = q.gamma * q.ls_m;
+    if (d.standardize) {                        // c . w_new of this range, class by class, through the LDS
+      if ((int)threadIdx.x < kGrp) sh_cw[threadIdx.x] = 0.0;
+      __syncthreads();
+    }
     for (int i = threadIdx.x; i < E; i += kRangeBlock) {
       const int f = i / K, k = i - f * K;
       const int64_t t = (int64_t)lo * K + i;
@@ -3329,11 +3347,18 @@ __global__ __launch_bounds__(kRangeBlock) void saga_binned_sweep_kernel(SagaDev 
       d.w[t] = v;
       if (d.wpad != d.w) d.wpad[(int64_t)(lo + f) * d.KS + k] = v;
       if (dk != 0.0) d.G[t] += dk / q.n_d;
-      if (d.standardize)
-        for (int kk = 0; kk < K; ++kk) cwp[kk] += kk == k ? cj * v : 0.0;
+      if (d.standardize && cj * v != 0.0)
+        __hip_atomic_fetch_add(&sh_cw[k], cj * v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (d.standardize) {                        // (as cw_accumulate: into the next batch's c.w slots)
+      __syncthreads();
+      if ((int)threadIdx.x < K) {
+        const double tot = sh_cw[threadIdx.x];
+        double* set = d.cw + (size_t)((batch_id + 1) & 1) * kCwSlots * K;
+        if (tot != 0.0) atomic_add_f64(set + (blockIdx.x % kCwSlots) * K + threadIdx.x, tot);
+      }
     }
   }
-  if (d.standardize) cw_accumulate<kRangeBlock>(d, batch_id, cwp);
   PHASE(10);
 }
 
@@ -3573,15 +3598,24 @@ int launch_batch_gather(const SagaDev& d, LamParams* lam, int64_t t0_in_epoch, i
     if (!battr_done_dev[cur & 63]) {
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_gather_kernel<16>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_gather_kernel<16, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
       SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_gather_kernel<64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsPerCu - kLdsStaticReserve));
-      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<16>),
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<16, false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRangeLdsBytes));
-      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<64>),
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<16, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRangeLdsBytes));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<64, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRangeLdsBytes));
+      SGD_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(saga_binned_sweep_kernel<64, true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRangeLdsBytes));
       battr_done_dev[cur & 63] = true;
     }
-    if (d.K <= 16)
+    if (d.K <= 16 && d.family == SGDNET_MULTINOMIAL)
+      hipExtLaunchKernelGGL((saga_binned_gather_kernel<16, true>), dim3(g.grid), dim3(kBinBlock), g.lds_bytes, st, ev0, ev1, 0,
+                            d, lam, t0_in_epoch, m, batch_id_offset);
+    else if (d.K <= 16)
       hipExtLaunchKernelGGL(saga_binned_gather_kernel<16>, dim3(g.grid), dim3(kBinBlock), g.lds_bytes, st, ev0, ev1, 0,
                             d, lam, t0_in_epoch, m, batch_id_offset);
     else
@@ -3656,13 +3690,19 @@ int launch_batch_sweep(const SagaDev& d, LamParams* lam, int penalty, int tail, 
   const int n_parts = ov_m > 0.0 ? kD0Slots : (g.grid < kD0Slots ? g.grid : kD0Slots);
   const SweepOverride ov{ov_r, ov_ls, ov_m};
   if (g.binned) {
-    if (d.K <= 16)
-      hipExtLaunchKernelGGL(saga_binned_sweep_kernel<16>, dim3(d.R + 1), dim3(kRangeBlock),
-                            sizeof(double) * (size_t)d.K * (size_t)d.range_max, st, ev0, ev1, 0, d, lam, tail, n_parts,
+    const size_t lds = sizeof(double) * (size_t)d.K * (size_t)d.range_max;
+    const dim3 grid(d.R + 1), block(kRangeBlock);
+    if (d.K <= 16 && penalty != SGDNET_GROUPLASSO)
+      hipExtLaunchKernelGGL((saga_binned_sweep_kernel<16, false>), grid, block, lds, st, ev0, ev1, 0, d, lam, tail, n_parts,
+                            batch_id_offset);
+    else if (d.K <= 16)
+      hipExtLaunchKernelGGL((saga_binned_sweep_kernel<16, true>), grid, block, lds, st, ev0, ev1, 0, d, lam, tail, n_parts,
+                            batch_id_offset);
+    else if (penalty != SGDNET_GROUPLASSO)
+      hipExtLaunchKernelGGL((saga_binned_sweep_kernel<64, false>), grid, block, lds, st, ev0, ev1, 0, d, lam, tail, n_parts,
                             batch_id_offset);
     else
-      hipExtLaunchKernelGGL(saga_binned_sweep_kernel<64>, dim3(d.R + 1), dim3(kRangeBlock),
-                            sizeof(double) * (size_t)d.K * (size_t)d.range_max, st, ev0, ev1, 0, d, lam, tail, n_parts,
+      hipExtLaunchKernelGGL((saga_binned_sweep_kernel<64, true>), grid, block, lds, st, ev0, ev1, 0, d, lam, tail, n_parts,
                             batch_id_offset);
     SGD_HIP_TRY(hipGetLastError());
     return SGDNET_OK;

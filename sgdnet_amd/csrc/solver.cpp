@@ -290,7 +290,10 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     SGD_HIP_TRY(hipStreamSynchronize(s->st));
     const int64_t fmax = (int64_t)binned_max_range_features(d.K);
     static const int target_env = exp_env_int("SGDNET_BIN_RANGES", 0);
-    const int target = target_env > 0 ? target_env : 512;   // range sweep workgroups (3 of 512 threads fit a CU)
+    // range sweep workgroups: two of them fit a CU beside each other (64 KB of LDS each at the widest range), and the
+    // launch carries one more workgroup for the intercept -- 2 x 256 - 12 ranges keep the whole launch resident in one
+    // wave (round 4: the rule's rounding made 513 ranges + 1 of 512, the last two workgroups ran after everybody else)
+    const int target = target_env > 0 ? target_env : 500;
     const double per = std::max(1.0, (double)s->nnz / target);
     std::vector<int32_t> lo{0};
     {
