@@ -3062,6 +3062,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   extern __shared__ __attribute__((aligned(16))) char bsm[];
   __shared__ double d0s[kGrp];
   __shared__ unsigned n_ent;
+  __shared__ int n_next;                                 // the next draw of this workgroup nobody has taken yet
   BinEntry* ent = reinterpret_cast<BinEntry*>(bsm);
   unsigned* cnt = reinterpret_cast<unsigned*>(bsm + sizeof(BinEntry) * kBinEntCap);
   unsigned* rbase = cnt + d.R;
@@ -3078,7 +3079,10 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   for (int r = threadIdx.x; r < d.R; r += kBinBlock) cnt[r] = 0u;
   for (int r = threadIdx.x; r <= d.R; r += kBinBlock) rlo[r] = d.range_lo[r];
   if (threadIdx.x < kGrp) d0s[threadIdx.x] = 0.0;
-  if (threadIdx.x == 0) n_ent = 0u;
+  if (threadIdx.x == 0) {
+    n_ent = 0u;
+    n_next = (int)blockIdx.x * kBinDraws;
+  }
   __syncthreads();
   const double bl = lane_on ? d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0) : 0.0;
   if (d.standardize) cw_clear_next(d, batch_id);
@@ -3113,17 +3117,29 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   };
 
   PHASE(1);
-  constexpr int kG = kBinBlock / kGrp;
+  // Draws are handed out wavefront by wavefront (round 4): a wavefront takes the next 64 / kGrp draws of the workgroup
+  // from an LDS counter, two takes ahead of the one it works on (sample id and record stay requested a pass ahead).
+  // Rows differ in length and in how their entries stage, and with a fixed share per group the workgroup's barrier
+  // waited 10 us of a 53 us loop for its slowest wavefront.  The four groups of a wavefront stay together, so the
+  // ballots of stage() remain wave-wide.
+  constexpr int kGpw = 64 / kGrp;
   const int lo = blockIdx.x * kBinDraws;
   const int hi = (lo + kBinDraws < m) ? lo + kBinDraws : m;
+  (void)group;
+  auto take = [&]() -> int {
+    int b = 0;
+    if (lane == 0) b = atomicAdd(&n_next, kGpw);
+    return __builtin_amdgcn_readfirstlane(b) + lane / kGrp;
+  };
   double gct = 0.0;
-  int i = lo + group;
-  uint32_t s_nxt = (i + kG < hi) ? d.stream[t0 + i + kG] : 0u;
+  int i = take();
+  int i_nxt = take();
+  uint32_t s_nxt = i_nxt < hi ? d.stream[t0 + i_nxt] : 0u;
   BinDraw cur = bin_fetch(d, i, i < hi ? d.stream[t0 + i] : 0u, i < hi, gl, batch_id);
-  const int passes = (hi - lo + kG - 1) / kG;           // the same for every group: ballots stay wave-wide
-  for (int pass = 0; pass < passes; ++pass, i += kG) {
-    const uint32_t s_nn = (i + 2 * kG < hi) ? d.stream[t0 + i + 2 * kG] : 0u;
-    const BinDraw nxt = bin_fetch(d, i + kG, s_nxt, i + kG < hi, gl, batch_id);
+  while (i - lane / kGrp < hi) {                        // (the wavefront's first draw: the same for all its lanes)
+    const int i_nn = take();
+    const uint32_t s_nn = i_nn < hi ? d.stream[t0 + i_nn] : 0u;
+    const BinDraw nxt = bin_fetch(d, i_nxt, s_nxt, i_nxt < hi, gl, batch_id);
     // the class index of this lane, opaque to the compiler inside the loop: it otherwise keeps (array + 8 gl) of every
     // K-fastest array in a register pair across the loop, and the loop is at the 128-register limit (spills reloaded
     // per draw behind s_waitcnt vmcnt(0), i.e. behind the prefetched record)
@@ -3208,6 +3224,8 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
         stage(true, cur.i, j, v, range_of((int)j));
       });
     cur = nxt;
+    i = i_nxt;
+    i_nxt = i_nn;
     s_nxt = s_nn;
   }
   PHASE(2);
