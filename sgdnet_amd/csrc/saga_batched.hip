@@ -2784,6 +2784,35 @@ __global__ __launch_bounds__(kBlock) void saga_loss_kernel(SagaDev d, LamParams*
     }
   }
   double loss = 0.0;
+  if (kSparse && K > 1 && K <= kGroup) {
+    // several classes of sparse x (round 4): lane k of the group = class k, the group walks the row together -- a non-zero
+    // is ONE request for the K contiguous coefficients of its feature instead of K requests of 8 bytes, and the row is
+    // read once instead of K times (config 5: 37 -> 9 ms per deviance, a hundred of them along the path)
+    const int kl = gl < K ? gl : 0;
+    const double off = (gl < K ? d.b[kl] : 0.0) - (d.standardize ? cw[kl] : 0.0);
+    for (int64_t s = group; s < d.n; s += ngroups) {
+      const int64_t q0 = d.ptr[s], q1 = d.ptr[s + 1];
+      double acc = 0.0;
+      for (int64_t q = q0; q < q1; q += 4) {
+        double xv[4];
+        int64_t jv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          xv[u] = q + u < q1 ? d.val[q + u] : 0.0;
+          jv[u] = q + u < q1 ? (int64_t)d.idx[q + u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += xv[u] * d.w[kl + jv[u] * K];
+      }
+      if (gl < K) lp[gl] = acc + off;
+      __builtin_amdgcn_wave_barrier();
+      if (gl == 0) loss += family_loss(d.family, K, lp, d.y + s * d.Ky);
+      __builtin_amdgcn_wave_barrier();
+    }
+    loss = wave_sum(loss);
+    if ((threadIdx.x & 63) == 0 && loss != 0.0) atomic_add_f64(&lamp->loss_acc, loss);
+    return;
+  }
   for (int64_t s = group; s < d.n; s += ngroups) {
     for (int k = 0; k < K; ++k) {
       double acc = 0.0;

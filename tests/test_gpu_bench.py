@@ -32,6 +32,7 @@ def _run_bench(args, extra_env=None, timeout=600):
 def have_gpu():
     # asked of the library, not of torch: torch.cuda.is_available() is false in a process where this library opened the
     # device first; bench.py itself runs in child processes
+    import torch  # noqa: F401  (before the library: sgdnet_amd/_lib.py, loaded_before_torch -- later tests use parallel.py)
     from sgdnet_amd import _lib
     if _lib.load().sgdnet_device_count() < 1:
         pytest.fail("bench.py needs a HIP device: the backend has no CPU fallback")

@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def sa():
+    import torch  # noqa: F401  (before the library: sgdnet_amd/_lib.py, loaded_before_torch)
     import sgdnet_amd
     from sgdnet_amd import _lib
     if _lib.load().sgdnet_device_count() < 1:      # (not torch.cuda.is_available(): see tests/test_gpu_bench.py)
