@@ -51,8 +51,6 @@ def test_random_problem_matches_the_oracle(sa, oracle, seed):
     c = _case(seed)
     r = np.random.default_rng(seed)
     n, p, K, family = c["n"], c["p"], c["K"], c["family"]
-    if c["mode"] == "batched" and c["dense"] and K > 16:
-        pytest.skip("dense x with more than 16 classes has no batched kernel (sgdnet_fit_dense routes it to the sparse form)")
     dens = 1.0 if c["dense"] else float(r.choice([0.05, 0.3, 0.9]))
     X = r.standard_normal((p, n)) * (r.random((p, n)) < dens)
     if not c["dense"]:
