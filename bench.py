@@ -65,7 +65,7 @@ def self_launch(n_gpus):
     return subprocess.call(cmd, env=env)
 
 
-def main():
+def main(merge_override=None, note_override=""):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -97,6 +97,8 @@ def main():
                          "state deltas between local runs; sync = a per-batch all-reduce of the scatter accumulator (exact "
                          "single-GPU iterates)")
     args = ap.parse_args()
+    if merge_override:                                         # second pass after the peers scheme failed at run time (below)
+        args.merge = merge_override
 
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         # Called as plain `python bench.py --gpus N`: start one process per GPU ourselves.  This
@@ -130,7 +132,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
-        if backend == "nccl":
+        if dist.is_initialized():
+            pass                                               # (second pass)
+        elif backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
         else:
@@ -203,7 +207,7 @@ def main():
     S.set("intercept", b0)
     if os.environ.get("SGDNET_BENCH_ONE_GPU") == "1" and world > 1 and K == 1 and not sync_mode:
         S.set_cu_budget(256 // world - 16)                     # rehearsal: the ranks share one GPU's CUs
-    peers_note = ""
+    peers_note = note_override
     if peers_mode:
         # link the ranks' solvers (sgdnet_solver_link_ipc: hipIpc mappings of the exchange buffers); every rank must
         # succeed, else everybody takes the RCCL scheme (--merge avg) -- the line's `merge` string says which ran
@@ -309,7 +313,7 @@ def main():
                       stage_on_host=(backend != "nccl"), fused=fused)
         sj = ShardedSaga(sh, world, segs, force_merge=force_merge)
         desc = ("none" if world == 1 and not force_merge else
-                (f"(peers link failed: {peers_note}) " if peers_note else "") +
+                (f"(peers scheme not used: {peers_note}) " if peers_note else "") +
                 f"avg: locally normalised shard runs, {backend} all-reduce of the weighted state deltas every "
                 f"{segs[0]} draws per rank ({len(segs)} per epoch)" + (", stream-ordered" if fused else ""))
         return sj.epoch, sh, desc, 0
@@ -368,7 +372,31 @@ def main():
             dt = float(t[0])
         return dt
 
-    elapsed = timed_epochs(run_epoch)
+    if peers_mode:
+        # The linked epoch kernels wait for each other across GPUs with bounded spins: should the peer traffic not work on
+        # this node (it could only be rehearsed with the ranks sharing one GPU), every rank's launch gives up within
+        # seconds and raises.  Then everybody starts over with the RCCL scheme -- a line, not a crash.
+        ok = 1.0
+        try:
+            if os.environ.get("SGDNET_BENCH_TEST_PEERS_FAILURE") == str(rank):   # (tests: this rank never launches)
+                raise RuntimeError("test: no launch on this rank")
+            elapsed = timed_epochs(run_epoch)
+        except Exception as e:                                 # noqa: BLE001
+            peers_note = f"epochs failed: {type(e).__name__}: {e}"[:200]
+            note(peers_note)
+            ok = 0.0
+        flag = torch.tensor([ok], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag[0]) < 0.5:
+            try:
+                if pipe:
+                    S.rng_close()
+                S.close()
+            except Exception:                                  # noqa: BLE001
+                pass
+            return main(merge_override="avg", note_override=peers_note or "epochs failed on another rank")
+    else:
+        elapsed = timed_epochs(run_epoch)
 
     note(f"timed region done: {elapsed:.4f}s")
     # dominant kernel, HIP events around every launch of one more epoch (same stream)

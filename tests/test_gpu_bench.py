@@ -76,3 +76,15 @@ def test_bench_rccl_scheme_still_runs(have_gpu):
                       "--no-convergence", "--merge", "avg"],
                      {"SGDNET_BENCH_BACKEND": "gloo", "SGDNET_BENCH_ONE_GPU": "1"})
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["merge"].startswith("avg")
+
+
+@pytest.mark.timeout(900)
+def test_bench_falls_back_when_the_linked_epochs_fail(have_gpu):
+    # rank 1 never launches: rank 0's linked epoch kernel waits for it at the first merge, gives up after its bounded spin
+    # and raises; both ranks then start over with the all-reduce scheme and the line says why
+    out = _run_bench(["--gpus", "2", "--workload", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                      "--no-convergence"],
+                     {"SGDNET_BENCH_BACKEND": "gloo", "SGDNET_BENCH_ONE_GPU": "1", "SGDNET_BENCH_TEST_PEERS_FAILURE": "1"})
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["value"] > 0
+    merge = out["config"]["merge"]
+    assert merge.startswith("(peers scheme not used: epochs failed") and "avg:" in merge
