@@ -167,6 +167,8 @@ struct SagaDev {
   const int64_t* bin_off;      // R + 1: first entry of every bin (capacity follows the range's non-zero mass)
   const int32_t* range_lo;     // R + 1 feature boundaries
   const uint16_t* feat_range;  // p: range of every feature
+  const uint16_t* range_coarse;  // n_coarse + 1: range of feature c << coarse_shift (the last entry: R - 1) -- where the
+  int coarse_shift, n_coarse;    // binned gather's bisection for a feature's range starts (<= 2048 cells, staged in LDS)
   char* bins;                  // bin_off[R] entries {u32 draw, u32 feature, f64 value}
   unsigned* bin_count;         // R entries used (reset by the range's sweep)
   double* gcb;                 // batch x KS: gradient change of every draw of the batch

@@ -3098,6 +3098,10 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   int* rlo = reinterpret_cast<int*>(rbase + d.R);       // R + 1 range boundaries: the range of a feature
   const int K = d.K, KS = d.KS;                          // is found by bisection in LDS, not by a table
                                                          // look-up that costs an L2 request per non-zero
+  // ... and the bisection starts from a coarse table (round 4): the range of the first feature of the 2^shift-feature cell
+  // the feature lies in, and of the next cell's -- one or two steps instead of log2(R) dependent LDS reads
+  unsigned short* rcl = reinterpret_cast<unsigned short*>(rlo + d.R + 1);
+  const int cshift = d.coarse_shift;
   const int gl = threadIdx.x & (kGrp - 1);
   const int group = threadIdx.x / kGrp;
   const int lane = threadIdx.x & 63;
@@ -3107,6 +3111,7 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   PHASE(0);
   for (int r = threadIdx.x; r < d.R; r += kBinBlock) cnt[r] = 0u;
   for (int r = threadIdx.x; r <= d.R; r += kBinBlock) rlo[r] = d.range_lo[r];
+  for (int c = threadIdx.x; c <= d.n_coarse; c += kBinBlock) rcl[c] = d.range_coarse[c];
   if (threadIdx.x < kGrp) d0s[threadIdx.x] = 0.0;
   if (threadIdx.x == 0) {
     n_ent = 0u;
@@ -3115,13 +3120,12 @@ __global__ __launch_bounds__(kBinBlock) void saga_binned_gather_kernel(SagaDev d
   __syncthreads();
   const double bl = lane_on ? d.b[gl] - (d.standardize ? cw_sum(d, batch_id, gl) : 0.0) : 0.0;
   if (d.standardize) cw_clear_next(d, batch_id);
-  int bis_steps = 0;
-  while ((1 << bis_steps) < d.R) ++bis_steps;
   auto range_of = [&](int j) {
-    int a = 0, b = d.R;                       // rlo[a] <= j < rlo[b]
-    for (int it = 0; it < bis_steps; ++it) {
+    const int c = j >> cshift;
+    int a = rcl[c], b = rcl[c + 1] + 1;       // rlo[a] <= j < rlo[b]
+    while (b - a > 1) {
       const int mid = (a + b) >> 1;
-      if (mid > a && j >= rlo[mid]) a = mid; else if (mid > a) b = mid;
+      if (j >= rlo[mid]) a = mid; else b = mid;
     }
     return (unsigned)a;
   };
@@ -3489,7 +3493,8 @@ static GatherPlan plan_gather(const SagaDev& d, int m) {
     g.draws_per_block = kBinDraws;
     g.grid = (m + kBinDraws - 1) / kBinDraws;
     if (g.grid < 1) g.grid = 1;
-    g.lds_bytes = sizeof(BinEntry) * (size_t)kBinEntCap + sizeof(unsigned) * (3 * (size_t)d.R + 1);
+    g.lds_bytes = sizeof(BinEntry) * (size_t)kBinEntCap + sizeof(unsigned) * (3 * (size_t)d.R + 1) +
+                  ((sizeof(unsigned short) * ((size_t)d.n_coarse + 1) + 15) & ~size_t(15));
     return g;
   }
   const bool pays = (double)m * (double)d.avg_nnz >= 48.0 * (double)d.K * (double)d.p;

@@ -325,8 +325,17 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     d.range_max = wmax;
     int32_t* lo_dev = nullptr;
     uint16_t* fr_dev = nullptr;
+    uint16_t* rc_dev = nullptr;
+    // coarse cells of 2^shift features (at most 2047 of them): the range of a cell's first feature
+    int shift = 7;
+    while (((d.p + (1ll << shift) - 1) >> shift) + 1 > 2048) ++shift;
+    const int n_coarse = (int)((d.p + (1ll << shift) - 1) >> shift);
+    std::vector<uint16_t> rcv((size_t)n_coarse + 1);
+    for (int c = 0; c < n_coarse; ++c) rcv[(size_t)c] = fr[(size_t)c << shift];
+    rcv[(size_t)n_coarse] = (uint16_t)(R - 1);
     rc = dev_upload(s, &lo_dev, lo.data(), lo.size());
     if (!rc) rc = dev_upload(s, &fr_dev, fr.data(), fr.size());
+    if (!rc) rc = dev_upload(s, &rc_dev, rcv.data(), rcv.size());
     unsigned* bc = nullptr;
     int* be = nullptr;
     if (!rc) rc = dev_alloc(s, &bc, (size_t)R, true);
@@ -362,6 +371,9 @@ int ensure_binned(sgdnet_solver* s, int64_t batch) {
     d.R = R;
     d.range_lo = lo_dev;
     d.feat_range = fr_dev;
+    d.range_coarse = rc_dev;
+    d.coarse_shift = shift;
+    d.n_coarse = n_coarse;
     d.bin_count = bc;
     d.bin_err = be;
     if (getenv("SGDNET_TRACE")) fprintf(stderr, "[sgdnet]   binned form: %d feature ranges (<= %lld features each)\n", R, (long long)fmax);
